@@ -1,0 +1,121 @@
+"""ctypes binding of libbsi_hip.so (the C ABI declared in include/bsi_hip.h).
+
+There is NO fallback: if the library is missing or a tensor is not on a HIP device the
+functions raise.  torch is used only for device memory and the current stream.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libbsi_hip.so binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbsi_hip.so")
+
+_lib = None
+
+
+class BSIParams(C.Structure):
+    _fields_ = [("lambda_0", C.c_float), ("alpha_M", C.c_float), ("alpha_R", C.c_float),
+                ("ln_low", C.c_float), ("delta", C.c_float)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldw", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int),
+                ("gate", C.c_void_p), ("gate_rows", C.c_int), ("gate_stride", C.c_int),
+                ("tokens", C.c_int), ("pos", C.c_void_p)]
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("patch", C.c_int),
+                ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
+                ("ff_nmin", C.c_int), ("ff_nmax", C.c_int)]
+
+
+class DitBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("qkv_w", "out_w", "fc1_w", "fc2_w", "ada0_w", "ada2_w",
+                 "qkv_b", "out_b", "fc1_b", "fc2_b", "ada0_b", "ada2_b")]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [("enc_w", C.c_void_p), ("enc_b", C.c_void_p), ("pos", C.c_void_p),
+                ("t_scale", C.c_void_p), ("t_bias", C.c_void_p),
+                ("dec_ln_w", C.c_void_p), ("dec_ln_b", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p),
+                ("blocks", C.POINTER(DitBlockWeights))]
+
+
+EPI_BIAS_F32, EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SILU_BF16, EPI_GATE_RESID, EPI_BIAS_POS_F32 = range(6)
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_PROTOS = {
+    "bsi_version": (C.c_int, []),
+    "bsi_last_error": (C.c_char_p, []),
+    "bsi_edm_coeffs": (_i, [C.POINTER(BSIParams), _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_lambda_to_t": (_i, [C.POINTER(BSIParams), _vp, _i, _vp, _vp, _vp]),
+    "bsi_schedule": (_i, [C.POINTER(BSIParams), _vp, _i, _vp, _vp, _vp]),
+    "bsi_lambda_grid": (_i, [C.POINTER(BSIParams), _vp, _vp, _i, _vp, _vp]),
+    "bsi_q_sample": (_i, [C.POINTER(BSIParams), _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "bsi_sample_init": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "bsi_fourier_features": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_scale_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "bsi_predict_combine": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "bsi_predict_combine_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "bsi_refine_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "bsi_sqerr_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_sqerr_rows_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_recon_nll": (_i, [_vp, _vp, _f, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_to_uint8": (_i, [_vp, _f, _f, _sz, _vp, _vp]),
+    "bsi_cast_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "bsi_nyquist_embed": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "bsi_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "bsi_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
+    "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
+    "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),
+    "bsi_dit_adaln_scratch_bytes": (_sz, [C.POINTER(DitConfig), _i]),
+    "bsi_dit_adaln": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _vp, _i, _vp, _vp, _vp]),
+    "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
+                             _vp, _vp, _vp, _vp]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C bsi_amd/csrc)")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().bsi_last_error()
+        raise RuntimeError(f"bsi_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("bsi_amd: tensor is not on a HIP device; the native path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("bsi_amd: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

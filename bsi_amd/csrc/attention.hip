@@ -1,0 +1,216 @@
+// Non-causal softmax attention for gfx950 (replaces F.scaled_dot_product_attention at
+// bsi/models/dit.py:43-44 and bsi/nn/attention.py:18,38 of the reference).
+//
+// One workgroup = 8 waves = up to 256 queries of one (batch, head); each wave owns 32 queries.
+// K and V of a KC-key chunk live in LDS (row-major, XOR-swizzled); scores are computed TRANSPOSED
+// (S^T = K . Q^T) so that a lane holds one query column: the softmax row reduction is lane-local
+// plus two shuffles, and the S^T accumulators are, after a bf16 pack, directly the B operand of
+// O^T = V^T . P^T (no LDS round trip for P).  V^T fragments come from the row-major V tile through
+// ds_read_b64_tr_b16.  Online softmax over chunks makes the kernel independent of the sequence length
+// (DiT: 256 tokens = one chunk; UNet centre attention: 1024 positions, dh 128).
+#include "common.h"
+
+namespace {
+
+template <int DH>
+__device__ __forceinline__ int k_chunk_swz(int row, int chunk) {  // 16-B chunk index within a K row
+    if constexpr (DH == 64) return chunk ^ ((row >> 1) & 7);
+    else return chunk ^ (row & 15);
+}
+template <int DH>
+__device__ __forceinline__ int v_block_swz(int row, int blk) {  // 32-B block index within a V row
+    if constexpr (DH == 64) return blk ^ ((row >> 1) & 3);
+    else return blk ^ (row & 7);
+}
+
+template <int DH, int KC>
+__global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
+                                                            int heads, __bf16* __restrict__ out, int ld_out,
+                                                            float scale_log2e) {
+    constexpr int RB = DH * 2;        // bytes per K/V row
+    constexpr int KS = DH / 32;       // k-steps of the QK^T contraction
+    constexpr int KT = KC / 16;       // 16-key tiles per chunk
+    constexpr int DT = DH / 16;       // 16-wide d tiles of the output
+    constexpr int CPR = DH / 8;       // 16-B chunks per row
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Kl = lds;
+    char* Vl = lds + KC * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+    const bool active = q0 < tokens;
+    const int g = lane >> 4, c16 = lane & 15;
+
+    const __bf16* base = qkv + (size_t)b * tokens * ld_qkv + h * DH;
+    const __bf16* Qg = base;
+    const __bf16* Kg = base + heads * DH;
+    const __bf16* Vg = base + 2 * heads * DH;
+
+    // Q fragments (B operand): lane holds Q[q0 + 16jq + c16][32ks + 8g .. +7]
+    bf16x8 qf[2][KS];
+    if (active) {
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[jq][ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)(q0 + 16 * jq + c16) * ld_qkv + 32 * ks + 8 * g);
+    }
+
+    f32x4 o[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) o[dt][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < tokens; kc0 += KC) {
+        __syncthreads();  // previous chunk fully consumed
+        // ---- stage K and V chunk: KC rows x CPR chunks each, 512 threads ---------------------------
+        for (int idx = tid; idx < KC * CPR; idx += 512) {
+            const int r = idx / CPR, c = idx % CPR;
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kg + (size_t)(kc0 + r) * ld_qkv + c * 8);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vg + (size_t)(kc0 + r) * ld_qkv + c * 8);
+            *reinterpret_cast<u32x4*>(Kl + r * RB + k_chunk_swz<DH>(r, c) * 16) = kv;
+            *reinterpret_cast<u32x4*>(Vl + r * RB + (v_block_swz<DH>(r, c >> 1) * 2 + (c & 1)) * 16) = vv;
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // ---- S^T = K . Q^T : rows = keys, cols = queries --------------------------------------------
+        f32x4 s[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = 16 * kt + c16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + row * RB + k_chunk_swz<DH>(row, 4 * ks + g) * 16);
+                s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+                s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (per query column) -------------------------------------------------------
+        float alpha[2];
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][jq][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[jq], mx);
+            alpha[jq] = __builtin_amdgcn_exp2f((m_run[jq] - m_new) * scale_log2e);
+            m_run[jq] = m_new;
+            const float mb = m_new * scale_log2e;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
+                    s[kt][jq][r] = pv;
+                    ps += pv;
+                }
+            l_run[jq] = l_run[jq] * alpha[jq] + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][jq][r] *= alpha[jq];
+        }
+
+        // ---- O^T += V^T . P^T  over 32-key blocks ---------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < KC / 32; ++kb) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[jq][r] = (__bf16)s[2 * kb][jq][r];
+                    pf[jq][4 + r] = (__bf16)s[2 * kb + 1][jq][r];
+                }
+            }
+            // transposed V reads: in-group lane i = 4q'+p supplies &V[key0 + q'][16dt + 4p]
+            const int qp = c16 >> 2, pp = c16 & 3;
+            const int rowA = 32 * kb + 4 * g + qp;
+            const int rowB = rowA + 16;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int blk = dt >> 1;                      // 32-B block holding columns 16dt..16dt+15
+                const int inblk = (dt & 1) * 32 + pp * 8;     // byte offset inside the 64-B block pair... see below
+                // a 32-B block holds 16 bf16 columns: block index = dt (16 cols * 2 B = 32 B)
+                (void)blk; (void)inblk;
+                const int offA = rowA * RB + v_block_swz<DH>(rowA, dt) * 32 + pp * 8;
+                const int offB = rowB * RB + v_block_swz<DH>(rowB, dt) * 32 + pp * 8;
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vl + offA));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vl + offB));
+                union { bf16x8 v; s16x4 h[2]; } vf;
+                vf.h[0] = va;
+                vf.h[1] = vb;
+                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[0], o[dt][0], 0, 0, 0);
+                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[1], o[dt][1], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!active) return;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        float l = l_run[jq];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        __bf16* orow = out + ((size_t)b * tokens + q0 + 16 * jq + c16) * ld_out + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            u32x2 w;
+            w[0] = pack_bf16x2(o[dt][jq][0] * inv, o[dt][jq][1] * inv);
+            w[1] = pack_bf16x2(o[dt][jq][2] * inv, o[dt][jq][3] * inv);
+            *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) = w;
+        }
+    }
+}
+
+template <int DH, int KC>
+int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, hipStream_t s) {
+    const size_t lds = 2 * (size_t)KC * DH * 2;
+    auto kern = attention_fwd_kernel<DH, KC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+    dim3 grid((tokens + 255) / 256, B * heads);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e);
+    BSI_CHECK_LAUNCH("bsi_attention_fwd");
+    return BSI_OK;
+}
+
+}  // namespace
+
+extern "C" int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
+                                 int ld_out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(qkv && out && B > 0 && heads > 0, "bsi_attention_fwd: bad args");
+    BSI_CHECK_ARG(dh == 64 || dh == 128, "bsi_attention_fwd: head dim %d unsupported (64 or 128)", dh);
+    BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0, "bsi_attention_fwd: tokens=%d must be a multiple of 64", tokens);
+    BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_qkv >= 3 * heads * dh && ld_out % 4 == 0 && ld_out >= heads * dh,
+                  "bsi_attention_fwd: bad leading dimensions");
+    const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
+    __bf16* o = reinterpret_cast<__bf16*>(out);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dh == 64) {
+        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+        return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+    }
+    if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+    return launch_attn<128, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+}

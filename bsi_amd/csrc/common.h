@@ -1,0 +1,77 @@
+// Shared device/host helpers for the BSI gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bsi_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// Status/err plumbing: every C-ABI entry returns 0 on success, a negative BSI_E* code otherwise,
+// and records a message retrievable with bsi_last_error().
+void bsi_set_error(const char* fmt, ...);
+
+#define BSI_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            bsi_set_error(__VA_ARGS__);          \
+            return BSI_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+#define BSI_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            bsi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return BSI_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+
+// Round-to-nearest-even fp32 -> bf16 through the hardware conversion (keeps NaN a NaN).
+__device__ __forceinline__ __bf16 f32_to_bf16(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return *reinterpret_cast<unsigned int*>(&v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// tanh-approximated GELU, evaluated as torch does: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))).
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(1+exp(2u)); exp overflow -> +inf -> tanh = 1, underflow -> -1: both exact limits
+    float e = __expf(2.0f * inner);
+    float th = 1.0f - 2.0f / (1.0f + e);
+    return 0.5f * x * (1.0f + th);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -1,0 +1,345 @@
+// Memory-bound kernels around the DiT GEMMs (bsi/models/dit.py, bsi/models/pos_emb.py,
+// bsi/nn/fourier_features.py of the reference): weight shadow casts, sinusoidal embeddings,
+// LayerNorm+adaLN-modulate producer, the patchify/Fourier-feature prologue and the
+// LayerNorm+Linear(dim->patch*patch*C)+unpatchify+preconditioning epilogue.
+#include <math.h>
+
+#include "common.h"
+#include "dit_ops.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, int rows, int cols, __bf16* __restrict__ out, int ld) {
+    const int r = blockIdx.y;
+    const float* ir = in + (size_t)r * cols;
+    __bf16* orow = out + (size_t)r * ld;
+    for (int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4; c < ld; c += gridDim.x * blockDim.x * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (c + k < cols) ? ir[c + k] : 0.0f;
+        if (c + 3 < ld) {
+            u32x2 w;
+            w[0] = pack_bf16x2(v[0], v[1]);
+            w[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(orow + c) = w;
+        } else {
+            for (int k = 0; k < 4 && c + k < ld; ++k) orow[c + k] = (__bf16)v[k];
+        }
+    }
+}
+
+// pos_emb.py:84: torch.addcmul(bias, scale, t[..., None]).sin()  -> sin(fma(scale, t, bias))
+__global__ void nyquist_kernel(const float* __restrict__ t, int rows, const float* __restrict__ scale,
+                               const float* __restrict__ bias, int size, float* __restrict__ of, __bf16* __restrict__ ob) {
+    const int r = blockIdx.y;
+    const float tv = t[r];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < size; j += gridDim.x * blockDim.x) {
+        const float v = sinf(__fmaf_rn(scale[j], tv, bias[j]));
+        if (of) of[(size_t)r * size + j] = v;
+        if (ob) ob[(size_t)r * size + j] = (__bf16)v;
+    }
+}
+
+// One wave per row.  LayerNorm statistics in fp32 (two-pass over registers), then
+// out = fma(1 + scale, (x - mean) * rstd, shift)   (dit.py:50-55: addcmul(shift, scale + 1, norm(x)))
+// or, without modulation, the affine LayerNorm  normed * w + b  (dit.py:163).
+template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
+__global__ void ln_modulate_kernel(const float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
+                                   const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
+                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                   __bf16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * d;
+    const int d4 = d >> 2;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dd = v[i][k] - mean;
+                q = __fmaf_rn(dd, dd, q);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    const int mrow = shift ? (row / tokens) % mod_rows : 0;
+    const float* sh = shift ? shift + (size_t)mrow * mod_stride : nullptr;
+    const float* sc = scale ? scale + (size_t)mrow * mod_stride : nullptr;
+    __bf16* orow = out + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd;
+            if (sh) {
+                const f32x4 a = reinterpret_cast<const f32x4*>(sh)[c];
+                const f32x4 b = reinterpret_cast<const f32x4*>(sc)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = __fmaf_rn(b[k] + 1.0f, y[k], a[k]);
+            } else if (ln_w) {
+                const f32x4 a = reinterpret_cast<const f32x4*>(ln_w)[c];
+                const f32x4 b = reinterpret_cast<const f32x4*>(ln_b)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = __fmaf_rn(y[k], a[k], b[k]);
+            }
+            u32x2 w;
+            w[0] = pack_bf16x2(y[0], y[1]);
+            w[1] = pack_bf16x2(y[2], y[3]);
+            reinterpret_cast<u32x2*>(orow)[c] = w;
+        }
+    }
+}
+
+// fourier_features.py:21-36 standalone: x [outer, C, inner] -> out [outer, C*nfreq*2, inner],
+// channel (c*nfreq + n)*2 + o holds sin(offset_o + coef_n * x[c]).
+__global__ void fourier_features_kernel(const float* __restrict__ x, size_t total, int C, int inner, int nmin,
+                                        int nfreq, float* __restrict__ out) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t in_i = idx % inner;
+        const size_t oc = idx / inner;  // outer*C + c
+        const float v = x[idx];
+        float* o = out + (oc * nfreq * 2) * inner + in_i;
+        for (int n = 0; n < nfreq; ++n) {
+            const float coef = 6.283185307179586f * (float)(1 << (nmin + n));
+            o[(size_t)(n * 2 + 0) * inner] = sinf(__fmaf_rn(coef, v, 0.0f));
+            o[(size_t)(n * 2 + 1) * inner] = sinf(__fmaf_rn(coef, v, 1.5707963267948966f));
+        }
+    }
+}
+
+// dit.py:225-231 + fourier_features.py:21-36 + dit.py:149-153 (+ bsi.py:385 input scaling):
+// one thread per pixel: v_c = c_in*mu[b,c,h,w]; features [v_0..v_{C-1}, sin(off + coef_n*v_c) ...] written as
+// bf16 at token (h/ps, w/ps), columns ((h%ps)*ps + (w%ps))*Cin + channel.  Columns K..Kpad are zeroed.
+__global__ void dit_prologue_kernel(const float* __restrict__ mu, const float* __restrict__ c_in, int coef_stride, int B,
+                                    int C, int H, int W, int ps, int nmin, int nfreq, int kpad, __bf16* __restrict__ out) {
+    const int HW = H * W;
+    const size_t total = (size_t)B * HW;
+    const int Cin = C + C * nfreq * 2;
+    const int nw = W / ps;
+    const int tokens = (H / ps) * nw;
+    const int K = ps * ps * Cin;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / HW);
+        const int pix = (int)(idx % HW);
+        const int h = pix / W, w = pix % W;
+        const float ci = c_in ? c_in[(size_t)b * coef_stride] : 1.0f;
+        const int tok = (h / ps) * nw + (w / ps);
+        const int intra = (h % ps) * ps + (w % ps);
+        __bf16* o = out + ((size_t)b * tokens + tok) * kpad + intra * Cin;
+        for (int c = 0; c < C; ++c) {
+            float v = mu[((size_t)b * C + c) * HW + pix];
+            if (c_in) v = __fmul_rn(ci, v);
+            o[c] = (__bf16)v;
+            for (int n = 0; n < nfreq; ++n) {
+                // coefs = 2*pi*2^n as an fp32 buffer (fourier_features.py:18); arg = addcmul(offset, coef, x)
+                const float coef = 6.283185307179586f * (float)(1 << (nmin + n));
+                o[C + (c * nfreq + n) * 2 + 0] = (__bf16)sinf(__fmaf_rn(coef, v, 0.0f));
+                o[C + (c * nfreq + n) * 2 + 1] = (__bf16)sinf(__fmaf_rn(coef, v, 1.5707963267948966f));
+            }
+        }
+        if (intra == ps * ps - 1) {
+            __bf16* z = out + ((size_t)b * tokens + tok) * kpad;
+            for (int c = K; c < kpad; ++c) z[c] = (__bf16)0.0f;
+        }
+    }
+}
+
+// dit.py:163-172,181 (+ bsi.py:382-386): per token LayerNorm(affine) -> Linear(dim -> P=ps*ps*C) in fp32 ->
+// unpatchify -> x_hat = fma(c_out, f, c_skip*mu).  dec_w (P x dim fp32) is staged in LDS once per workgroup;
+// each wave walks tokens with a grid stride.
+template <int VPL>
+__global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, int P, const float* __restrict__ ln_w,
+                                 const float* __restrict__ ln_b, const float* __restrict__ dec_w,
+                                 const float* __restrict__ dec_b, int C, int H, int W, int ps,
+                                 const float* __restrict__ mu, const float* __restrict__ c_skip,
+                                 const float* __restrict__ c_out, int coef_stride, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // [P][d]
+    const int d4 = d >> 2;
+    for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
+        reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int nw = W / ps;
+    const int tokens = (H / ps) * nw;
+    const int HW = H * W;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Mtok; row += gridDim.x * wpb) {
+        const float* xr = x + (size_t)row * d;
+        f32x4 v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = v[i][k] - mean;
+                    q = __fmaf_rn(dd, dd, q);
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                const f32x4 a = reinterpret_cast<const f32x4*>(ln_w)[c];
+                const f32x4 b = reinterpret_cast<const f32x4*>(ln_b)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = __fmaf_rn((v[i][k] - mean) * rstd, a[k], b[k]);
+            }
+        }
+        const int b_idx = row / tokens, tok = row % tokens;
+        const int th = tok / nw, tw = tok % nw;
+        float mine = 0.f;
+        for (int o = 0; o < P; ++o) {  // P <= 64: lane o keeps output o
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+                    const f32x4 wv = reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = __fmaf_rn(v[i][k], wv[k], acc);
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == o) mine = acc + dec_b[o];
+        }
+        if (lane < P) {
+            const int intra = lane / C, ch = lane % C;
+            const int hh = th * ps + intra / ps, ww = tw * ps + intra % ps;
+            const size_t gi = ((size_t)b_idx * C + ch) * HW + (size_t)hh * W + ww;
+            float r = mine;
+            if (c_skip) {
+                const float cs = c_skip[(size_t)b_idx * coef_stride], co = c_out[(size_t)b_idx * coef_stride];
+                r = __fmaf_rn(co, mine, __fmul_rn(cs, mu[gi]));
+            }
+            out[gi] = r;
+        }
+    }
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int bsi_cast_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_out >= cols && ld_out % 4 == 0,
+                  "bsi_cast_bf16: bad args rows=%d cols=%d ld=%d", rows, cols, ld_out);
+    int gx = (ld_out / 4 + TPB - 1) / TPB;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(gx, rows), dim3(TPB), 0, S(stream), in, rows, cols,
+                       reinterpret_cast<__bf16*>(out), ld_out);
+    BSI_CHECK_LAUNCH("bsi_cast_bf16");
+    return BSI_OK;
+}
+
+extern "C" int bsi_fourier_features(const float* x, int outer, int C, int inner, int n_min, int n_max, float* out,
+                                    bsi_stream_t stream) {
+    BSI_CHECK_ARG(x && out && outer > 0 && C > 0 && inner > 0 && n_max >= n_min && n_min >= 0 && n_max < 31,
+                  "bsi_fourier_features: bad args");
+    const size_t total = (size_t)outer * C * inner;
+    size_t g = (total + TPB - 1) / TPB;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fourier_features_kernel, dim3((int)g), dim3(TPB), 0, S(stream), x, total, C, inner, n_min,
+                       n_max - n_min + 1, out);
+    BSI_CHECK_LAUNCH("bsi_fourier_features");
+    return BSI_OK;
+}
+
+extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, const float* bias, int size,
+                                 float* out_f32, void* out_bf16, bsi_stream_t stream) {
+    BSI_CHECK_ARG(t && scale && bias && rows > 0 && size > 0 && (out_f32 || out_bf16), "bsi_nyquist_embed: bad args");
+    int gx = (size + TPB - 1) / TPB;
+    hipLaunchKernelGGL(nyquist_kernel, dim3(gx, rows), dim3(TPB), 0, S(stream), t, rows, scale, bias, size, out_f32,
+                       reinterpret_cast<__bf16*>(out_bf16));
+    BSI_CHECK_LAUNCH("bsi_nyquist_embed");
+    return BSI_OK;
+}
+
+extern "C" int bsi_ln_modulate(const float* x, int M, int d, float eps, const float* shift, const float* scale,
+                               int mod_rows, int mod_stride, int tokens, const float* ln_w, const float* ln_b,
+                               void* out_bf16, bsi_stream_t stream) {
+    BSI_CHECK_ARG(x && out_bf16 && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_ln_modulate: bad args M=%d d=%d", M, d);
+    BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_ln_modulate: shift and scale go together");
+    BSI_CHECK_ARG(!shift || (mod_rows > 0 && tokens > 0 && mod_stride % 4 == 0), "bsi_ln_modulate: bad modulation table");
+    BSI_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "bsi_ln_modulate: ln weight and bias go together");
+    const int wpb = TPB / 64;
+    dim3 grid((M + wpb - 1) / wpb);
+    __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
+    if (d <= 256)
+        hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
+                           mod_stride, tokens, ln_w, ln_b, o);
+    else if (d <= 1024)
+        hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
+                           mod_stride, tokens, ln_w, ln_b, o);
+    else
+        hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
+                           mod_stride, tokens, ln_w, ln_b, o);
+    BSI_CHECK_LAUNCH("bsi_ln_modulate");
+    return BSI_OK;
+}
+
+int bsi_dit_prologue_launch(const float* mu, const float* c_in, int coef_stride, int B, int C, int H, int W, int ps,
+                            int nmin, int nfreq, int kpad, void* out, hipStream_t s) {
+    const size_t total = (size_t)B * H * W;
+    size_t g = (total + TPB - 1) / TPB;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(dit_prologue_kernel, dim3((int)g), dim3(TPB), 0, s, mu, c_in, coef_stride, B, C, H, W, ps, nmin,
+                       nfreq, kpad, reinterpret_cast<__bf16*>(out));
+    BSI_CHECK_LAUNCH("bsi_dit_prologue");
+    return BSI_OK;
+}
+
+int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
+                         const float* dec_w, const float* dec_b, int C, int H, int W, int ps, const float* mu,
+                         const float* c_skip, const float* c_out, int coef_stride, float* out, hipStream_t s) {
+    const size_t lds = (size_t)P * d * sizeof(float);
+    if (lds > 160 * 1024 || P > 64) {
+        bsi_set_error("bsi_dit_final: decoder P=%d d=%d unsupported (needs P <= 64 and P*d*4 <= 160 KiB)", P, d);
+        return BSI_EINVAL;
+    }
+    const int wpb = TPB / 64;
+    int grid = (Mtok + wpb * 8 - 1) / (wpb * 8);  // ~8 tokens per wave amortise the LDS fill
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+#define LAUNCH_FINAL(V)                                                                                              \
+    do {                                                                                                             \
+        auto kern = dit_final_kernel<V>;                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, ln_w, ln_b, dec_w, dec_b, C, H, W, ps, \
+                           mu, c_skip, c_out, coef_stride, out);                                                     \
+    } while (0)
+    if (d <= 256) LAUNCH_FINAL(1);
+    else if (d <= 1024) LAUNCH_FINAL(4);
+    else LAUNCH_FINAL(8);
+#undef LAUNCH_FINAL
+    BSI_CHECK_LAUNCH("bsi_dit_final");
+    return BSI_OK;
+}

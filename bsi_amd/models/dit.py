@@ -1,0 +1,210 @@
+"""Mirror of bsi/models/dit.py:26-233 (Attention, DiTBlock, DiT, DenoisingDiT) on the native DiT engine.
+
+The module tree, constructor signatures, parameter names/shapes and non-persistent buffers are those
+of the reference, so `state_dict`s interchange.  The torch submodules only HOLD the
+fp32 parameters; `forward` runs `bsi_dit_adaln` + `bsi_dit_forward` (include/bsi_hip.h): bf16 MFMA GEMMs
+with fused epilogues, fused attention, fp32 residual stream.  No torch compute op is on the path.
+"""
+import ctypes as C
+from functools import partial
+
+import torch
+from torch import Tensor, nn
+
+from .. import _native as N
+from ..nn import FourierFeatures
+from .pos_emb import NyquistPositionalEmbedding
+
+
+class Attention(nn.Module):
+    """Parameter holder for dit.py:26-47 (`to_qkv`, `to_out`); rows of to_qkv are ordered (qkv, head, channel)."""
+
+    def __init__(self, dim: int, *, heads: int, dropout: float = 0.0):
+        super().__init__()
+        self.heads = heads
+        self.dropout = dropout
+        self.to_qkv = nn.Linear(dim, dim * 3)
+        self.to_out = nn.Linear(dim, dim)
+
+
+class DiTBlock(nn.Module):
+    """Parameter holder for dit.py:58-103 (adaLN-Zero block with the extra Linear before SiLU)."""
+
+    def __init__(self, size: int, heads: int, mlp_ratio: int = 4, dropout: float | None = None):
+        super().__init__()
+        self.norm = nn.LayerNorm(size, elementwise_affine=False)
+        self.attn = Attention(size, heads=heads, dropout=dropout if dropout is not None else 0.0)
+        self.dropout = nn.Dropout(dropout) if dropout is not None else nn.Identity()
+        # bsi.nn.MLP(in, out, hidden_features=[4*size], actfn=GELU(tanh)) is nn.Sequential(Linear, GELU, Linear)
+        self.mlp = nn.Sequential(nn.Linear(size, mlp_ratio * size), nn.GELU(approximate="tanh"),
+                                 nn.Linear(mlp_ratio * size, size))
+        self.adaLN_modulation = nn.Sequential(nn.Linear(size, size), nn.SiLU(), nn.Linear(size, 6 * size))
+        nn.init.constant_(self.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.adaLN_modulation[-1].bias, 0)
+
+
+class DiT(nn.Module):
+    """Parameter/buffer holder for dit.py:106-181."""
+
+    def __init__(self, input_size, patch_size: int, in_channels: int, out_channels: int, hidden_size: int,
+                 depth: int, heads: int, mlp_ratio: int, dropout: float | None):
+        super().__init__()
+        self.input_size = tuple(input_size)
+        self.patch_size = patch_size
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        height, width = input_size
+        patch_area = patch_size**2
+        patches_h = height // patch_size
+        patches_w = width // patch_size
+
+        # fixed Fourier positional embeddings (dit.py:135-146), built on the host at construction
+        pe = NyquistPositionalEmbedding(hidden_size // 2, max(height, width))
+
+        def table(pos):
+            return torch.addcmul(pe.bias, pe.scale, pos[..., None]).sin()
+
+        pos_h = table(torch.linspace(0, 1, patches_h))
+        pos_w = table(torch.linspace(0, 1, patches_w))
+        pos_embs = torch.cat((pos_h.repeat_interleave(patches_w, dim=0), pos_w.repeat(patches_h, 1)), dim=1)
+        self.register_buffer("patch_pos_embedding", pos_embs, persistent=False)
+        self.t_embedding = NyquistPositionalEmbedding(hidden_size, 1000)
+
+        self.patch_encoder = nn.Linear(patch_area * in_channels, hidden_size)
+        self.blocks = nn.ModuleList(
+            [DiTBlock(hidden_size, heads, mlp_ratio=mlp_ratio, dropout=dropout) for _ in range(depth)])
+        self.patch_decoder = nn.Sequential(nn.LayerNorm(hidden_size), nn.Linear(hidden_size, patch_area * out_channels))
+
+
+class DenoisingDiT(nn.Module):
+    """Diffusion Transformer denoiser f(mu, t) — same constructor as bsi.models.dit.DenoisingDiT."""
+
+    def __init__(self, data_shape, patch_size: int, dim: int, depth: int, heads: int, dropout: float | None = None,
+                 fourier_features: FourierFeatures | None = None, **kwargs):
+        super().__init__()
+        self.data_shape = tuple(data_shape)
+        self.fourier_features = fourier_features
+        assert len(self.data_shape) == 3, "Only works for 2D images"
+        n_channels = data_shape[0]
+        in_channels = out_channels = n_channels
+        if fourier_features is not None:
+            in_channels += n_channels * fourier_features.n_features()
+        self.dit = DiT(input_size=data_shape[1:], patch_size=patch_size, in_channels=in_channels,
+                       out_channels=out_channels, hidden_size=dim, depth=depth, heads=heads, mlp_ratio=4,
+                       dropout=dropout)
+        self._cfg_args = dict(patch=patch_size, dim=dim, depth=depth, heads=heads)
+        self._pack = None       # cached bf16 weight shadows + ctypes tables
+        self._pack_key = None
+        self._ws = None         # cached workspace tensor
+
+    # ------------------------------------------------------------------------------------------------
+    # native plumbing
+    # ------------------------------------------------------------------------------------------------
+    def _config(self) -> N.DitConfig:
+        Cc, H, W = self.data_shape
+        ff = self.fourier_features
+        a = self._cfg_args
+        return N.DitConfig(Cc, H, W, a["patch"], a["dim"], a["depth"], a["heads"],
+                           ff.n_min if ff is not None else 1, ff.n_max if ff is not None else 0)
+
+    def _weights_key(self):
+        ps = list(self.parameters())
+        return (ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))
+
+    def native_pack(self):
+        """bf16 [N][K] shadows of the GEMM weights + the ctypes weight table; rebuilt only when a parameter
+        changed (optimizer step / load_state_dict)."""
+        key = self._weights_key()
+        if self._pack is not None and self._pack_key == key:
+            return self._pack
+        lib = N.lib()
+        dev = self.dit.patch_encoder.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("bsi_amd.DenoisingDiT: parameters must live on a HIP device (no CPU path)")
+        cfg = self._config()
+        kpad = lib.bsi_dit_kpad(C.byref(cfg))
+        keep = []
+
+        def shadow(w: Tensor, ld=None):
+            w = w.detach().contiguous()
+            rows, cols = w.shape
+            ld = ld or cols
+            out = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+            N.check(lib.bsi_cast_bf16(N.ptr(w), rows, cols, N.ptr(out), ld, N.stream()))
+            keep.append(out)
+            return out.data_ptr()
+
+        def f32(p: Tensor):
+            t = p.detach().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        blocks = (N.DitBlockWeights * cfg.depth)()
+        for i, blk in enumerate(self.dit.blocks):
+            b = blocks[i]
+            b.qkv_w, b.qkv_b = shadow(blk.attn.to_qkv.weight), f32(blk.attn.to_qkv.bias)
+            b.out_w, b.out_b = shadow(blk.attn.to_out.weight), f32(blk.attn.to_out.bias)
+            b.fc1_w, b.fc1_b = shadow(blk.mlp[0].weight), f32(blk.mlp[0].bias)
+            b.fc2_w, b.fc2_b = shadow(blk.mlp[2].weight), f32(blk.mlp[2].bias)
+            b.ada0_w, b.ada0_b = shadow(blk.adaLN_modulation[0].weight), f32(blk.adaLN_modulation[0].bias)
+            b.ada2_w, b.ada2_b = shadow(blk.adaLN_modulation[2].weight), f32(blk.adaLN_modulation[2].bias)
+        w = N.DitWeights()
+        w.enc_w, w.enc_b = shadow(self.dit.patch_encoder.weight, kpad), f32(self.dit.patch_encoder.bias)
+        w.pos = f32(self.dit.patch_pos_embedding)
+        w.t_scale, w.t_bias = f32(self.dit.t_embedding.scale), f32(self.dit.t_embedding.bias)
+        w.dec_ln_w, w.dec_ln_b = f32(self.dit.patch_decoder[0].weight), f32(self.dit.patch_decoder[0].bias)
+        w.dec_w, w.dec_b = f32(self.dit.patch_decoder[1].weight), f32(self.dit.patch_decoder[1].bias)
+        w.blocks = C.cast(blocks, C.POINTER(N.DitBlockWeights))
+        self._pack = (cfg, w, blocks, keep)
+        self._pack_key = key
+        return self._pack
+
+    def _workspace(self, nbytes: int, dev):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def adaln_table(self, t: Tensor) -> Tensor:
+        """adaLN modulation rows for the times `t` ([R] fp32): returns fp32 [R, depth, 6*dim]
+        (dit.py:77-81,90-92 for every block).  Depends only on t, so `BSI.sample` builds it once for the
+        whole schedule."""
+        cfg, w, _, _ = self.native_pack()
+        lib = N.lib()
+        t = t.detach().to(torch.float32).contiguous()
+        R = t.numel()
+        mod = torch.empty((R, cfg.depth, 6 * cfg.dim), dtype=torch.float32, device=t.device)
+        scratch = torch.empty(lib.bsi_dit_adaln_scratch_bytes(C.byref(cfg), R), dtype=torch.uint8, device=t.device)
+        N.check(lib.bsi_dit_adaln(C.byref(cfg), C.byref(w), N.ptr(t), R, N.ptr(mod), N.ptr(scratch), N.stream()))
+        return mod
+
+    def forward_native(self, mu: Tensor, mod: Tensor, *, c_in=None, c_skip=None, c_out=None, coef_stride=1,
+                       out: Tensor | None = None, return_tokens: bool = False):
+        """One engine call: out = c_skip*mu + c_out*f(c_in*mu) (or f(mu) without coefficients).
+        `mod`: [1 or B, depth, 6*dim] rows of `adaln_table`."""
+        cfg, w, _, _ = self.native_pack()
+        lib = N.lib()
+        if mu.dtype != torch.float32:
+            raise RuntimeError("bsi_amd.DenoisingDiT: input must be fp32 (bf16 is used inside the kernels)")
+        mu = mu.contiguous()
+        B = mu.shape[0]
+        assert tuple(mu.shape[1:]) == self.data_shape, f"expected [B,{self.data_shape}], got {tuple(mu.shape)}"
+        if out is None:
+            out = torch.empty_like(mu)
+        ws = self._workspace(lib.bsi_dit_workspace_bytes(C.byref(cfg), B), mu.device)
+        tokens = None
+        if return_tokens:
+            tokens = torch.empty((B * lib.bsi_dit_tokens(C.byref(cfg)), cfg.dim), dtype=torch.float32, device=mu.device)
+        N.check(lib.bsi_dit_forward(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(mod), mod.shape[0],
+                                    N.ptr(c_in), N.ptr(c_skip), N.ptr(c_out), coef_stride, N.ptr(out), N.ptr(ws),
+                                    N.ptr(tokens), N.stream()))
+        return (out, tokens) if return_tokens else out
+
+    def forward(self, mu: Tensor, t: Tensor) -> Tensor:
+        """f(mu, t): mu [B, *data_shape] fp32, t [B] in [0, 1]  (dit.py:225-233)."""
+        if not mu.is_cuda:
+            raise RuntimeError("bsi_amd.DenoisingDiT: input is not on a HIP device; there is no CPU path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .dit_train import dit_forward_autograd  # backward kernels live in the training engine
+            return dit_forward_autograd(self, mu, t)
+        mod = self.adaln_table(t)
+        return self.forward_native(mu, mod)

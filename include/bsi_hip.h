@@ -1,0 +1,230 @@
+/* bsi_hip.h — C ABI of the MI355X-native BSI hot path (libbsi_hip.so).
+ *
+ * The reference (martenlienen/bsi) has no FFI: its hot path is the Python surface
+ * bsi.bsi.BSI + bsi.models.{dit,vdm_unet} executing torch ops.  This header declares the
+ * native entry points the Python mirror (bsi_amd/) binds with ctypes; each entry cites the
+ * reference lines it replaces.  Conventions:
+ *   - plain pointers and sizes; all pointers are DEVICE pointers unless marked `host`;
+ *   - fp32 tensors are `float*`, bf16 tensors are `void*` (raw bfloat16 bits);
+ *   - the library allocates nothing persistent: callers pass outputs and workspaces;
+ *   - every call enqueues on `stream` (a hipStream_t; NULL = the default stream) and returns
+ *     immediately; no host synchronisation happens inside;
+ *   - return value 0 = ok, negative = error (message via bsi_last_error()); never aborts.
+ */
+#ifndef BSI_HIP_H
+#define BSI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bsi_stream_t; /* hipStream_t */
+
+enum {
+    BSI_OK = 0,
+    BSI_EINVAL = -1,       /* bad argument / unsupported shape */
+    BSI_ELAUNCH = -2,      /* HIP launch error */
+    BSI_EUNSUPPORTED = -3, /* feature not built */
+};
+
+int bsi_version(void);
+const char* bsi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * BSI algorithm wrapper — bsi/bsi.py
+ * ---------------------------------------------------------------------------------------- */
+
+/* LogUniform constants held by BSI.p_lambda (bsi.py:67-84,135): ln_low = log(float(lambda_0)),
+ * delta = log(float(lambda_0 + alpha_M)) - ln_low, both Python doubles in the reference and cast
+ * to fp32 when they meet an fp32 tensor. */
+typedef struct bsi_params {
+    float lambda_0;
+    float alpha_M;
+    float alpha_R;
+    float ln_low; /* (float)ln_low  */
+    float delta;  /* (float)delta   */
+} bsi_params;
+
+/* bsi.py:390-403 (_edm_preconditioning) with bsi.py:83-84 (icdf): for every t[i]
+ *   lam = exp(delta*t + ln_low); alpha = lam - lambda_0; kappa = 1 + alpha*(alpha/lam);
+ *   c_skip = alpha/kappa; c_out = rsqrt(kappa); c_in = sqrt(lam/kappa).
+ * Any output pointer may be NULL. */
+int bsi_edm_coeffs(const bsi_params* p /*host*/, const float* t, int n, float* lam, float* c_skip,
+                   float* c_out, float* c_in, bsi_stream_t stream);
+
+/* bsi.py:80-81 / 76-78: t = cdf(lam) = (log(lam) - ln_low)/delta and w = lam*delta (reciprocal pdf). */
+int bsi_lambda_to_t(const bsi_params* p /*host*/, const float* lam, int n, float* t, float* rpdf,
+                    bsi_stream_t stream);
+
+/* bsi.py:322-323 (sample), 352-353, 261-262: lam[i] = icdf(t[i]) (i < k1), alpha[i] = lam[i+1]-lam[i]. */
+int bsi_schedule(const bsi_params* p /*host*/, const float* t, int k1, float* lam, float* alpha,
+                 bsi_stream_t stream);
+
+/* bsi.py:422-440 (_sample_lambda, low-discrepancy branch): t = (perm/(1+total) + offset) mod 1,
+ * lam = icdf(t).  perm: int64[total], offset: device scalar. */
+int bsi_lambda_grid(const bsi_params* p /*host*/, const int64_t* perm, const float* offset, int total,
+                    float* lam, bsi_stream_t stream);
+
+/* bsi.py:405-420 (_sample_q_mu_lambda): mu[r] = ((lam[r]-lambda_0)/lam[r]) * x[r % B] + rsqrt(lam[r]) * eps[r],
+ * r < rows (rows = n_samples*B), each row D floats. */
+int bsi_q_sample(const bsi_params* p /*host*/, const float* x, const float* lam, const float* eps, int rows,
+                 int B, int D, float* mu, bsi_stream_t stream);
+
+/* bsi.py:325 / 356: mu_0[r] = rsqrt(lam[0]) * eps0[r]  (start of the sampling chain; lam = bsi_schedule output). */
+int bsi_sample_init(const float* eps0, const float* lam, int rows, int D, float* mu, bsi_stream_t stream);
+
+/* bsi.py:385: out[r] = c[r*c_stride] * mu[r]  (the c_in * mu input scaling for a generic denoiser). */
+int bsi_scale_rows(const float* mu, const float* c, int c_stride, int rows, int D, float* out,
+                   bsi_stream_t stream);
+
+/* bsi.py:382-386: x_hat = c_skip*mu + c_out*f (torch.addcmul). c_* indexed [r*c_stride]. */
+int bsi_predict_combine(const float* mu, const float* f, const float* c_skip, const float* c_out,
+                        int c_stride, int rows, int D, float* x_hat, bsi_stream_t stream);
+/* backward of the above w.r.t. f (and optionally mu): g_f = c_out*g, g_mu = c_skip*g. */
+int bsi_predict_combine_bwd(const float* g, const float* c_skip, const float* c_out, int c_stride, int rows,
+                            int D, float* g_f, float* g_mu /*nullable*/, bsi_stream_t stream);
+
+/* bsi.py:331-335 / 364-368: one measure/refine step of Algorithm 3 for `rows` images of D floats:
+ *   x_hat = c_skip*mu + c_out*f        (skipped when f_is_xhat != 0: f already holds x_hat)
+ *   y     = x_hat + rsqrt(alpha[i]) * eps
+ *   mu'   = (alpha[i]*y + lam[i]*mu) / lam[i+1]
+ * lam/alpha/c_skip/c_out are the device vectors of bsi_schedule / bsi_edm_coeffs over the schedule,
+ * `i` the step index.  x_hat_out / y_out may be NULL (history capture of sample_history). */
+int bsi_refine_step(const float* mu, const float* f, const float* eps, const float* lam, const float* alpha,
+                    const float* c_skip, const float* c_out, int i, int f_is_xhat, int rows, int D,
+                    float* x_hat_out, float* y_out, float* mu_next, bsi_stream_t stream);
+
+/* bsi.py:309-310, 273-274, 288-289: out[r] = w[r] * scale * reduce_D((x[r % B] - x_hat[r])^2),
+ * reduce = mean if mean != 0 else sum.  diff_out (nullable) receives x - x_hat for the backward. */
+int bsi_sqerr_rows(const float* x, const float* x_hat, const float* w, float scale, int mean, int rows,
+                   int B, int D, float* out, bsi_stream_t stream);
+/* gradient of the above w.r.t. x_hat: g_xhat[r] = -2 * g[r] * w[r] * scale * (x - x_hat) / (mean ? D : 1). */
+int bsi_sqerr_rows_bwd(const float* x, const float* x_hat, const float* w, const float* g, float scale,
+                       int mean, int rows, int B, int D, float* g_xhat, bsi_stream_t stream);
+
+/* bsi.py:230-247 (reconstruction_loss): Normal(x_hat, alpha_R^-1/2) integrated over the bin of x.
+ * bounds: device vector of the k+1 bin boundaries (Discretization.bin_boundaries, bsi.py:29-30, built by the
+ * caller with torch.linspace exactly as the reference does); bucket index = clamp(trunc((x - lo_edge)/dx), 0, k-1)
+ * with lo_edge = min - dx/2 (bsi.py:32-35); outer bins are open (bsi.py:241-242), floor 1e-20 (244).
+ * k == 0 (bounds NULL): continuous -log N(x; x_hat, 1/alpha_R) (bsi.py:235).  out[r] = -sum_D log p. */
+int bsi_recon_nll(const float* x, const float* x_hat, float alpha_R, const float* bounds, float lo_edge, float dx,
+                  int k, int rows, int B, int D, float* out, bsi_stream_t stream);
+
+/* bsi.py:41-48 (Discretization.to_8bit_image) on device: uint8 = clamp(((x-lo)/(hi-lo))*255, 0, 255). */
+int bsi_to_uint8(const float* x, float lo, float hi, size_t n, uint8_t* out, bsi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks of the denoisers — bsi/models/dit.py, bsi/models/pos_emb.py, bsi/nn
+ * ---------------------------------------------------------------------------------------- */
+
+/* fp32 -> bf16 (round to nearest even); used to refresh the bf16 weight shadows.
+ * Copies `rows` rows of `cols` floats into rows of `ld_out` bf16 (zero-filling cols..ld_out). */
+int bsi_cast_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream);
+
+/* fourier_features.py:21-36 (FourierFeatures.forward): x fp32 viewed as [outer, C, inner] ->
+ * out [outer, C*nf*2, inner], nf = n_max-n_min+1, channel (c*nf + n)*2 + o = sin(o*pi/2 + fl32(2*pi*2^n) * x[c]). */
+int bsi_fourier_features(const float* x, int outer, int C, int inner, int n_min, int n_max, float* out,
+                         bsi_stream_t stream);
+
+/* pos_emb.py:78-84: out[r, j] = sin(bias[j] + scale[j]*t[r]) (fp32, accurate sin). out_bf16 nullable. */
+int bsi_nyquist_embed(const float* t, int rows, const float* scale, const float* bias, int size,
+                      float* out_f32, void* out_bf16, bsi_stream_t stream);
+
+/* GEMM  C[M,N] = A[M,K] . W[N,K]^T  with bf16 operands, fp32 accumulation (MFMA 16x16x32) and a fused
+ * epilogue.  Replaces every nn.Linear of the DiT (dit.py:33-34,71-81,154,163-165; mlp.py:34-38).
+ * K % 64 == 0, N % 16 == 0, lda/ldw in elements (multiples of 8). */
+enum {
+    BSI_EPI_BIAS_F32 = 0,       /* out_f32[m,n] = acc + bias[n]                                       */
+    BSI_EPI_BIAS_BF16 = 1,      /* out_bf16[m,n] = bf16(acc + bias[n])                                */
+    BSI_EPI_BIAS_GELU_BF16 = 2, /* out_bf16 = bf16(gelu_tanh(acc + bias))           (mlp.0, dit.py:71-76) */
+    BSI_EPI_BIAS_SILU_BF16 = 3, /* out_bf16 = bf16(silu(acc + bias))       (adaLN_modulation.0-1, :79-81) */
+    BSI_EPI_GATE_RESID = 4,     /* out_f32[m,n] += gate[row(m), n] * (acc + bias[n])    (dit.py:93-102) */
+    BSI_EPI_BIAS_POS_F32 = 5,   /* out_f32[m,n] = acc + bias[n] + pos[m % tokens, n]     (dit.py:178)  */
+};
+typedef struct bsi_gemm_args {
+    const void* A;  /* bf16 [M, lda] */
+    const void* W;  /* bf16 [N, ldw] */
+    const float* bias; /* [N] or NULL */
+    void* out;      /* f32 or bf16 [M, ldo] */
+    int M, N, K;
+    int lda, ldw, ldo;
+    int epilogue;
+    /* GATE_RESID: gate value for row m is gate[(m / tokens) % gate_rows * gate_stride + n] */
+    const float* gate;
+    int gate_rows, gate_stride;
+    int tokens;       /* tokens per sample (GATE_RESID, BIAS_POS) */
+    const float* pos; /* [tokens, N] (BIAS_POS) */
+} bsi_gemm_args;
+int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
+
+/* dit.py:50-55,66,96: out_bf16[m,:] = LayerNorm(x[m,:]; eps, no affine) * (1 + scale[row]) + shift[row]
+ * with row = (m / tokens) % mod_rows; shift/scale point into the adaLN chunk table (stride mod_stride).
+ * With shift == scale == NULL it is a plain LayerNorm with optional affine weight/bias (dit.py:163). */
+int bsi_ln_modulate(const float* x, int M, int d, float eps, const float* shift, const float* scale,
+                    int mod_rows, int mod_stride, int tokens, const float* ln_w, const float* ln_b,
+                    void* out_bf16, bsi_stream_t stream);
+
+/* dit.py:39-46 / attention.py:34-40: softmax(q k^T / sqrt(dh)) v per (batch, head), non-causal.
+ * qkv: bf16 [B, tokens, 3, heads, dh] (row stride ld_qkv elements); out: bf16 [B, tokens, heads*dh]
+ * (row stride ld_out).  dh in {64, 128}; tokens % 64 == 0. */
+int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
+                      bsi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DenoisingDiT engine — bsi/models/dit.py:106-233
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bsi_dit_config {
+    int C, H, W;     /* data_shape */
+    int patch;       /* patch_size */
+    int dim, depth, heads;
+    int ff_nmin, ff_nmax; /* FourierFeatures n_min..n_max (fourier_features.py:11-19); ff_nmin > ff_nmax = none */
+} bsi_dit_config;
+
+typedef struct bsi_dit_block_weights {
+    const void *qkv_w, *out_w, *fc1_w, *fc2_w, *ada0_w, *ada2_w;    /* bf16 [N][K] shadows */
+    const float *qkv_b, *out_b, *fc1_b, *fc2_b, *ada0_b, *ada2_b;   /* fp32 biases */
+} bsi_dit_block_weights;
+
+typedef struct bsi_dit_weights {
+    const void* enc_w;     /* bf16 [dim][kpad], kpad = bsi_dit_kpad(cfg) (zero padded)        */
+    const float* enc_b;    /* [dim]                                                           */
+    const float* pos;      /* [tokens, dim] fp32 patch_pos_embedding (dit.py:135-146)         */
+    const float* t_scale;  /* [dim] NyquistPositionalEmbedding(dim,1000).scale (dit.py:147)   */
+    const float* t_bias;   /* [dim]                                                           */
+    const float* dec_ln_w; /* [dim] patch_decoder.0 */
+    const float* dec_ln_b;
+    const float* dec_w;    /* fp32 [patch*patch*C][dim] patch_decoder.1 */
+    const float* dec_b;
+    const bsi_dit_block_weights* blocks; /* host array [depth] */
+} bsi_dit_weights;
+
+int bsi_dit_kpad(const bsi_dit_config* cfg);
+int bsi_dit_tokens(const bsi_dit_config* cfg);
+/* bytes of scratch needed by bsi_dit_forward for a batch of B images */
+size_t bsi_dit_workspace_bytes(const bsi_dit_config* cfg, int B);
+
+/* adaLN tables (dit.py:77-81,90-92) for `rows` conditioning times: mod[r, l, 0:6*dim] =
+ * Linear2_l(SiLU(Linear1_l(emb(t[r])))) for every block l.  mod: fp32 [rows, depth, 6*dim].
+ * In `sample` t is shared by the whole batch, so the table is built once for all k+1 steps.
+ * scratch: bsi_dit_adaln_scratch_bytes(cfg, rows). */
+size_t bsi_dit_adaln_scratch_bytes(const bsi_dit_config* cfg, int rows);
+int bsi_dit_adaln(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, const float* t, int rows,
+                  float* mod, void* scratch, bsi_stream_t stream);
+
+/* One denoiser evaluation f(c_in*mu, t) (dit.py:225-233) with the BSI preconditioning fused around it
+ * (bsi.py:381-386).  mu: fp32 [B,C,H,W].  mod: adaLN table rows for this call, `mod_rows` in {1, B}
+ * (row b % mod_rows).  c_in/c_skip/c_out: device vectors indexed [b*coef_stride] (coef_stride 0 = shared
+ * scalar); pass NULL for all three to evaluate the bare denoiser.  out: fp32 [B,C,H,W] =
+ * c_skip*mu + c_out*f  (or f).  tokens_out (nullable): fp32 [B*tokens, dim] copy of the final residual
+ * stream (tests). */
+int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, int B, const float* mu,
+                    const float* mod, int mod_rows, const float* c_in, const float* c_skip, const float* c_out,
+                    int coef_stride, float* out, void* workspace, float* tokens_out, bsi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSI_HIP_H */

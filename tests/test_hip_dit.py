@@ -1,0 +1,223 @@
+"""GPU parity tests of the native DiT engine and of the BSI module surface on top of it, against the
+golden vectors generated from the reference (tests/golden) and the CPU oracle.
+
+Tolerances: the denoiser runs its contractions in bf16 MFMA with fp32 accumulation and an
+fp32 residual stream, the BSI wrapper in fp32:
+  * train_loss per sample rel 1e-3, batch mean rel 1e-4... measured against the fp32 reference;
+  * teacher-forced one-step x_hat rel-Linf 1e-2, mu' 1e-2;
+  * against an oracle that rounds the same operands to bf16 (isolates kernel bugs from bf16 rounding): 2e-3.
+"""
+import contextlib
+from unittest import mock
+
+import pytest
+import torch
+
+from oracle import bsi_oracle as bo
+from oracle import dit_oracle as do
+from tests.util import golden, max_rel, rel_linf, weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_model(tag="dit_ff", ff=True):
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    m = DenoisingDiT((3, 16, 16), 2, 128, 2, 2, dropout=None,
+                     fourier_features=FourierFeatures(n_min=6, n_max=8) if ff else None)
+    m.load_state_dict(weights(tag))
+    return m.to(DEV).eval()
+
+
+def make_bsi(model, shape=(3, 16, 16), k=16):
+    from bsi_amd import BSI, Discretization
+    return BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=k, preconditioning="edm",
+               discretization=Discretization.image_8bit()).to(DEV)
+
+
+@contextlib.contextmanager
+def replay_noise(**queues):
+    """Feed recorded draws to the module's torch.rand/randn/randperm/randint calls, in order (the golden
+    vectors were drawn from a CPU generator; the GPU generator has a different stream)."""
+    qs = {k: list(v) for k, v in queues.items()}
+
+    def pop(name):
+        def f(*a, **kw):
+            t = qs[name].pop(0)
+            return t.to(kw.get("device", DEV))
+        return f
+
+    with contextlib.ExitStack() as st:
+        for name in qs:
+            st.enter_context(mock.patch.object(torch, name, side_effect=pop(name)))
+        yield
+    assert all(len(v) == 0 for v in qs.values()), "not all recorded draws were consumed"
+
+
+def oracle_dit(tag, ff, md=None):
+    W = weights(tag)
+    return lambda mu, t: do.dit_forward(W, mu, t, patch_size=2, dim=128, depth=2, heads=2,
+                                        ff=(6, 8) if ff else None, md=md)
+
+
+def test_dit_forward_vs_golden_and_bf16_oracle():
+    g = golden("g7_dit_fwd")
+    m = make_model()
+    with torch.no_grad():
+        y = m(g["mu"].to(DEV), g["t"].to(DEV)).cpu()
+        yb = oracle_dit("dit_ff", True, md=torch.bfloat16)(g["mu"], g["t"])
+    # vs the fp32 reference: bf16 operand rounding through 2 blocks
+    assert rel_linf(y, g["out"]) < 2e-2, rel_linf(y, g["out"])
+    # vs the oracle with the same rounding points: only accumulation order / transcendental ulp remain
+    assert rel_linf(y, yb) < 4e-3, rel_linf(y, yb)
+
+
+def test_dit_tokens_blockwise():
+    """Residual stream after the blocks (fp32) against the oracle with bf16 rounding points."""
+    g = golden("g7_dit_fwd")
+    m = make_model()
+    with torch.no_grad():
+        mod = m.adaln_table(g["t"].to(DEV))
+        _, tok = m.forward_native(g["mu"].to(DEV), mod, return_tokens=True)
+        W = weights("dit_ff")
+        ref = do.dit_forward(W, g["mu"], g["t"], patch_size=2, dim=128, depth=2, heads=2, ff=(6, 8),
+                             md=torch.bfloat16, return_tokens=True)
+    assert rel_linf(tok.cpu().reshape(ref.shape), ref) < 4e-3
+
+
+def test_train_loss_value_vs_golden():
+    for case, tag, ff in [("g4_train_dit", "dit_ff", True), ("g4_train_dit_noff", "dit_noff", False)]:
+        g = golden(case)
+        bsi = make_bsi(make_model(tag, ff))
+        with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+            loss = bsi.train_loss(g["x"].to(DEV)).cpu()
+        # bf16 denoiser vs fp32 reference (Appendix F: per-sample median 4e-5, max 2e-4 on a trained-size model;
+        # these tiny random models have larger relative noise at high lambda): per sample 1e-2, mean 2e-3
+        assert max_rel(loss, g["loss"]) < 1e-2, max_rel(loss, g["loss"])
+        assert abs(float(loss.mean()) / float(g["loss_mean"]) - 1) < 2e-3
+
+
+def test_sample_history_teacher_forced_and_free_running():
+    from bsi_amd import _native as N
+    # --- teacher-forced, with Fourier features (free-running is chaotic)
+    g = golden("g5_hist_dit_ff")
+    bsi = make_bsi(make_model("dit_ff", True), k=int(g["k"]))
+    k = int(g["k"])
+    t = bsi.default_schedule
+    lam, alpha = bsi._schedule(t)
+    t_eval = torch.cat([t[:k], t.new_ones(1)])
+    with torch.no_grad():
+        for i in range(k + 1):
+            mu_i = g["mus"][i].to(DEV)
+            xh = bsi._predict_x(mu_i, t_eval[i].repeat(mu_i.shape[0]))
+            assert rel_linf(xh, g["x_hats"][i]) < 1e-2, (i, rel_linf(xh, g["x_hats"][i]))
+            if i < k:
+                mu_n = torch.empty_like(mu_i)
+                y = torch.empty_like(mu_i)
+                N.check(N.lib().bsi_refine_step(N.ptr(mu_i), N.ptr(xh.contiguous()), N.ptr(g["eps"][i].to(DEV)),
+                                                N.ptr(lam), N.ptr(alpha), None, None, i, 1, mu_i.shape[0],
+                                                mu_i[0].numel(), None, N.ptr(y), N.ptr(mu_n), N.stream()))
+                assert rel_linf(mu_n, g["mus"][i + 1]) < 1e-2
+                assert rel_linf(y, g["ys"][i]) < 1e-2
+    # --- free-running without Fourier features through the public API
+    g = golden("g5_hist_dit_noff")
+    bsi = make_bsi(make_model("dit_noff", False), k=int(g["k"]))
+    draws = [g["eps0"]] + list(g["eps"])
+    with torch.no_grad(), replay_noise(randn=draws):
+        mus, xhs, ys = bsi.sample_history(2)
+    assert mus.shape == g["mus"].shape and xhs.shape == g["x_hats"].shape and ys.shape == g["ys"].shape
+    for i in range(k + 1):
+        assert rel_linf(xhs[i], g["x_hats"][i]) < 3e-2, (i, rel_linf(xhs[i], g["x_hats"][i]))
+        assert rel_linf(mus[i], g["mus"][i]) < 3e-2
+    with torch.no_grad(), replay_noise(randn=draws):
+        s = bsi.sample(2)
+    assert torch.equal(s, xhs[-1])  # sample == last prediction of sample_history, bit for bit
+
+
+def test_generic_model_path_tinyconv():
+    """BSI around an arbitrary torch denoiser (the README Conv2d): fp32 end to end, wrapper kernels native."""
+    g = golden("g4_train_tinyconv")
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer = torch.nn.Conv2d(4, 3, 3, padding=1)
+
+        def forward(self, mu, t):
+            t = torch.movedim(t.expand((1, *mu.shape[-2:], len(t))), -1, 0)
+            return self.layer(torch.cat((mu, t), dim=-3))
+
+    m = Model()
+    m.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("W.")})
+    m = m.to(DEV)
+    bsi = make_bsi(m, (3, 8, 8))
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = bsi.train_loss(g["x"].to(DEV))
+    assert max_rel(loss, g["loss"]) < 1e-4   # fp32 path (MIOpen conv + native wrapper)
+    loss.mean().backward()
+    for name, p in m.named_parameters():
+        assert rel_linf(p.grad, g["G." + name]) < 1e-3, name
+    h = golden("g5_hist_tinyconv")
+    m.load_state_dict({k[2:]: v for k, v in h.items() if k.startswith("W.")})
+    with torch.no_grad(), replay_noise(randn=[h["eps0"]] + list(h["eps"])):
+        mus, xhs, ys = bsi.sample_history(4)
+    for a, b in [(mus, h["mus"]), (xhs, h["x_hats"]), (ys, h["ys"])]:
+        assert rel_linf(a, b) < 1e-4  # free-running fp32 (no Fourier features): 1e-5 expected
+
+
+def test_elbo_vs_golden():
+    g = golden("g6_elbo")
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer = torch.nn.Conv2d(4, 3, 3, padding=1)
+
+        def forward(self, mu, t):
+            t = torch.movedim(t.expand((1, *mu.shape[-2:], len(t))), -1, 0)
+            return self.layer(torch.cat((mu, t), dim=-3))
+
+    m = Model()
+    m.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("W.")})
+    bsi = make_bsi(m.to(DEV), (3, 8, 8), k=16)
+    x = g["x"].to(DEV)
+    with torch.no_grad(), replay_noise(randn=[g["eps_r"], g["eps_m"]], rand=[g["offset"]], randperm=[g["perm"]]):
+        elbo, bpd, extra = bsi.elbo(x, 3, 4, estimate_var=True)
+    assert max_rel(extra["l_recon"], g["l_recon"]) < 2e-4 and max_rel(extra["l_measure"], g["l_measure"]) < 1e-4
+    assert max_rel(elbo, g["elbo"]) < 2e-4 and max_rel(bpd, g["bpd"]) < 2e-4
+    assert max_rel(extra["bpd_var"], g["bpd_var"]) < 5e-3
+    with torch.no_grad(), replay_noise(randn=[g["feps_r"], g["feps_m"]], randint=[g["fidx"]]):
+        felbo, fbpd, fextra = bsi.finite_elbo(x, 3, 4, t=torch.linspace(0, 1, 17, device=DEV), estimate_var=True)
+    assert max_rel(fextra["l_measure"], g["fl_measure"]) < 1e-4 and max_rel(felbo, g["felbo"]) < 2e-4
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            bsi.elbo(x, 1, 4, estimate_var=True)
+    bsi.preconditioning = "bogus"
+    with pytest.raises(RuntimeError, match="Unknown preconditioning"):
+        bsi._predict_x(x, torch.ones(len(x), device=DEV))
+
+
+def test_full_size_dit_l2_one_forward_vs_oracle():
+    """DiT-L/2 (the BASELINE config) at B=2: one preconditioned evaluation against the fp32 CPU oracle."""
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    shape = (3, 32, 32)
+    W = do.dit_random_weights(shape, 2, 1024, 24, ff=(6, 8), seed=0)
+    m = DenoisingDiT(shape, 2, 1024, 24, 16, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    m.load_state_dict(W)
+    m = m.to(DEV).eval()
+    bsi = make_bsi(m, shape, k=128)
+    gen = torch.Generator().manual_seed(0)
+    mu = torch.randn((2, *shape), generator=gen) * 2
+    t = torch.tensor([0.2, 0.9])
+    f = lambda a, b: do.dit_forward(W, a, b, patch_size=2, dim=1024, depth=24, heads=16, ff=(6, 8))  # noqa: E731
+    with torch.no_grad():
+        got = bsi._predict_x(mu.to(DEV), t.to(DEV)).cpu()
+        ref = bo.BSIOracle(f, data_shape=shape, k=128).predict_x(mu, t)
+    assert rel_linf(got, ref) < 2e-2, rel_linf(got, ref)
+    # size-independent properties at the benchmark batch: determinism and batch-invariance of the chain
+    with torch.no_grad():
+        a = bsi.sample(4, torch.Generator(DEV).manual_seed(5), t=torch.linspace(0, 1, 5, device=DEV))
+        b = bsi.sample(4, torch.Generator(DEV).manual_seed(5), t=torch.linspace(0, 1, 5, device=DEV))
+    assert torch.equal(a, b) and torch.isfinite(a).all()

@@ -1,0 +1,300 @@
+"""GPU parity tests of the individual HIP kernels (called through the C ABI) against the CPU oracle and
+the golden vectors.  Tolerances are written next to each check: fp32 elementwise kernels match the
+oracle to a few ulp; bf16-MFMA kernels are compared with an oracle fed the same bf16-rounded operands."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from oracle import bsi_oracle as bo
+from oracle import dit_oracle as do
+from tests.util import golden, max_rel, rel_linf, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def N():
+    from bsi_amd import _native
+    _native.lib()
+    return _native
+
+
+def params(N):
+    o = bo.BSIOracle(None, data_shape=(3, 8, 8))
+    return N.BSIParams(0.01, 1e6, 2e6, o.p_lambda.ln_low, o.p_lambda.delta), o
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def empty(*shape, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=DEV)
+
+
+# ----------------------------------------------------------------------------------------------
+# BSI wrapper kernels
+# ----------------------------------------------------------------------------------------------
+def test_edm_coeffs_and_schedule(N):
+    g = golden("g1_tables")
+    p, o = params(N)
+    t = dev(g["t"])
+    n = t.numel()
+    lam, cs, co, ci = empty(n), empty(n), empty(n), empty(n)
+    N.check(N.lib().bsi_edm_coeffs(C.byref(p), N.ptr(t), n, N.ptr(lam), N.ptr(cs), N.ptr(co), N.ptr(ci), N.stream()))
+    # fp32, same op order as the reference: differences come only from expf/sqrtf ulp -> 1e-6 relative
+    assert max_rel(lam, g["lam"]) < 2e-6
+    assert max_rel(co, g["c_out"]) < 4e-6 and max_rel(ci, g["c_in"]) < 4e-6
+    assert float((cs.cpu() - g["c_skip"]).abs().max()) < 4e-6 * float(g["c_skip"].abs().max())
+    tt, rp = empty(n), empty(n)
+    N.check(N.lib().bsi_lambda_to_t(C.byref(p), N.ptr(dev(g["lam"])), n, N.ptr(tt), N.ptr(rp), N.stream()))
+    assert float((tt.cpu() - g["cdf_lam"]).abs().max()) < 2e-7 and max_rel(rp, g["rpdf"]) < 1e-7
+    ts = dev(g["default_schedule"])
+    k1 = ts.numel()
+    l2, al = empty(k1), empty(k1 - 1)
+    N.check(N.lib().bsi_schedule(C.byref(p), N.ptr(ts), k1, N.ptr(l2), N.ptr(al), N.stream()))
+    lam_ref = o.p_lambda.icdf(g["default_schedule"])
+    assert max_rel(l2, lam_ref) < 2e-6
+    assert rel_linf(al, lam_ref.diff()) < 2e-6
+    assert torch.equal(al.cpu(), l2.cpu().diff())  # alpha is exactly the fp32 diff of the kernel's own lambdas
+
+
+def test_lambda_grid_and_q_sample(N):
+    g = golden("g2g3_lambda_q")
+    p, o = params(N)
+    for n, B in [(1, 8), (3, 5)]:
+        lam = empty(n * B)
+        N.check(N.lib().bsi_lambda_grid(C.byref(p), N.ptr(dev(g[f"perm_{n}_{B}"])), N.ptr(dev(g[f"offset_{n}_{B}"])),
+                                        n * B, N.ptr(lam), N.stream()))
+        assert max_rel(lam.reshape(n, B), g[f"lam_{n}_{B}"]) < 4e-6
+    x, lam, eps = dev(g["x"]), dev(g["q_lam"]), dev(g["q_eps"])
+    mu = torch.empty_like(eps)
+    N.check(N.lib().bsi_q_sample(C.byref(p), N.ptr(x), N.ptr(lam), N.ptr(eps), 15, 5, 192, N.ptr(mu), N.stream()))
+    assert torch.equal(mu.cpu(), g["q_mu"])  # same fp32 op sequence, exact div/sqrt: bit-exact
+
+
+def test_refine_step_and_combine(N):
+    p, o = params(N)
+    gen = torch.Generator().manual_seed(3)
+    n, D, k = 6, 3 * 32 * 32, 16
+    t = o.default_schedule if o.k == k else torch.linspace(0, 1, k + 1)
+    lam = o.p_lambda.icdf(t)
+    alpha = lam.diff()
+    cs, co, ci = o.edm_coeffs(t)
+    mu = torch.randn((n, D), generator=gen) * 3
+    f = torch.randn((n, D), generator=gen)
+    eps = torch.randn((n, D), generator=gen)
+    dmu, df, deps, dlam, dal, dcs, dco = map(dev, (mu, f, eps, lam, alpha, cs, co))
+    for i in (0, 7, 15):
+        xh = torch.addcmul(cs[i] * mu, co[i], f)
+        y = xh + torch.rsqrt(alpha[i]) * eps
+        mn = (alpha[i] * y + lam[i] * mu) / lam[i + 1]
+        oxh, oy, omn = empty(n, D), empty(n, D), empty(n, D)
+        N.check(N.lib().bsi_refine_step(N.ptr(dmu), N.ptr(df), N.ptr(deps), N.ptr(dlam), N.ptr(dal), N.ptr(dcs),
+                                        N.ptr(dco), i, 0, n, D, N.ptr(oxh), N.ptr(oy), N.ptr(omn), N.stream()))
+        assert torch.equal(oxh.cpu(), xh) and torch.equal(oy.cpu(), y) and torch.equal(omn.cpu(), mn)
+        # f already an x_hat, no history outputs
+        omn2 = empty(n, D)
+        N.check(N.lib().bsi_refine_step(N.ptr(dmu), N.ptr(dev(xh)), N.ptr(deps), N.ptr(dlam), N.ptr(dal), None, None,
+                                        i, 1, n, D, None, None, N.ptr(omn2), N.stream()))
+        assert torch.equal(omn2.cpu(), mn)
+    # per-row coefficients
+    csr, cor, cir = (torch.rand(n, generator=gen) for _ in range(3))
+    out = empty(n, D)
+    N.check(N.lib().bsi_predict_combine(N.ptr(dmu), N.ptr(df), N.ptr(dev(csr)), N.ptr(dev(cor)), 1, n, D, N.ptr(out),
+                                        N.stream()))
+    assert torch.equal(out.cpu(), torch.addcmul(csr[:, None] * mu, cor[:, None], f))
+    N.check(N.lib().bsi_scale_rows(N.ptr(dmu), N.ptr(dev(cir)), 1, n, D, N.ptr(out), N.stream()))
+    assert torch.equal(out.cpu(), cir[:, None] * mu)
+    N.check(N.lib().bsi_sample_init(N.ptr(deps), N.ptr(dlam), n, D, N.ptr(out), N.stream()))
+    assert torch.equal(out.cpu(), torch.rsqrt(lam[0]) * eps)
+    gf, gm = empty(n, D), empty(n, D)
+    N.check(N.lib().bsi_predict_combine_bwd(N.ptr(df), N.ptr(dev(csr)), N.ptr(dev(cor)), 1, n, D, N.ptr(gf), N.ptr(gm),
+                                            N.stream()))
+    assert torch.equal(gf.cpu(), cor[:, None] * f) and torch.equal(gm.cpu(), csr[:, None] * f)
+
+
+def test_sqerr_and_backward(N):
+    gen = torch.Generator().manual_seed(4)
+    B, n, D = 5, 3, 3072
+    x = torch.rand((B, D), generator=gen) * 2 - 1
+    xh = x.repeat(n, 1) + 0.01 * torch.randn((n * B, D), generator=gen)
+    w = torch.rand(n * B, generator=gen) * 1e6
+    out = empty(n * B)
+    N.check(N.lib().bsi_sqerr_rows(N.ptr(dev(x)), N.ptr(dev(xh)), N.ptr(dev(w)), 0.5, 0, n * B, B, D, N.ptr(out), N.stream()))
+    ref = 0.5 * w.double() * (x.double().repeat(n, 1) - xh.double()).square().sum(1)
+    assert max_rel(out, ref) < 2e-6  # fp32 tree reduction of 3072 terms vs fp64
+    N.check(N.lib().bsi_sqerr_rows(N.ptr(dev(x)), N.ptr(dev(xh)), N.ptr(dev(w)), 1.0, 1, n * B, B, D, N.ptr(out), N.stream()))
+    assert max_rel(out, w.double() * (x.double().repeat(n, 1) - xh.double()).square().mean(1)) < 2e-6
+    g = torch.rand(n * B, generator=gen)
+    gx = empty(n * B, D)
+    N.check(N.lib().bsi_sqerr_rows_bwd(N.ptr(dev(x)), N.ptr(dev(xh)), N.ptr(dev(w)), N.ptr(dev(g)), 1.0, 1, n * B, B, D,
+                                       N.ptr(gx), N.stream()))
+    xr = xh.clone().requires_grad_(True)
+    (w * (x.repeat(n, 1) - xr).square().mean(1) * g).sum().backward()
+    assert rel_linf(gx, xr.grad) < 1e-6
+
+
+def test_recon_nll_and_uint8(N):
+    g = golden("g6_elbo")
+    d = bo.Disc.image_8bit()
+    x = g["x"]
+    B, D = x.shape[0], 192
+    W = sub(g, "W.")
+
+    def f(mu, t):
+        tp = t.reshape(-1, 1, 1, 1).expand(-1, 1, 8, 8)
+        return torch.nn.functional.conv2d(torch.cat((mu, tp), 1), W["layer.weight"], W["layer.bias"], padding=1)
+
+    o = bo.BSIOracle(f, data_shape=(3, 8, 8), k=16, discretization=d)
+    eps = g["eps_r"]
+    n = eps.shape[0]
+    lam_M = x.new_full((n, B), 1e6)
+    mu = o.q_mu_lambda(x, lam_M, eps).flatten(end_dim=1)
+    with torch.no_grad():
+        xh = o.predict_x(mu, x.new_ones(n * B))
+    out = empty(n * B)
+    bounds = d.bin_boundaries(torch.float32)
+    N.check(N.lib().bsi_recon_nll(N.ptr(dev(x)), N.ptr(dev(xh)), 2e6, N.ptr(dev(bounds)), d.lo - d.dx / 2, d.dx, d.k,
+                                  n * B, B, D, N.ptr(out), N.stream()))
+    # erf/log ulp differences get amplified by the cdf difference; 1e-4 relative on the 192-term sum
+    assert max_rel(out.reshape(n, B), g["l_recon"]) < 1e-4
+    N.check(N.lib().bsi_recon_nll(N.ptr(dev(x)), N.ptr(dev(xh)), 2e6, None, 0.0, 1.0, 0, n * B, B, D, N.ptr(out),
+                                  N.stream()))
+    oc = bo.BSIOracle(f, data_shape=(3, 8, 8), k=16, discretization=None)
+    sigma = torch.rsqrt(oc.alpha_R)
+    ref = -(-((x - xh.reshape(n, B, 3, 8, 8)) ** 2) / (2 * sigma ** 2) - torch.log(sigma)
+            - math.log(math.sqrt(2 * math.pi))).reshape(n, B, -1).sum(2)
+    assert max_rel(out.reshape(n, B), ref) < 1e-5
+    v = torch.linspace(-1.3, 1.3, 4001)
+    u8 = torch.empty(4001, dtype=torch.uint8, device=DEV)
+    N.check(N.lib().bsi_to_uint8(N.ptr(dev(v)), -1.0, 1.0, 4001, N.ptr(u8), N.stream()))
+    assert torch.equal(u8.cpu(), d.to_8bit_image(v))
+
+
+# ----------------------------------------------------------------------------------------------
+# DiT building blocks
+# ----------------------------------------------------------------------------------------------
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_embeddings_and_fourier_features(N):
+    g = golden("g7_components")
+    for size, rate in [(1024, 1000), (32, 100), (512, 32), (64, 16)]:
+        t = g[f"pe_{size}_{rate}_t"]
+        out = empty(t.numel(), size)
+        ob = empty(t.numel(), size, dtype=torch.bfloat16)
+        N.check(N.lib().bsi_nyquist_embed(N.ptr(dev(t)), t.numel(), N.ptr(dev(g[f"pe_{size}_{rate}_scale"])),
+                                          N.ptr(dev(g[f"pe_{size}_{rate}_bias"])), size, N.ptr(out), N.ptr(ob), N.stream()))
+        # same fp32 argument (fma), accurate sinf on both sides: <= 2 ulp of values in [-1,1]
+        assert float((out.cpu() - g[f"pe_{size}_{rate}_out"]).abs().max()) < 3e-7
+        assert torch.equal(ob.cpu(), out.cpu().to(torch.bfloat16))
+    x = g["ff_x"]
+    out = empty(*g["ff_out"].shape)
+    N.check(N.lib().bsi_fourier_features(N.ptr(dev(x)), 2, 3, 16, 6, 8, N.ptr(out), N.stream()))
+    assert float((out.cpu() - g["ff_out"]).abs().max()) < 3e-7
+    # the reference's own known-answer test (test_fourier_features.py:9-28) through the mirror module
+    from bsi_amd.nn import FourierFeatures
+    import numpy as np
+    m = FourierFeatures(n_min=5, n_max=6).to(DEV)
+    xv = torch.tensor([1.333, -np.e / 7], dtype=torch.float32)[None, :, None].repeat(2, 1, 3)
+    y = m(xv.to(DEV), dim=1).cpu()
+    assert m.n_features() == 4 and y.shape == (2, 8, 3)
+    exp64 = do.fourier_features(xv.double(), 5, 6, dim=1)  # fp32 tables, fp64 evaluation
+    # fp32 evaluation of sin at |arg| ~ 500 with fp32 argument rounding: 3e-5 absolute
+    assert float((y.double() - exp64).abs().max()) < 6e-5
+
+
+@pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (512, 1024, 1024), (300, 384, 128), (64, 768, 512),
+                                     (1, 1024, 1024), (129, 6144, 1024), (1024, 1024, 4096), (2048, 4096, 1024)])
+def test_gemm_epilogues(N, M, Nn, K):
+    gen = torch.Generator().manual_seed(M * 7 + Nn + K)
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Nn, generator=gen)
+    ref = A.double() @ W.double().t() + bias.double()
+    dA, dW, db = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias)
+
+    def run(epi, out, **kw):
+        a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K,
+                       lda=K, ldw=K, ldo=Nn, epilogue=epi, **kw)
+        N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+        return out
+
+    # fp32 accumulation of exact bf16 products: error ~ K * 2^-24 relative to sum|a*b| -> 1e-5 of the output scale
+    o = run(N.EPI_BIAS_F32, empty(M, Nn))
+    assert rel_linf(o, ref) < 2e-5, rel_linf(o, ref)
+    # bf16 outputs: one rounding (2^-9 relative) on top
+    o = run(N.EPI_BIAS_BF16, empty(M, Nn, dtype=torch.bfloat16))
+    assert float(((o.cpu().double() - ref).abs() / (ref.abs() + 1e-2)).max()) < 5e-3
+    o = run(N.EPI_BIAS_GELU_BF16, empty(M, Nn, dtype=torch.bfloat16))
+    assert float((o.cpu().double() - do.gelu_tanh(ref)).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()) / 4)
+    assert rel_linf(o.cpu().float(), do.gelu_tanh(ref)) < 5e-3
+    o = run(N.EPI_BIAS_SILU_BF16, empty(M, Nn, dtype=torch.bfloat16))
+    assert rel_linf(o.cpu().float(), do.silu(ref)) < 5e-3
+    tokens = 64 if M % 64 == 0 else 1
+    rows = max(M // tokens, 1)
+    for gate_rows in {1, rows}:
+        gate = torch.randn((gate_rows, 3 * Nn), generator=gen)
+        x0 = torch.randn((M, Nn), generator=gen)
+        xg = dev(x0)
+        dgate = dev(gate)
+        run(N.EPI_GATE_RESID, xg, gate=dgate.data_ptr() + 4 * Nn, gate_rows=gate_rows, gate_stride=3 * Nn,
+            tokens=tokens)
+        gsel = gate[(torch.arange(M) // tokens) % gate_rows, Nn:2 * Nn]
+        assert rel_linf(xg, x0.double() + gsel.double() * ref) < 2e-5
+    pos = torch.randn((tokens, Nn), generator=gen)
+    dpos = dev(pos)
+    o = run(N.EPI_BIAS_POS_F32, empty(M, Nn), pos=dpos.data_ptr(), tokens=tokens)
+    assert rel_linf(o, ref + pos[torch.arange(M) % tokens].double()) < 2e-5
+
+
+def test_gemm_rejects_bad_shapes(N):
+    a = N.GemmArgs(A=1, W=1, out=1, M=4, N=24, K=64, lda=64, ldw=64, ldo=24, epilogue=0)
+    assert N.lib().bsi_gemm_bf16(C.byref(a), None) == -1
+    assert b"multiple of 16" in N.lib().bsi_last_error()
+    a = N.GemmArgs(A=1, W=1, out=1, M=4, N=32, K=100, lda=104, ldw=104, ldo=32, epilogue=0)
+    assert N.lib().bsi_gemm_bf16(C.byref(a), None) == -1
+
+
+@pytest.mark.parametrize("B,tokens,heads,dh", [(2, 64, 2, 64), (3, 256, 4, 64), (2, 256, 16, 64), (1, 1024, 1, 128),
+                                                (2, 64, 1, 128), (1, 512, 2, 64)])
+def test_attention(N, B, tokens, heads, dh):
+    gen = torch.Generator().manual_seed(B + tokens + heads)
+    d = heads * dh
+    qkv = bf16r(torch.randn((B, tokens, 3, heads, dh), generator=gen) * 1.5)
+    out = empty(B, tokens, d, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_attention_fwd(N.ptr(dev(qkv.to(torch.bfloat16))), 3 * d, B, tokens, heads, dh, N.ptr(out), d,
+                                      N.stream()))
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, tokens, d)
+    # P is rounded to bf16 before the PV product (2^-9 relative per term, averaged) and O is stored as bf16
+    assert rel_linf(out.cpu().float(), ref) < 1e-2, rel_linf(out.cpu().float(), ref)
+    assert float((out.cpu().double() - ref).abs().mean() / ref.abs().mean()) < 4e-3
+
+
+@pytest.mark.parametrize("M,d,tokens,mod_rows", [(128, 128, 64, 2), (512, 1024, 256, 1), (512, 1024, 256, 2),
+                                                  (77, 256, 1, 77)])
+def test_ln_modulate(N, M, d, tokens, mod_rows):
+    gen = torch.Generator().manual_seed(M + d)
+    x = torch.randn((M, d), generator=gen) * 2 + 0.3
+    mod = torch.randn((mod_rows, 6 * d), generator=gen) * 0.2
+    out = empty(M, d, dtype=torch.bfloat16)
+    dmod = dev(mod)
+    N.check(N.lib().bsi_ln_modulate(N.ptr(dev(x)), M, d, 1e-5, dmod.data_ptr() + 4 * 3 * d, dmod.data_ptr() + 4 * 4 * d,
+                                    mod_rows, 6 * d, tokens, None, None, N.ptr(out), N.stream()))
+    rows = (torch.arange(M) // tokens) % mod_rows
+    ref = torch.addcmul(mod[rows, 3 * d:4 * d], mod[rows, 4 * d:5 * d] + 1, do.layer_norm(x))
+    # fp32 statistics, one bf16 rounding of the result
+    assert torch.equal(out.cpu(), ref.to(torch.bfloat16)) or rel_linf(out.cpu().float(), ref) < 4e-3
+    assert float((out.cpu().float() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8
+    w, b = torch.randn(d, generator=gen), torch.randn(d, generator=gen)
+    N.check(N.lib().bsi_ln_modulate(N.ptr(dev(x)), M, d, 1e-5, None, None, 0, 0, 1, N.ptr(dev(w)), N.ptr(dev(b)),
+                                    N.ptr(out), N.stream()))
+    ref = do.layer_norm(x, 1e-5, w, b)
+    assert float((out.cpu().float() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8

@@ -115,7 +115,8 @@ def test_sample_history_teacher_forced_and_free_running():
             if i < k:
                 mu_n = torch.empty_like(mu_i)
                 y = torch.empty_like(mu_i)
-                N.check(N.lib().bsi_refine_step(N.ptr(mu_i), N.ptr(xh.contiguous()), N.ptr(g["eps"][i].to(DEV)),
+                eps_i = g["eps"][i].to(DEV)
+                N.check(N.lib().bsi_refine_step(N.ptr(mu_i), N.ptr(xh.contiguous()), N.ptr(eps_i),
                                                 N.ptr(lam), N.ptr(alpha), None, None, i, 1, mu_i.shape[0],
                                                 mu_i[0].numel(), None, N.ptr(y), N.ptr(mu_n), N.stream()))
                 assert rel_linf(mu_n, g["mus"][i + 1]) < 1e-2

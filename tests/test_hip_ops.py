@@ -27,8 +27,20 @@ def params(N):
     return N.BSIParams(0.01, 1e6, 2e6, o.p_lambda.ln_low, o.p_lambda.delta), o
 
 
+_KEEP = []  # device copies stay alive until the test ends (kernels are enqueued asynchronously)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_copies():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
 def dev(t):
-    return t.to(DEV).contiguous()
+    d = t.to(DEV).contiguous()
+    _KEEP.append(d)
+    return d
 
 
 def empty(*shape, dtype=torch.float32):

@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of BSI.sample (k=128, DiT-L/2, 3x32x32) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `BSI.sample` call (k measure/refine steps = k+1 denoiser evaluations) of `--batch`
+images per GPU, synthetic inputs (Gaussian noise from the device generator), random-init weights of the
+BASELINE architecture (config/experiment/imagenet32.yaml:33-39 of the reference) with the adaLN output
+layers ~N(0, 0.02^2) so that blocks are not the identity.  Sampling is embarrassingly parallel: ranks draw
+rank-distinct chains, no data-path collective; value = images of all ranks / max-over-ranks wall time
+(weak scaling).  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the fc1 bf16 MFMA GEMM,
+timed with HIP events around every launch inside the timed region) and `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md:43
+FWD_GFLOP_PER_IMG = 161.46  # DiT-L/2 forward, 2*MAC
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call")
+    ap.add_argument("--k", type=int, default=128, help="sampling steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")
+    return ap.parse_args()
+
+
+def build_model(dev):
+    from bsi_amd import BSI, Discretization
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+
+    shape = (3, 32, 32)
+    torch.manual_seed(0)  # identical weights on every rank
+    model = DenoisingDiT(shape, 2, 1024, 24, 16, dropout=0.05, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for blk in model.dit.blocks:
+            lin = blk.adaLN_modulation[2]
+            lin.weight.copy_(0.02 * torch.randn(lin.weight.shape, generator=g))
+            lin.bias.copy_(0.02 * torch.randn(lin.bias.shape, generator=g))
+    model = model.to(dev).eval()
+    return model, shape
+
+
+def host_threads():
+    """Threads actually usable on this box: CPU affinity mask, cgroup CPU quota, capped at 32 (beyond that the
+    fp32 oracle's GEMMs at B=4 do not scale and oversubscription makes it slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(k):
+    """CPU oracle (a port of the reference's algorithm, oracle/) on the host cores: 2 complete sampling steps
+    (denoiser evaluation + measure/refine update) + the final prediction at B=4, extrapolated to k+1
+    evaluations per image.  Bounded: 3 DiT-L/2 evaluations of 4 images (about 2 TFLOP of fp32 work)."""
+    from oracle import bsi_oracle as bo
+    from oracle import dit_oracle as do
+
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    shape, B = (3, 32, 32), 4
+    W = do.dit_random_weights(shape, 2, 1024, 24, ff=(6, 8), seed=0)
+    f = lambda m, t: do.dit_forward(W, m, t, patch_size=2, dim=1024, depth=24, heads=16, ff=(6, 8))  # noqa: E731
+    o = bo.BSIOracle(f, data_shape=shape, k=k)
+    g = torch.Generator().manual_seed(0)
+    tt = torch.linspace(0, 1, k + 1)[[0, k // 2, k]]  # 2 steps taken from the k-step schedule
+    eps0 = torch.randn((B, *shape), generator=g)
+    eps = torch.randn((2, B, *shape), generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o.sample_history(eps0, eps, t=tt)          # 2 steps + final prediction = 3 evaluations
+        dt = time.perf_counter() - t0
+    per_eval = dt / 3.0
+    return {"value": B / (per_eval * (k + 1)), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32, {threads} threads) DiT-L/2, B={B}: 3 denoiser evaluations + 2 refine "
+                      f"steps in {dt:.1f} s, extrapolated to k+1={k + 1} evaluations per image"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == max(a.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {a.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from bsi_amd import _native as N
+    from bsi_amd import BSI, Discretization
+
+    model, shape = build_model(dev)
+    bsi = BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=a.k, preconditioning="edm",
+              discretization=Discretization.image_8bit()).to(dev)
+    gen = torch.Generator(dev).manual_seed(1234 + rank)  # rank-distinct chains
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return bsi.sample(a.batch, gen)
+
+    for _ in range(a.warmup):
+        step()
+    N.prof_enable(["gemm_fc1"])
+    N.prof_read("gemm_fc1")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cnt, tot_ms = N.prof_read("gemm_fc1")
+    N.prof_enable([])
+    assert torch.isfinite(out).all()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if a.breakdown and rank == 0:
+        names = list(N.PROF_CLASSES)
+        N.prof_enable(names)
+        step()
+        torch.cuda.synchronize()
+        rows = [(n, *N.prof_read(n)) for n in names]
+        N.prof_enable([])
+        tot = sum(r[2] for r in rows)
+        for n, c, ms in rows:
+            print(f"  {n:12s} {c:6d} launches {ms:10.2f} ms  {100 * ms / max(tot, 1e-9):5.1f} %", file=sys.stderr)
+
+    if rank == 0:
+        n_gpus = world
+        imgs = a.batch * a.steps * n_gpus
+        value = imgs / elapsed
+        # dominant kernel: fc1 GEMM  [B*256, 1024] x [4096, 1024]^T  (+bias, GELU-tanh, bf16 store)
+        flops_per_launch = 2.0 * (a.batch * 256) * 1024 * 4096
+        avg_ms = tot_ms / max(cnt, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec BSI.sample k=128 (DiT, 3x32x32)",
+            "value": value, "unit": "images/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ImageNet32 DiT-L/2 (dim 1024, depth 24, heads 16, patch 2, Fourier features 6..8), "
+                                   f"BSI.sample k={a.k}, EDM preconditioning, {a.batch} images per GPU per call, "
+                                   "random-init weights",
+                       "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}"},
+            "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "gemm_bf16_kernel<8,2,4,BIAS_GELU_BF16> (fc1)",
+                         "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.k)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

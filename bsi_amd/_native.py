@@ -79,9 +79,26 @@ _PROTOS = {
     "bsi_dit_adaln": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                              _vp, _vp, _vp, _vp]),
+    "bsi_prof_enable": (_i, [C.c_uint]),
+    "bsi_prof_read": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
 
 EXPORTS = tuple(_PROTOS)
+PROF_CLASSES = {"gemm_qkv": 0, "gemm_out": 1, "gemm_fc1": 2, "gemm_fc2": 3, "attention": 4, "ln_modulate": 5,
+                "prologue": 6, "final": 7, "gemm_enc": 8, "adaln": 9}
+
+
+def prof_enable(names=()):
+    mask = 0
+    for n in names:
+        mask |= 1 << PROF_CLASSES[n]
+    check(lib().bsi_prof_enable(mask))
+
+
+def prof_read(name):
+    cnt, tot = C.c_int(0), C.c_double(0.0)
+    check(lib().bsi_prof_read(PROF_CLASSES[name], C.byref(cnt), C.byref(tot)))
+    return cnt.value, tot.value
 
 
 def lib():

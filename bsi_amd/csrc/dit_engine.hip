@@ -2,6 +2,7 @@
 // reference) on a HIP stream.  No allocation, no synchronisation: the caller owns the workspace.
 #include "common.h"
 #include "dit_ops.h"
+#include "prof.h"
 
 namespace {
 
@@ -82,6 +83,7 @@ extern "C" int bsi_dit_adaln(const bsi_dit_config* cfg, const bsi_dit_weights* w
     char* emb = reinterpret_cast<char*>(scratch);
     char* hid = emb + align_up((size_t)rows * dim * 2, 256);
     // c = t_embedding(t)  (dit.py:177)
+    ProfScope prof(BSI_PROF_ADALN, reinterpret_cast<hipStream_t>(stream));
     if (int rc = bsi_nyquist_embed(t, rows, w->t_scale, w->t_bias, dim, nullptr, emb, stream)) return rc;
     for (int l = 0; l < cfg->depth; ++l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
@@ -116,51 +118,77 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
     Workspace ws = carve(cfg, B, workspace);
 
     // 1. c_in*mu -> Fourier features -> patchify -> bf16 tokens
-    if (int rc = bsi_dit_prologue_launch(mu, c_in, coef_stride, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin,
-                                         d.nfreq, d.kpad, ws.a0, s))
-        return rc;
+    {
+        ProfScope prof(BSI_PROF_PROLOGUE, s);
+        if (int rc = bsi_dit_prologue_launch(mu, c_in, coef_stride, B, cfg->C, cfg->H, cfg->W, cfg->patch,
+                                             cfg->ff_nmin, d.nfreq, d.kpad, ws.a0, s))
+            return rc;
+    }
     // 2. patch encoder + positional embedding (dit.py:178)
     {
         bsi_gemm_args g{};
         g.A = ws.a0; g.W = w->enc_w; g.bias = w->enc_b; g.out = ws.x;
         g.M = M; g.N = dim; g.K = d.kpad; g.lda = d.kpad; g.ldw = d.kpad; g.ldo = dim;
         g.epilogue = BSI_EPI_BIAS_POS_F32; g.pos = w->pos; g.tokens = d.tokens;
+        ProfScope prof(BSI_PROF_GEMM_ENC, s);
         if (int rc = bsi_gemm_bf16(&g, stream)) return rc;
     }
     // 3. blocks (dit.py:87-103)
     for (int l = 0; l < cfg->depth; ++l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
         const float* ml = mod + (size_t)l * 6 * dim;
-        if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml, ml + dim, mod_rows, mod_stride, d.tokens, nullptr, nullptr,
-                                     ws.xn, stream))
-            return rc;
+        {
+            ProfScope prof(BSI_PROF_LN, s);
+            if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml, ml + dim, mod_rows, mod_stride, d.tokens, nullptr,
+                                         nullptr, ws.xn, stream))
+                return rc;
+        }
         bsi_gemm_args g{};
         g.A = ws.xn; g.W = bw.qkv_w; g.bias = bw.qkv_b; g.out = ws.big;
         g.M = M; g.N = 3 * dim; g.K = dim; g.lda = dim; g.ldw = dim; g.ldo = 3 * dim;
         g.epilogue = BSI_EPI_BIAS_BF16;
-        if (int rc = bsi_gemm_bf16(&g, stream)) return rc;
-        if (int rc = bsi_attention_fwd(ws.big, 3 * dim, B, d.tokens, cfg->heads, dim / cfg->heads, ws.xn, dim, stream))
-            return rc;
+        {
+            ProfScope prof(BSI_PROF_GEMM_QKV, s);
+            if (int rc = bsi_gemm_bf16(&g, stream)) return rc;
+        }
+        {
+            ProfScope prof(BSI_PROF_ATTN, s);
+            if (int rc = bsi_attention_fwd(ws.big, 3 * dim, B, d.tokens, cfg->heads, dim / cfg->heads, ws.xn, dim,
+                                           stream))
+                return rc;
+        }
         bsi_gemm_args go{};
         go.A = ws.xn; go.W = bw.out_w; go.bias = bw.out_b; go.out = ws.x;
         go.M = M; go.N = dim; go.K = dim; go.lda = dim; go.ldw = dim; go.ldo = dim;
         go.epilogue = BSI_EPI_GATE_RESID; go.gate = ml + 2 * dim; go.gate_rows = mod_rows; go.gate_stride = mod_stride;
         go.tokens = d.tokens;
-        if (int rc = bsi_gemm_bf16(&go, stream)) return rc;
-        if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml + 3 * dim, ml + 4 * dim, mod_rows, mod_stride, d.tokens,
-                                     nullptr, nullptr, ws.xn, stream))
-            return rc;
+        {
+            ProfScope prof(BSI_PROF_GEMM_OUT, s);
+            if (int rc = bsi_gemm_bf16(&go, stream)) return rc;
+        }
+        {
+            ProfScope prof(BSI_PROF_LN, s);
+            if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml + 3 * dim, ml + 4 * dim, mod_rows, mod_stride,
+                                         d.tokens, nullptr, nullptr, ws.xn, stream))
+                return rc;
+        }
         bsi_gemm_args g1{};
         g1.A = ws.xn; g1.W = bw.fc1_w; g1.bias = bw.fc1_b; g1.out = ws.big;
         g1.M = M; g1.N = 4 * dim; g1.K = dim; g1.lda = dim; g1.ldw = dim; g1.ldo = 4 * dim;
         g1.epilogue = BSI_EPI_BIAS_GELU_BF16;
-        if (int rc = bsi_gemm_bf16(&g1, stream)) return rc;
+        {
+            ProfScope prof(BSI_PROF_GEMM_FC1, s);
+            if (int rc = bsi_gemm_bf16(&g1, stream)) return rc;
+        }
         bsi_gemm_args g2{};
         g2.A = ws.big; g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = ws.x;
         g2.M = M; g2.N = dim; g2.K = 4 * dim; g2.lda = 4 * dim; g2.ldw = 4 * dim; g2.ldo = dim;
         g2.epilogue = BSI_EPI_GATE_RESID; g2.gate = ml + 5 * dim; g2.gate_rows = mod_rows; g2.gate_stride = mod_stride;
         g2.tokens = d.tokens;
-        if (int rc = bsi_gemm_bf16(&g2, stream)) return rc;
+        {
+            ProfScope prof(BSI_PROF_GEMM_FC2, s);
+            if (int rc = bsi_gemm_bf16(&g2, stream)) return rc;
+        }
     }
     if (tokens_out) {
         hipError_t e = hipMemcpyAsync(tokens_out, ws.x, (size_t)M * dim * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -170,6 +198,7 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         }
     }
     // 4. LayerNorm + Linear + unpatchify (+ x_hat = c_skip*mu + c_out*f)
+    ProfScope prof(BSI_PROF_FINAL, s);
     return bsi_dit_final_launch(ws.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, w->dec_b, cfg->C, cfg->H, cfg->W,
                                 cfg->patch, mu, c_skip, c_out, coef_stride, out, s);
 }

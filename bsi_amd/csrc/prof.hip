@@ -1,0 +1,69 @@
+// Optional in-library kernel timing with HIP events (used by bench.py to measure the dominant kernel's
+// average launch duration live, on the stream the kernels are launched on).  Disabled by default: when the
+// class mask is 0 the hooks are a single predictable branch.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+struct Pair {
+    hipEvent_t a, b;
+};
+unsigned g_mask = 0;
+std::vector<Pair> g_rec[BSI_PROF_NCLASS];
+std::vector<hipEvent_t> g_pool;
+std::mutex g_mu;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void bsi_prof_begin(int cls, hipStream_t s) {
+    if (!(g_mask & (1u << cls))) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Pair p{get_event(), get_event()};
+    (void)hipEventRecord(p.a, s);
+    g_rec[cls].push_back(p);
+}
+
+void bsi_prof_end(int cls, hipStream_t s) {
+    if (!(g_mask & (1u << cls))) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_rec[cls].empty()) (void)hipEventRecord(g_rec[cls].back().b, s);
+}
+
+extern "C" int bsi_prof_enable(unsigned mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_mask = mask;
+    return BSI_OK;
+}
+
+extern "C" int bsi_prof_read(int cls, int* count, double* total_ms) {
+    BSI_CHECK_ARG(cls >= 0 && cls < BSI_PROF_NCLASS && count && total_ms, "bsi_prof_read: bad args");
+    std::lock_guard<std::mutex> lk(g_mu);
+    double tot = 0.0;
+    int n = 0;
+    for (Pair& p : g_rec[cls]) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_rec[cls].clear();
+    *count = n;
+    *total_ms = tot;
+    return BSI_OK;
+}

@@ -224,6 +224,20 @@ int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/
                     const float* mod, int mod_rows, const float* c_in, const float* c_skip, const float* c_out,
                     int coef_stride, float* out, void* workspace, float* tokens_out, bsi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): per-kernel-class timing with HIP events on the launch stream.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    BSI_PROF_GEMM_QKV = 0, BSI_PROF_GEMM_OUT = 1, BSI_PROF_GEMM_FC1 = 2, BSI_PROF_GEMM_FC2 = 3,
+    BSI_PROF_ATTN = 4, BSI_PROF_LN = 5, BSI_PROF_PROLOGUE = 6, BSI_PROF_FINAL = 7, BSI_PROF_GEMM_ENC = 8,
+    BSI_PROF_ADALN = 9, BSI_PROF_NCLASS = 16
+};
+/* bit i of mask enables class i; 0 disables.  Events are recorded around every launch of an enabled class
+ * made through bsi_dit_forward / bsi_dit_adaln. */
+int bsi_prof_enable(unsigned mask);
+/* Waits for the recorded launches of `cls`, returns their count and summed duration, and clears them. */
+int bsi_prof_read(int cls, int* count, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

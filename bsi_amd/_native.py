@@ -70,7 +70,9 @@ _PROTOS = {
     "bsi_cast_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "bsi_nyquist_embed": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "bsi_gemm_set_variant": (_i, [_i]),
     "bsi_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "bsi_resid_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),

@@ -65,13 +65,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // tanh-approximated GELU, evaluated as torch does: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))).
+// 0.5*x*(1+tanh(u)) == x * sigmoid(2u) == x / (1 + 2^(-2u*log2 e)):  2 transcendentals (v_exp_f32, v_rcp_f32),
+// ~1e-6 relative error, far below the bf16 rounding that follows in every epilogue that uses it.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float inner = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(1+exp(2u)); exp overflow -> +inf -> tanh = 1, underflow -> -1: both exact limits
-    float e = __expf(2.0f * inner);
-    float th = 1.0f - 2.0f / (1.0f + e);
-    return 0.5f * x * (1.0f + th);
+    const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2*sqrt(2/pi)*log2(e)
+    const float b = a * 0.044715f;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(x * (a + b * x2));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}

@@ -133,14 +133,17 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         ProfScope prof(BSI_PROF_GEMM_ENC, s);
         if (int rc = bsi_gemm_bf16(&g, stream)) return rc;
     }
-    // 3. blocks (dit.py:87-103)
+    // 3. blocks (dit.py:87-103).  Every branch GEMM stores its output (bias included) as a bf16 "delta"; the gated
+    //    residual update x += gate*delta is fused into the NEXT LayerNorm+modulate pass (or the final kernel).
+    const void* pend_delta = nullptr;  // delta of the previous branch, not yet added to x
+    const float* pend_gate = nullptr;
     for (int l = 0; l < cfg->depth; ++l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
         const float* ml = mod + (size_t)l * 6 * dim;
         {
             ProfScope prof(BSI_PROF_LN, s);
-            if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml, ml + dim, mod_rows, mod_stride, d.tokens, nullptr,
-                                         nullptr, ws.xn, stream))
+            if (int rc = bsi_resid_ln_modulate(ws.x, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, mod_rows,
+                                               mod_stride, d.tokens, nullptr, nullptr, ws.xn, stream))
                 return rc;
         }
         bsi_gemm_args g{};
@@ -157,19 +160,18 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
                                            stream))
                 return rc;
         }
-        bsi_gemm_args go{};
-        go.A = ws.xn; go.W = bw.out_w; go.bias = bw.out_b; go.out = ws.x;
+        bsi_gemm_args go{};  // attention output projection -> delta (in the now dead qkv buffer)
+        go.A = ws.xn; go.W = bw.out_w; go.bias = bw.out_b; go.out = ws.big;
         go.M = M; go.N = dim; go.K = dim; go.lda = dim; go.ldw = dim; go.ldo = dim;
-        go.epilogue = BSI_EPI_GATE_RESID; go.gate = ml + 2 * dim; go.gate_rows = mod_rows; go.gate_stride = mod_stride;
-        go.tokens = d.tokens;
+        go.epilogue = BSI_EPI_BIAS_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_OUT, s);
             if (int rc = bsi_gemm_bf16(&go, stream)) return rc;
         }
-        {
+        {   // x += gate_msa * delta; xn = LN(x) * (1 + scale_mlp) + shift_mlp
             ProfScope prof(BSI_PROF_LN, s);
-            if (int rc = bsi_ln_modulate(ws.x, M, dim, 1e-5f, ml + 3 * dim, ml + 4 * dim, mod_rows, mod_stride,
-                                         d.tokens, nullptr, nullptr, ws.xn, stream))
+            if (int rc = bsi_resid_ln_modulate(ws.x, M, dim, 1e-5f, ws.big, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim,
+                                               mod_rows, mod_stride, d.tokens, nullptr, nullptr, ws.xn, stream))
                 return rc;
         }
         bsi_gemm_args g1{};
@@ -180,15 +182,23 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
             ProfScope prof(BSI_PROF_GEMM_FC1, s);
             if (int rc = bsi_gemm_bf16(&g1, stream)) return rc;
         }
-        bsi_gemm_args g2{};
-        g2.A = ws.big; g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = ws.x;
+        bsi_gemm_args g2{};  // MLP output -> delta (in the now dead xn buffer)
+        g2.A = ws.big; g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = ws.xn;
         g2.M = M; g2.N = dim; g2.K = 4 * dim; g2.lda = 4 * dim; g2.ldw = 4 * dim; g2.ldo = dim;
-        g2.epilogue = BSI_EPI_GATE_RESID; g2.gate = ml + 5 * dim; g2.gate_rows = mod_rows; g2.gate_stride = mod_stride;
-        g2.tokens = d.tokens;
+        g2.epilogue = BSI_EPI_BIAS_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_FC2, s);
             if (int rc = bsi_gemm_bf16(&g2, stream)) return rc;
         }
+        pend_delta = ws.xn;
+        pend_gate = ml + 5 * dim;
+    }
+    if (tokens_out) {  // tests: materialise the final residual stream
+        if (int rc = bsi_resid_ln_modulate(ws.x, M, dim, 1e-5f, pend_delta, pend_gate, nullptr, nullptr, mod_rows,
+                                           mod_stride, d.tokens, nullptr, nullptr, nullptr, stream))
+            return rc;
+        pend_delta = nullptr;
+        pend_gate = nullptr;
     }
     if (tokens_out) {
         hipError_t e = hipMemcpyAsync(tokens_out, ws.x, (size_t)M * dim * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -200,5 +210,6 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
     // 4. LayerNorm + Linear + unpatchify (+ x_hat = c_skip*mu + c_out*f)
     ProfScope prof(BSI_PROF_FINAL, s);
     return bsi_dit_final_launch(ws.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, w->dec_b, cfg->C, cfg->H, cfg->W,
-                                cfg->patch, mu, c_skip, c_out, coef_stride, out, s);
+                                cfg->patch, mu, c_skip, c_out, coef_stride, pend_delta, pend_gate, mod_rows, mod_stride, out,
+                                s);
 }

@@ -45,24 +45,39 @@ __global__ void nyquist_kernel(const float* __restrict__ t, int rows, const floa
 // One wave per row.  LayerNorm statistics in fp32 (two-pass over registers), then
 // out = fma(1 + scale, (x - mean) * rstd, shift)   (dit.py:50-55: addcmul(shift, scale + 1, norm(x)))
 // or, without modulation, the affine LayerNorm  normed * w + b  (dit.py:163).
+// With `delta` (bf16 [M,d]) and `gate`: first the gated residual update of the block
+//     x[m,:] += gate[row] * delta[m,:]          (dit.py:93-97 / 98-102: torch.addcmul(x, gate, branch))
+// is applied and written back (fp32), then the norm runs on the updated row — one streaming pass instead of a
+// read-modify-write inside the GEMM epilogue.  `delta` may alias `out` (a wave reads its row before writing it).
 template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
-__global__ void ln_modulate_kernel(const float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
+__global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
                                    const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                   __bf16* __restrict__ out) {
+                                   const __bf16* delta, const float* __restrict__ gate, __bf16* out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (size_t)row * d;
+    float* xr = x + (size_t)row * d;
     const int d4 = d >> 2;
+    const int mrow = (shift || gate) ? (row / tokens) % mod_rows : 0;
     f32x4 v[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
         v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (delta && c < d4) {
+            const u32x2 dw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)row * d) + c);
+            const f32x4 g = reinterpret_cast<const f32x4*>(gate + (size_t)mrow * mod_stride)[c];
+            v[i][0] = __fmaf_rn(g[0], __uint_as_float(dw[0] << 16), v[i][0]);
+            v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
+            v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
+            v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
+            reinterpret_cast<f32x4*>(xr)[c] = v[i];
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
+    if (!out) return;
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -77,7 +92,6 @@ __global__ void ln_modulate_kernel(const float* __restrict__ x, int M, int d, fl
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
-    const int mrow = shift ? (row / tokens) % mod_rows : 0;
     const float* sh = shift ? shift + (size_t)mrow * mod_stride : nullptr;
     const float* sc = scale ? scale + (size_t)mrow * mod_stride : nullptr;
     __bf16* orow = out + (size_t)row * d;
@@ -169,7 +183,9 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
                                  const float* __restrict__ ln_b, const float* __restrict__ dec_w,
                                  const float* __restrict__ dec_b, int C, int H, int W, int ps,
                                  const float* __restrict__ mu, const float* __restrict__ c_skip,
-                                 const float* __restrict__ c_out, int coef_stride, float* __restrict__ out) {
+                                 const float* __restrict__ c_out, int coef_stride, const __bf16* __restrict__ delta,
+                                 const float* __restrict__ gate, int gate_rows, int gate_stride,
+                                 float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // [P][d]
     const int d4 = d >> 2;
     for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
@@ -182,12 +198,21 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
     const int HW = H * W;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Mtok; row += gridDim.x * wpb) {
         const float* xr = x + (size_t)row * d;
+        const int b_idx = row / tokens, tok = row % tokens;
         f32x4 v[VPL];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = i * 64 + lane;
             v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (delta && c < d4) {  // pending gated residual of the last block's MLP branch (dit.py:98-102)
+                const u32x2 dw = reinterpret_cast<const u32x2*>(delta + (size_t)row * d)[c];
+                const f32x4 g = reinterpret_cast<const f32x4*>(gate + (size_t)(b_idx % gate_rows) * gate_stride)[c];
+                v[i][0] = __fmaf_rn(g[0], __uint_as_float(dw[0] << 16), v[i][0]);
+                v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
+                v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
+                v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         const float mean = wave_sum(s) / (float)d;
@@ -214,7 +239,6 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
                 for (int k = 0; k < 4; ++k) v[i][k] = __fmaf_rn((v[i][k] - mean) * rstd, a[k], b[k]);
             }
         }
-        const int b_idx = row / tokens, tok = row % tokens;
         const int th = tok / nw, tw = tok % nw;
         float mine = 0.f;
         for (int o = 0; o < P; ++o) {  // P <= 64: lane o keeps output o
@@ -283,27 +307,39 @@ extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, c
     return BSI_OK;
 }
 
-extern "C" int bsi_ln_modulate(const float* x, int M, int d, float eps, const float* shift, const float* scale,
-                               int mod_rows, int mod_stride, int tokens, const float* ln_w, const float* ln_b,
-                               void* out_bf16, bsi_stream_t stream) {
-    BSI_CHECK_ARG(x && out_bf16 && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_ln_modulate: bad args M=%d d=%d", M, d);
-    BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_ln_modulate: shift and scale go together");
-    BSI_CHECK_ARG(!shift || (mod_rows > 0 && tokens > 0 && mod_stride % 4 == 0), "bsi_ln_modulate: bad modulation table");
-    BSI_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "bsi_ln_modulate: ln weight and bias go together");
+extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, const float* gate,
+                                     const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
+                                     const float* ln_w, const float* ln_b, void* out_bf16, bsi_stream_t stream) {
+    BSI_CHECK_ARG(x && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_resid_ln_modulate: bad args M=%d d=%d", M, d);
+    BSI_CHECK_ARG(out_bf16 || delta, "bsi_resid_ln_modulate: nothing to do");
+    BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_resid_ln_modulate: shift and scale go together");
+    BSI_CHECK_ARG((delta == nullptr) == (gate == nullptr), "bsi_resid_ln_modulate: delta and gate go together");
+    BSI_CHECK_ARG(!(shift || gate) || (mod_rows > 0 && tokens > 0 && mod_stride % 4 == 0),
+                  "bsi_resid_ln_modulate: bad modulation table");
+    BSI_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "bsi_resid_ln_modulate: ln weight and bias go together");
     const int wpb = TPB / 64;
     dim3 grid((M + wpb - 1) / wpb);
     __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
+    const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, o);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
     else if (d <= 1024)
         hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, o);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
     else
         hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, o);
-    BSI_CHECK_LAUNCH("bsi_ln_modulate");
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
+    BSI_CHECK_LAUNCH("bsi_resid_ln_modulate");
     return BSI_OK;
+}
+
+extern "C" int bsi_ln_modulate(const float* x, int M, int d, float eps, const float* shift, const float* scale,
+                               int mod_rows, int mod_stride, int tokens, const float* ln_w, const float* ln_b,
+                               void* out_bf16, bsi_stream_t stream) {
+    BSI_CHECK_ARG(out_bf16, "bsi_ln_modulate: null output");
+    return bsi_resid_ln_modulate(const_cast<float*>(x), M, d, eps, nullptr, nullptr, shift, scale, mod_rows, mod_stride,
+                                 tokens, ln_w, ln_b, out_bf16, stream);
 }
 
 int bsi_dit_prologue_launch(const float* mu, const float* c_in, int coef_stride, int B, int C, int H, int W, int ps,
@@ -319,7 +355,8 @@ int bsi_dit_prologue_launch(const float* mu, const float* c_in, int coef_stride,
 
 int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
                          const float* dec_w, const float* dec_b, int C, int H, int W, int ps, const float* mu,
-                         const float* c_skip, const float* c_out, int coef_stride, float* out, hipStream_t s) {
+                         const float* c_skip, const float* c_out, int coef_stride, const void* delta, const float* gate,
+                         int gate_rows, int gate_stride, float* out, hipStream_t s) {
     const size_t lds = (size_t)P * d * sizeof(float);
     if (lds > 160 * 1024 || P > 64) {
         bsi_set_error("bsi_dit_final: decoder P=%d d=%d unsupported (needs P <= 64 and P*d*4 <= 160 KiB)", P, d);
@@ -334,7 +371,8 @@ int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln
         auto kern = dit_final_kernel<V>;                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, ln_w, ln_b, dec_w, dec_b, C, H, W, ps, \
-                           mu, c_skip, c_out, coef_stride, out);                                                     \
+                           mu, c_skip, c_out, coef_stride, reinterpret_cast<const __bf16*>(delta), gate,             \
+                           gate_rows > 0 ? gate_rows : 1, gate_stride, out);                                         \
     } while (0)
     if (d <= 256) LAUNCH_FINAL(1);
     else if (d <= 1024) LAUNCH_FINAL(4);

@@ -40,7 +40,20 @@ struct GemmParams {
     int tokens;
     const float* pos;
     int tiles_m, tiles_n;
+    int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
+    int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
 };
+
+// tile index (n-fastest order when gm == 1) -> (tm, tn).  Inside an XCD 32 consecutive tiles run together; with
+// bands of gm m-tiles they form a gm x (32/gm) block, so an A panel is shared by 32/gm CUs and a W panel by gm.
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm, int& tn) {
+    const int band_tiles = p.gm * p.tiles_n;
+    const int band = t / band_tiles;
+    const int r = t - band * band_tiles;
+    const int rows = min(p.gm, p.tiles_m - band * p.gm);  // last band may be short
+    tm = band * p.gm + r % rows;
+    tn = r / rows;
+}
 
 template <int EPI>
 struct EpiTraits {
@@ -53,6 +66,105 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
+}
+
+// `scratch`: this wave's private 16 KB of LDS (or nullptr).  With it, bf16 outputs are transposed through LDS so
+// that every global_store_dwordx4 instruction writes 8 complete 128-B lines (8 lanes x 16 B per row).  Without it a
+// row's line is written as 16-B pieces by several instructions, and the L2 answers such partial-line writes with a
+// fill read of the destination line (measured: fabric reads grew by exactly the output size).
+template <int TM, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][TM], int mw0, int nw0, int lane,
+                                              char* scratch = nullptr) {
+    // lane owns rows m = mw0 + 16j + (lane&15), columns nb .. nb+15
+    const int nb = nw0 + 16 * (lane >> 4);
+    const bool nb_ok = nb < p.N;
+    float bias[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mw0 + 16 * j + (lane & 15);
+        if ((m >= p.M || !nb_ok) && !(EpiTraits<EPI>::out_bf16 && scratch)) continue;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+
+        if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+        } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
+        }
+
+        if constexpr (EpiTraits<EPI>::out_bf16) {
+            u32x4 w0, w1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            }
+            if (scratch) {
+                // row r of the wave's [16*TM][128 B] image, 16-B chunks XOR-swizzled by (r & 7)
+                const int r = 16 * j + (lane & 15), q2 = (lane >> 4) * 2;
+                *reinterpret_cast<u32x4*>(scratch + r * 128 + (((q2) ^ (r & 7)) << 4)) = w0;
+                *reinterpret_cast<u32x4*>(scratch + r * 128 + (((q2 + 1) ^ (r & 7)) << 4)) = w1;
+            } else {
+                __bf16* o = reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nb;
+                __builtin_nontemporal_store(w0, reinterpret_cast<u32x4*>(o));
+                __builtin_nontemporal_store(w1, reinterpret_cast<u32x4*>(o + 8));
+            }
+        } else {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + nb;
+            if constexpr (EPI == BSI_EPI_GATE_RESID) {
+                const int row = (m / p.tokens) % p.gate_rows;
+                const float* g = p.gate + (size_t)row * p.gate_stride + nb;
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(o + e);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] = xv[r] + gv[r] * v[e + r];
+                    *reinterpret_cast<f32x4*>(o + e) = xv;
+                }
+            } else {
+                if constexpr (EPI == BSI_EPI_BIAS_POS_F32) {
+                    const float* ps = p.pos + (size_t)(m % p.tokens) * p.N + nb;
+#pragma unroll
+                    for (int e = 0; e < 16; e += 4) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + e);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[e + r] += pv[r];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 4)
+                    __builtin_nontemporal_store(f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]}, reinterpret_cast<f32x4*>(o + e));
+            }
+        }
+    }
+    if constexpr (EpiTraits<EPI>::out_bf16) {
+        if (scratch) {
+            // the wave reads back its own writes: LDS accesses of one wave are ordered, only the counter must drain
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int rr = lane >> 3, ch = lane & 7;
+            const bool cols_ok = nw0 + 8 * ch < p.N;
+#pragma unroll
+            for (int t = 0; t < 2 * TM; ++t) {
+                const int r = 8 * t + rr;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
+                const int m = mw0 + r;
+                if (m < p.M && cols_ok)
+                    __builtin_nontemporal_store(
+                        d, reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nw0 + 8 * ch));
+            }
+        }
+    }
 }
 
 template <int TM, int WM, int WN, int EPI>
@@ -149,72 +261,838 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
         }
     }
 
-    // ---- epilogue: lane owns rows m = m0 + wm*TM*16 + 16j + (lane&15), columns nb .. nb+15 ------------
-    const int nb = n0 + wn * 64 + 16 * (lane >> 4);
-    if (nb >= p.N) return;
-    float bias[16];
+    gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong schedule (variant 1).  The 8 waves form two groups (waves 0-3: upper half of the M tile, waves 4-7:
+// lower half); waves w and w+4 share a SIMD.  Every wave runs the phase sequence
+//     L0(kt): ds_read fragments of k-step 0 (+ issue the global_load_lds of tile kt+1)
+//     C0(kt): 32 MFMA            L1(kt): ds_read fragments of k-step 1, wait for its own tile-(kt+1) loads
+//     C1(kt): 32 MFMA
+// with one s_barrier between phases, and group B runs ONE phase behind group A.  So in every phase exactly one
+// wave per SIMD issues MFMAs while its partner reads LDS / issues DMA: the matrix pipe never waits for LDS
+// latency or the barrier.  Hazards (two LDS buffers, tile kt in buffer kt&1):
+//   RAW  tile kt+1 is read first by group A in its L0(kt+1); every wave drained its own loads of tile kt+1
+//        (vmcnt(0)) in its L1(kt), which for both groups ends at least one barrier earlier;
+//   WAR  loads of tile kt+2 are issued in L0(kt+1) of each wave into the buffer of tile kt, whose last reads
+//        (group B's L1(kt)) completed (lgkmcnt(0)) one barrier earlier.
+// ABL: compile-time ablation bits used only by tools/experiments/gemm_lab.hip (0 in the product):
+//   1 = no global_load_lds in the loop, 2 = no ds_read in the loop, 4 = no epilogue, 8 = no barriers in the loop.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+    constexpr int TM = 8, WN = 4, NW = 8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int ROWS = BM + BN;
+    constexpr int BUF_BYTES = ROWS * ROW_BYTES;
+    constexpr int STAGE_INSTR = 8;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    const char* gsrc[STAGE_INSTR];
 #pragma unroll
-    for (int e = 0; e < 16; e += 4) {
-        f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+    for (int q = 0; q < STAGE_INSTR; ++q) {
+        const int r = (q * NW + wave) * 8 + srow;
+        if (r < BM) {
+            const int c = schunk ^ ((r >> 1) & 7);
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
+        } else {
+            const int rw = r - BM;
+            const int c = schunk ^ (((rw >> 1) & 1) | (((rw >> 4) & 3) << 1));
+            int n = n0 + rw;
+            n = n < p.N ? n : p.N - 1;
+            gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
+        }
     }
+    auto stage = [&](int kt, int buf) {
+        char* base = lds + buf * BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * TM * 16 + 16 * j + (lane & 15);
-        if (m >= p.M) continue;
-        float v[16];
+        for (int q = 0; q < STAGE_INSTR; ++q) {
+            char* dst = base + (q * NW + wave) * 8 * ROW_BYTES;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kt * ROW_BYTES), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    const int fx = (lane >> 1) & 7;
+    const int xoff = (wm * TM * 16 + (lane & 15)) * ROW_BYTES;
+    const int woff = (BM + wn * 64 + 16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
+    const int c0 = (((lane >> 4)) ^ fx) << 4;
+    const int c1 = (((lane >> 4) + 4) ^ fx) << 4;
+
+    f32x4 acc[4][TM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 wf[4], xf[TM];
+    auto load_frags = [&](const char* b, int cc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * ROW_BYTES + cc);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * ROW_BYTES + cc);
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    const int nk = p.K / BK;
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    if constexpr (ABL & 2) load_frags(lds, c0);
+    // experiment (ABL & 16): touch the 128-B lines of K step kt+PF so that they are L2-resident when the DMA asks
+    constexpr int PF = 3;
+    const char* pfrow;
+    {
+        const int r = tid;  // one LDS row (= one 128-B line per K step) per thread
+        if (r < BM) { int m = m0 + r; m = m < p.M ? m : p.M - 1; pfrow = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda); }
+        else { int n = n0 + r - BM; n = n < p.N ? n : p.N - 1; pfrow = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw); }
+    }
+    unsigned pfdummy = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* b = lds + (kt & 1) * BUF_BYTES;
+        // L0
+        if constexpr (!(ABL & 2)) load_frags(b, c0);
+        if constexpr (!(ABL & 1)) {
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        }
+        bool pf_issued = false;
+        if constexpr (ABL & 16) {
+            if (kt + PF < nk) {
+                const char* a = pfrow + (size_t)(kt + PF) * ROW_BYTES;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pfdummy) : "v"(a) : "memory");
+                pf_issued = true;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 8)) PHASE_BARRIER();
+        // C0
+        compute();
+        if constexpr (!(ABL & 8)) PHASE_BARRIER();
+        // L1
+        if constexpr (!(ABL & 2)) load_frags(b, c1);
+        if (pf_issued) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 8)) PHASE_BARRIER();
+        // C1
+        compute();
+        if constexpr (!(ABL & 8)) PHASE_BARRIER();
+    }
+    if (wm == 0) PHASE_BARRIER();  // balance the barrier count of the two groups
+#undef PHASE_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfdummy)::"memory");
+
+    if constexpr (ABL & 4) {
+        float sacc = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+    } else {
+        gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane, lds + wave * 16384);
+    }
+}
 
-        if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
-        } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
-        }
 
-        if constexpr (EpiTraits<EPI>::out_bf16) {
-            __bf16* o = reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nb;
-            u32x4 w0, w1;
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2: two workgroups per CU.  Workgroup = 4 waves (one per SIMD), tile 128(M) x 256(N), K step 32,
+// three-slot LDS ring (72 KB, so two workgroups share a CU's 160 KB and 2 waves sit on every SIMD).
+// Per K step: counted vmcnt (the newest stage stays in flight) -> one barrier -> issue the DMA of stage kt+3
+// into the slot just freed -> ds_read the fragments of step kt+1 into the alternate register set -> 32 MFMA on
+// the current set.  Loads run three K steps ahead of the math; the LDS->register reads of the next step and the
+// DMA issue hide behind this wave's own MFMAs, barrier waits and the whole epilogue hide behind the co-resident
+// workgroup, which is at an unrelated phase (no chip-wide lock step of store bursts).
+// LDS rows are 64 B (4 chunks of 16 B): chunk' = chunk ^ ((-(rowgroup)) & 3) with rowgroup = (row>>2)&3 for
+// activation rows and (row>>4)&3 for the permuted weight rows makes every ds_read_b128 conflict free.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_w4_kernel(const GemmParams p) {
+    constexpr int TM = 8;
+    constexpr int BM = 128, BN = 256, BKS = 32;
+    constexpr int RB = 64;                        // bytes per LDS row
+    constexpr int SLOT_BYTES = (BM + BN) * RB;    // 24 KB
+    constexpr int A_BYTES = BM * RB;              // 8 KB
+    constexpr int NSLOT = 3;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = wn
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging: 24 wave-instructions of 16 rows x 64 B per stage; wave w issues instruction slots q*4 + w
+    const int srow = lane >> 2, spos = lane & 3;
+    unsigned goff[6];  // byte offsets from p.A (q < 2) / p.W (q >= 2); the launcher guarantees they fit 32 bits
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-            }
-            *reinterpret_cast<u32x4*>(o) = w0;
-            *reinterpret_cast<u32x4*>(o + 8) = w1;
-        } else {
-            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + nb;
-            if constexpr (EPI == BSI_EPI_GATE_RESID) {
-                const int row = (m / p.tokens) % p.gate_rows;
-                const float* g = p.gate + (size_t)row * p.gate_stride + nb;
-#pragma unroll
-                for (int e = 0; e < 16; e += 4) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
-                    f32x4 xv = *reinterpret_cast<const f32x4*>(o + e);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xv[r] = xv[r] + gv[r] * v[e + r];
-                    *reinterpret_cast<f32x4*>(o + e) = xv;
-                }
-            } else {
-                if constexpr (EPI == BSI_EPI_BIAS_POS_F32) {
-                    const float* ps = p.pos + (size_t)(m % p.tokens) * p.N + nb;
-#pragma unroll
-                    for (int e = 0; e < 16; e += 4) {
-                        const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + e);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[e + r] += pv[r];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e += 4)
-                    *reinterpret_cast<f32x4*>(o + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
-            }
+    for (int q = 0; q < 6; ++q) {
+        const int slot = q * 4 + wave;
+        if (q < 2) {  // activation rows 0..127
+            const int r = slot * 16 + srow;
+            const int c = spos ^ ((-(r >> 2)) & 3);
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            goff[q] = (unsigned)m * (unsigned)(p.lda * 2) + c * 16;
+        } else {  // weight rows 0..255
+            const int rw = (slot - 8) * 16 + srow;
+            const int c = spos ^ ((-(rw >> 4)) & 3);
+            int n = n0 + rw;
+            n = n < p.N ? n : p.N - 1;
+            goff[q] = (unsigned)n * (unsigned)(p.ldw * 2) + c * 16;
         }
     }
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    auto stage = [&](int kt, int slot) {
+        char* base = lds + slot * SLOT_BYTES;
+        const char* ak = Ab + (size_t)kt * (BKS * 2);  // wave-uniform bases -> saddr + 32-bit voffset addressing
+        const char* wk = Wb + (size_t)kt * (BKS * 2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            char* dst = base + (q * 4 + wave) * 1024;  // instruction slot s covers LDS rows [16s, 16s+16)
+            __builtin_amdgcn_global_load_lds(GLB_PTR((q < 2 ? ak : wk) + goff[q]), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses
+    const int rho = lane & 15, qd = lane >> 4;
+    const int cc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
+    const int xoff = rho * RB + cc;
+    const int woff = A_BYTES + (wave * 64 + 16 * (rho >> 2) + (rho & 3)) * RB + cc;
+
+    f32x4 acc[4][TM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 wf0[4], xf0[TM], wf1[4], xf1[TM];
+#define LOAD_FRAGS(WF, XF, SLOT)                                                                       \
+    do {                                                                                               \
+        const char* b_ = lds + (SLOT) * SLOT_BYTES;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+            WF[i] = *reinterpret_cast<const bf16x8*>(b_ + woff + i * 4 * RB);                          \
+        _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                 \
+            XF[j] = *reinterpret_cast<const bf16x8*>(b_ + xoff + j * 16 * RB);                         \
+    } while (0)
+#define COMPUTE(WF, XF)                                                                                \
+    do {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); \
+    } while (0)
+    // one K step: frags of step kt are in (WFc, XFc); prefetch step kt+1 into (WFn, XFn)
+#define KSTEP(kt, WFc, XFc, WFn, XFn)                                                                  \
+    do {                                                                                               \
+        if ((kt) + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if constexpr (!(ABL & 1)) {                                                                    \
+            if ((kt) + 3 < nk) stage((kt) + 3, slot_c);                                                \
+        }                                                                                              \
+        if ((kt) + 1 < nk) LOAD_FRAGS(WFn, XFn, slot_n);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        COMPUTE(WFc, XFc);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        slot_c = slot_n;                                                                               \
+        slot_n = (slot_n == NSLOT - 1) ? 0 : slot_n + 1;                                               \
+    } while (0)
+
+    const int nk = p.K / BKS;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    LOAD_FRAGS(wf0, xf0, 0);
+    int slot_c = 0, slot_n = 1;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        KSTEP(kt, wf0, xf0, wf1, xf1);
+        KSTEP(kt + 1, wf1, xf1, wf0, xf0);
+    }
+    if (kt < nk) KSTEP(kt, wf0, xf0, wf1, xf1);
+#undef KSTEP
+#undef COMPUTE
+#undef LOAD_FRAGS
+
+    if constexpr (ABL & 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+    } else {
+        gemm_epilogue<TM, EPI>(p, acc, m0, n0 + wave * 64, lane);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 3 (default): PERSISTENT ping-pong.  One workgroup per CU walks its share of the output tiles; the
+// phase sequence of variant 1 simply continues across tile boundaries:
+//     ... L1 C1 | E(tile T) | L0 C0 L1 C1 ... (tile T+1)
+// The DMA of the next tile's first K step is issued in the last L0 of the current tile (the LDS buffer parity
+// keeps alternating), so no tile starts with a cold prologue, and because group B runs one phase behind group
+// A, A's epilogue overlaps B's last MFMA phase and B's epilogue overlaps A's first loads: per tile the matrix
+// pipe idles for about one epilogue instead of prologue + epilogue + store drain.  Epilogue stores are
+// fire-and-forget; they retire (in vmcnt order) before the next L1's vmcnt(0), two phases later.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_ppp_kernel(const GemmParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int ROWS = BM + BN;
+    constexpr int BUF_BYTES = ROWS * ROW_BYTES;
+    constexpr int STAGE_INSTR = 8;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // tiles of this workgroup: XCD x = blockIdx % 8 owns the contiguous chunk [lo, hi) of the n-fastest tile order;
+    // its workgroups take tiles lo + (blockIdx / 8), stepping by the number of workgroups on that XCD.
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;  // workgroups living on this XCD
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;  // fewer tiles than workgroups on this XCD (whole workgroup leaves together)
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    const char* gsrc[STAGE_INSTR];
+    auto set_sources = [&](int t) {
+        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+#pragma unroll
+        for (int q = 0; q < STAGE_INSTR; ++q) {
+            const int r = (q * NW + wave) * 8 + srow;
+            if (r < BM) {
+                const int c = schunk ^ ((r >> 1) & 7);
+                int m = m0 + r;
+                m = m < p.M ? m : p.M - 1;
+                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
+            } else {
+                const int rw = r - BM;
+                const int c = schunk ^ (((rw >> 1) & 1) | (((rw >> 4) & 3) << 1));
+                int n = n0 + rw;
+                n = n < p.N ? n : p.N - 1;
+                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
+            }
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        char* base = lds + buf * BUF_BYTES;
+#pragma unroll
+        for (int q = 0; q < STAGE_INSTR; ++q) {
+            char* dst = base + (q * NW + wave) * 8 * ROW_BYTES;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kt * ROW_BYTES), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    const int fx = (lane >> 1) & 7;
+    const int xoff = (wm * TM * 16 + (lane & 15)) * ROW_BYTES;
+    const int woff = (BM + wn * 64 + 16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
+    const int c0 = (((lane >> 4)) ^ fx) << 4;
+    const int c1 = (((lane >> 4) + 4) ^ fx) << 4;
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+    auto load_frags = [&](const char* b, int cc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * ROW_BYTES + cc);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * ROW_BYTES + cc);
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    const int nk = p.K / BK;
+    if (p.stagger > 0) {
+        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    set_sources(tile);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int v = 0;  // running K-step count: LDS buffer parity continues across tiles
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt, ++v) {
+            const char* b = lds + (v & 1) * BUF_BYTES;
+            // L0
+            load_frags(b, c0);
+            if (kt + 1 < nk) {
+                stage(kt + 1, (v + 1) & 1);
+            } else if (has_next) {
+                set_sources(next);
+                stage(0, (v + 1) & 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            compute();  // C0
+            PHASE_BARRIER();
+            load_frags(b, c1);  // L1
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            compute();  // C1
+            PHASE_BARRIER();
+        }
+        // E
+        if constexpr (ABL & 4) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+        } else {
+            gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
+        }
+        PHASE_BARRIER();
+        if (!has_next) break;
+        tile = next;
+    }
+    if (wm == 0) PHASE_BARRIER();  // balance the barrier count of the two groups
+#undef PHASE_BARRIER
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 4: ping-pong wave groups over a DEEP LDS ring.  Tile 256 x 256, K step 32, ring of R slots of 32 KB
+// (R = 5 uses all 160 KB of the CU).  The L2->LDS DMA path moves at most ~70 GB/s per CU, i.e. a 64-KB K=64
+// stage needs ~0.9 us of transfer on top of its latency, more than the ~1.1 us one such stage of MFMA work lasts:
+// with two 64-KB buffers the DMA queue runs dry every step.  Here R-1 stages (up to 128 KB) are in flight,
+// issued 4 per wave per phase with a counted vmcnt, so the DMA path streams continuously while the two wave
+// groups alternate L (12 ds_read_b128 + 4 DMA issues) and C (32 MFMA) phases one barrier apart.
+//   RAW: stage v+1 is waited for (vmcnt(4*(D-1))) by every wave at the end of its L(v); group A reads it two
+//        barriers later at the earliest.   WAR: stage v+D overwrites the slot of tile v-1, whose last reads
+//        (group B's L(v-1)) finished one barrier before group A issues it.   D = R-1.
+template <int EPI, int R, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int RB = 64;                       // bytes per LDS row (K step 32)
+    constexpr int SLOT_BYTES = (BM + BN) * RB;   // 32 KB
+    constexpr int A_BYTES = BM * RB;
+    constexpr int D = R - 1;
+    constexpr int KSB = 64;                      // global bytes per K step
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging: 32 wave-instructions (16 rows x 64 B) per stage, wave w issues instruction slots q*8 + w, q < 4
+    const int srow = lane >> 2, spos = lane & 3;
+    const char* gsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = q * NW + wave;  // 0..15 activation rows, 16..31 weight rows
+        if (q < 2) {
+            const int r = slot * 16 + srow;
+            const int c = spos ^ ((-(r >> 2)) & 3);
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
+        } else {
+            const int rw = (slot - 16) * 16 + srow;
+            const int c = spos ^ ((-(rw >> 4)) & 3);
+            int n = n0 + rw;
+            n = n < p.N ? n : p.N - 1;
+            gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
+        }
+    }
+    auto stage = [&](int v, int slot) {
+        char* base = lds + slot * SLOT_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            char* dst = base + (q * NW + wave) * 1024;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)v * KSB), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int cc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
+    const int xoff = (wm * TM * 16 + rho) * RB + cc;
+    const int woff = A_BYTES + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB + cc;
+
+    f32x4 acc[4][TM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 wf[4], xf[TM];
+    auto load_frags = [&](const char* b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
+    };
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    const int nk = p.K / 32;
+    // prologue: stages 0..D-1 in flight, stage 0 landed
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) stage(d, d);
+    if (nk >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int slot = 0, pslot = D;  // slot of tile v, slot receiving tile v+D
+    for (int v = 0; v < nk; ++v) {
+        // L(v)
+        load_frags(lds + slot * SLOT_BYTES);
+        if constexpr (!(ABL & 1)) {
+            if (v + D < nk) stage(v + D, pslot);
+        }
+        // stage v+1 must have landed (own part): allow the D-1 younger stages to stay in flight
+        if (v + D < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE_BARRIER();
+        // C(v)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_BARRIER();
+        slot = (slot == R - 1) ? 0 : slot + 1;
+        pslot = (pslot == R - 1) ? 0 : pslot + 1;
+    }
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
+
+    if constexpr (ABL & 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+    } else {
+        gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane, lds + wave * 16384);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 6: PERSISTENT deep-ring ping-pong (the production schedule).
+//   * one workgroup per CU walks its tiles; tile 256 x 256, K step 32, ring of R = 4 slots of 32 KB + 32 KB
+//     of per-wave epilogue scratch = the whole 160 KB of LDS;
+//   * the DMA stream never stops at a tile boundary: from step nk-D on, the stages issued belong to the NEXT
+//     tile, so a tile never starts cold and the previous tile's output stores (16 per wave, issued in E) have
+//     2 K steps + the epilogue to retire before a vmcnt wait reaches them (the two L phases after E allow 16
+//     extra outstanding operations);
+//   * groups A/B alternate L and C phases as in variant 4; the epilogue E of group A runs right after the
+//     barrier that ends its last C phase, that of group B right after its last C phase before the barrier,
+//     so both epilogues (VALU bound, two waves per SIMD) overlap each other: one epilogue of idle matrix pipe
+//     per tile instead of prologue + two epilogues + store drain;
+//   * bf16 outputs leave through the LDS scratch in 4 rounds of 32 rows so that every store instruction writes
+//     whole 128-B lines.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p) {
+    constexpr int TM = 8, NW = 8, R = 4, D = R - 1;
+    constexpr int BM = 256, BN = 256;
+    constexpr int RB = 64;
+    constexpr int SLOT_BYTES = (BM + BN) * RB;
+    constexpr int A_BYTES = BM * RB;
+    constexpr int KSB = 64;
+    constexpr bool BF16_OUT = EpiTraits<EPI>::out_bf16;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    char* scratch = lds + R * SLOT_BYTES + wave * 4096;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;
+
+    const int srow = lane >> 2, spos = lane & 3;
+    const char* gsrc[4];
+    auto set_sources = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+        const int m0 = tm_ * BM, n0 = tn_ * BN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = q * NW + wave;
+            if (q < 2) {
+                const int r = slot * 16 + srow;
+                const int c = spos ^ ((-(r >> 2)) & 3);
+                int m = m0 + r;
+                m = m < p.M ? m : p.M - 1;
+                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
+            } else {
+                const int rw = (slot - 16) * 16 + srow;
+                const int c = spos ^ ((-(rw >> 4)) & 3);
+                int n = n0 + rw;
+                n = n < p.N ? n : p.N - 1;
+                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
+            }
+        }
+    };
+    auto stage = [&](int kstep, int slot) {
+        char* base = lds + slot * SLOT_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            char* dst = base + (q * NW + wave) * 1024;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kstep * KSB), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int cc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
+    const int xoff = (wm * TM * 16 + rho) * RB + cc;
+    const int woff = A_BYTES + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB + cc;
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    auto epilogue = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+        const int mw0 = tm_ * BM + wm * TM * 16, nw0 = tn_ * BN + wn * 64;
+        if constexpr (ABL & 4) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+        } else if constexpr (BF16_OUT) {
+            const int nb = nw0 + 16 * qd;
+            const bool nb_ok = nb < p.N;
+            float bias[16];
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+            }
+            const int rr = lane >> 3, ch = lane & 7;
+            const bool cols_ok = nw0 + 8 * ch < p.N;
+#pragma unroll
+            for (int rnd = 0; rnd < TM / 2; ++rnd) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * rnd + jj;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
+                    }
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                        w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                    }
+                    const int r = 16 * jj + rho;  // row within this round's 32-row image
+                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
+                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u32x4 d[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int r = 8 * t4 + rr;
+                    d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int m = mw0 + 32 * rnd + 8 * t4 + rr;
+                    if (m < p.M && cols_ok) {
+                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nw0 + 8 * ch);
+                        // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
+                        // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
+                        if constexpr (ABL & 32) *dst = d[t4];
+                        else __builtin_nontemporal_store(d[t4], dst);
+                    }
+                }
+            }
+        } else {
+            gemm_epilogue<TM, EPI>(p, acc, mw0, nw0, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fp32 read-modify-write paths: simple drain
+        }
+    };
+
+    const int nk = p.K / 32;  // launcher guarantees nk >= D
+    set_sources(tile);
+#pragma unroll
+    for (int d = 0; d < D; ++d) stage(d, d);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int slot = 0, pslot = D;
+    int after_e = 0;  // L phases since the last epilogue whose stores may still be in flight
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < nk; ++v) {
+            // ---- L(v)
+            {
+                const char* b = lds + slot * SLOT_BYTES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
+            }
+            bool issued = false;
+            if constexpr (!(ABL & 1)) {
+                if (v + D < nk) {
+                    stage(v + D, pslot);
+                    issued = true;
+                } else if (has_next) {
+                    if (v + D == nk) set_sources(next);
+                    stage(v + D - nk, pslot);
+                    issued = true;
+                }
+            }
+            // the stage of step v+1 must have landed; younger stages (and, right after an epilogue, its 16
+            // stores) may stay in flight
+            if (issued) {
+                if (BF16_OUT && after_e > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1) + 16) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (after_e > 0) --after_e;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            // ---- C(v)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
+            PHASE_BARRIER();
+            slot = (slot == R - 1) ? 0 : slot + 1;
+            pslot = (pslot == R - 1) ? 0 : pslot + 1;
+        }
+        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
+        after_e = 2;
+        if (!has_next) break;
+        tile = next;
+    }
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
 }
 
 template <int TM, int WM, int WN, int EPI>
@@ -235,8 +1113,133 @@ int launch_cfg(const GemmParams& p0, hipStream_t s) {
     return BSI_OK;
 }
 
+int g_variant = 6;  // 0: two-barrier double buffer, 1: ping-pong wave groups, 2: two workgroups per CU,
+                    // 3: persistent ping-pong (default)
+int g_stagger = 0;
+int g_gm = 1;
+int g_num_cus = 0;
+
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <int EPI, int R>
+int launch_ring(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = (size_t)R * 512 * 64;
+    auto kern = gemm_bf16_ring_kernel<EPI, R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+int num_cus();
+
+template <int EPI>
+int launch_pring(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const size_t lds = 4 * (size_t)512 * 64 + 32768;
+    auto kern = gemm_bf16_pring_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+template <int EPI>
+int launch_ppp(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.stagger = g_stagger;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = nwg < g_num_cus ? nwg : g_num_cus;
+    const size_t lds = 2 * (size_t)512 * ROW_BYTES;
+    auto kern = gemm_bf16_ppp_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+template <int EPI>
+int launch_w4(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = 3 * (size_t)384 * 64;
+    auto kern = gemm_bf16_w4_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+template <int EPI>
+int launch_pp(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = 2 * (size_t)512 * ROW_BYTES;
+    auto kern = gemm_bf16_pp_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t s) {
+    if (g_variant == 6 && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
+    if (g_variant == 4 && p.M > 128) return launch_ring<EPI, 5>(p, s);
+    if (g_variant == 5 && p.M > 128) return launch_ring<EPI, 4>(p, s);
+    if (g_variant == 3 && p.M > 128) return launch_ppp<EPI>(p, s);
+    const bool off32 = (size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.N * p.ldw * 2 < (1ull << 32);
+    if (g_variant == 2 && p.M > 128 && off32) return launch_w4<EPI>(p, s);
+    if (g_variant == 1 && p.M > 128) return launch_pp<EPI>(p, s);
     // Large problems: 256x256 tile, 8 waves (2x4), wave tile 128x64.
     // Small M (adaLN tables, tiny test models): 64x256 tile, 4 waves (1x4), wave tile 64x64... keeps N coverage.
     if (p.M > 128) return launch_cfg<8, 2, 4, EPI>(p, s);
@@ -244,6 +1247,14 @@ int launch_epi(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int bsi_gemm_set_variant(int v) {
+    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 6, "bsi_gemm_set_variant: unknown variant %d", v);
+    g_variant = v & 0xff;
+    g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger of variant 3, in units of 64 clocks per step
+    g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 1;  // bits 16..23: band height of variant 6
+    return BSI_OK;
+}
 
 extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
     BSI_CHECK_ARG(a != nullptr, "bsi_gemm_bf16: null args");

@@ -159,6 +159,10 @@ typedef struct bsi_gemm_args {
     const float* pos; /* [tokens, N] (BIAS_POS) */
 } bsi_gemm_args;
 int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
+/* Tuning/testing hook: main-loop schedule of the large-tile GEMM. 0 = two-barrier double buffer,
+ * 1 = ping-pong wave groups, 2 = two workgroups per CU, 3 = persistent ping-pong (default).  Bits 8.. select the
+ * start stagger of variant 3.  Results are bit-identical between variants. */
+int bsi_gemm_set_variant(int variant);
 
 /* dit.py:50-55,66,96: out_bf16[m,:] = LayerNorm(x[m,:]; eps, no affine) * (1 + scale[row]) + shift[row]
  * with row = (m / tokens) % mod_rows; shift/scale point into the adaLN chunk table (stride mod_stride).
@@ -166,6 +170,14 @@ int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
 int bsi_ln_modulate(const float* x, int M, int d, float eps, const float* shift, const float* scale,
                     int mod_rows, int mod_stride, int tokens, const float* ln_w, const float* ln_b,
                     void* out_bf16, bsi_stream_t stream);
+
+/* The same with the block's gated residual update fused in front (dit.py:93-102: torch.addcmul(x, gate, branch)):
+ *   x[m,:] += gate[row] * delta[m,:]   (delta: bf16 [M,d] branch output incl. bias, gate: adaLN chunk, same row
+ *   indexing as shift/scale), written back to x, then LayerNorm+modulate of the updated row into out_bf16.
+ * delta == NULL skips the update; out_bf16 == NULL skips the norm (pure residual update).  delta may alias out_bf16. */
+int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, const float* gate,
+                          const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
+                          const float* ln_w, const float* ln_b, void* out_bf16, bsi_stream_t stream);
 
 /* dit.py:39-46 / attention.py:34-40: softmax(q k^T / sqrt(dh)) v per (batch, head), non-causal.
  * qkv: bf16 [B, tokens, 3, heads, dh] (row stride ld_qkv elements); out: bf16 [B, tokens, heads*dh]

@@ -114,12 +114,13 @@ def dit_block(x, c, W, pre, heads, md=None):
     mod = linear(silu(h), W[pre + "adaLN_modulation.2.weight"], W[pre + "adaLN_modulation.2.bias"], md)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
     a_in = torch.addcmul(sh_a[:, None], sc_a[:, None] + 1, layer_norm(x))
-    x = torch.addcmul(x, g_a[:, None], attention(
+    # with md set, branch outputs are rounded once more: the HIP engine hands them to the residual update as bf16
+    x = torch.addcmul(x, g_a[:, None], _rt(attention(
         a_in, W[pre + "attn.to_qkv.weight"], W[pre + "attn.to_qkv.bias"],
-        W[pre + "attn.to_out.weight"], W[pre + "attn.to_out.bias"], heads, md))
+        W[pre + "attn.to_out.weight"], W[pre + "attn.to_out.bias"], heads, md), md))
     m_in = torch.addcmul(sh_m[:, None], sc_m[:, None] + 1, layer_norm(x))
     hdn = gelu_tanh(linear(m_in, W[pre + "mlp.0.weight"], W[pre + "mlp.0.bias"], md))
-    x = torch.addcmul(x, g_m[:, None], linear(_rt(hdn, md), W[pre + "mlp.2.weight"], W[pre + "mlp.2.bias"], md))
+    x = torch.addcmul(x, g_m[:, None], _rt(linear(_rt(hdn, md), W[pre + "mlp.2.weight"], W[pre + "mlp.2.bias"], md), md))
     return x
 
 

@@ -310,3 +310,28 @@ def test_ln_modulate(N, M, d, tokens, mod_rows):
                                     N.ptr(out), N.stream()))
     ref = do.layer_norm(x, 1e-5, w, b)
     assert float((out.cpu().float() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8
+
+
+@pytest.mark.parametrize("M,d,tokens,mod_rows", [(128, 128, 64, 2), (512, 1024, 256, 2), (256, 1024, 256, 1)])
+def test_resid_ln_modulate(N, M, d, tokens, mod_rows):
+    """Fused gated residual update + LayerNorm + modulate (dit.py:93-102 followed by :96 of the next branch)."""
+    gen = torch.Generator().manual_seed(M * 3 + d)
+    x = torch.randn((M, d), generator=gen) * 2
+    delta = bf16r(torch.randn((M, d), generator=gen))
+    mod = torch.randn((mod_rows, 6 * d), generator=gen) * 0.3
+    rows = (torch.arange(M) // tokens) % mod_rows
+    x_ref = torch.addcmul(x, mod[rows, 2 * d:3 * d], delta)
+    y_ref = torch.addcmul(mod[rows, 3 * d:4 * d], mod[rows, 4 * d:5 * d] + 1, do.layer_norm(x_ref))
+    dx, dmod = dev(x.clone()), dev(mod)
+    buf = dev(delta.to(torch.bfloat16))  # delta aliases the output buffer, as in the engine
+    N.check(N.lib().bsi_resid_ln_modulate(N.ptr(dx), M, d, 1e-5, N.ptr(buf), dmod.data_ptr() + 4 * 2 * d,
+                                          dmod.data_ptr() + 4 * 3 * d, dmod.data_ptr() + 4 * 4 * d, mod_rows, 6 * d,
+                                          tokens, None, None, N.ptr(buf), N.stream()))
+    assert torch.equal(dx.cpu(), x_ref)  # fp32 fma, exact
+    assert float((buf.cpu().float() - y_ref).abs().max()) <= float(y_ref.abs().max()) * 2 ** -8
+    # pure residual update (no norm)
+    dx2 = dev(x.clone())
+    dd = dev(delta.to(torch.bfloat16))
+    N.check(N.lib().bsi_resid_ln_modulate(N.ptr(dx2), M, d, 1e-5, N.ptr(dd), dmod.data_ptr() + 4 * 2 * d, None, None,
+                                          mod_rows, 6 * d, tokens, None, None, None, N.stream()))
+    assert torch.equal(dx2.cpu(), x_ref)

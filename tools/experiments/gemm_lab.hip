@@ -1,0 +1,106 @@
+// Standalone GEMM laboratory (not part of the product): includes the production kernel source and times
+// ablated / alternative schedules with HIP events.  Build + run on the GPU box:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I bsi_amd/csrc tools/experiments/gemm_lab.hip -o /tmp/gemm_lab && /tmp/gemm_lab
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../bsi_amd/csrc/gemm_bf16.hip"
+#include "../../bsi_amd/csrc/bsi_ops.hip"  // bsi_set_error
+
+template <int EPI, int ABL>
+float time_pp(GemmParams p, int iters) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = 2 * 512 * ROW_BYTES;
+    auto kern = gemm_bf16_pp_kernel<EPI, ABL>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, 0, p);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, 0, p);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
+template <int EPI, int ABL>
+float time_pring(GemmParams p, int iters) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = 4 * 512 * 64 + 32768;
+    auto kern = gemm_bf16_pring_kernel<EPI, ABL>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int grid = 256;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
+int main() {
+    const int M = 65536;
+    struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 3072, 1024}, {"fc2", 1024, 4096}};
+    for (auto sh : shapes) {
+        size_t na = (size_t)M * sh.K, nw = (size_t)sh.N * sh.K, no = (size_t)M * sh.N;
+        std::vector<unsigned short> ha(na), hw(nw);
+        srand(1);
+        for (auto& v : ha) v = (unsigned short)((rand() & 0xFFFF) & 0xBFFF) | 0x3000;  // random finite bf16 ~[0.0, 2]
+        for (auto& v : ha) if (rand() & 1) v |= 0x8000;
+        for (auto& v : hw) { v = (unsigned short)(0x3800 | (rand() & 0x3FF)); if (rand() & 1) v |= 0x8000; }
+        void *dA, *dW, *dO; float* dB;
+        hipMalloc(&dA, na * 2); hipMalloc(&dW, nw * 2); hipMalloc(&dO, no * 4); hipMalloc(&dB, sh.N * 4);
+        hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        hipMemset(dB, 0, sh.N * 4);
+        GemmParams p{};
+        p.A = (const __bf16*)dA; p.W = (const __bf16*)dW; p.bias = dB; p.out = dO;
+        p.M = M; p.N = sh.N; p.K = sh.K; p.lda = sh.K; p.ldw = sh.K; p.ldo = sh.N; p.tokens = 256;
+        const double fl = 2.0 * M * sh.N * sh.K;
+        auto rep = [&](const char* what, float ms) { printf("%s %-28s %8.3f ms %8.0f TF\n", sh.name, what, ms, fl / ms / 1e9); };
+        constexpr int E = BSI_EPI_BIAS_BF16;
+        if (getenv("LAB_V6")) {
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            rep("v6 full", time_pring<E, 0>(p, 20));
+            rep("v6 no epilogue", time_pring<E, 4>(p, 20));
+            rep("v6 no glds", time_pring<E, 1>(p, 20));
+            rep("v6 no glds, no epi", time_pring<E, 5>(p, 20));
+            rep("v6 gelu full", time_pring<G, 0>(p, 20));
+            rep("v6 full nt stores", time_pring<E, 32>(p, 20));
+            rep("v6 gelu nt stores", time_pring<G, 32>(p, 20));
+            continue;
+        }
+        if (getenv("LAB_PMC")) {
+            rep("full", time_pp<E, 0>(p, 3));
+            rep("no epilogue", time_pp<E, 4>(p, 3));
+            rep("no glds, no epi", time_pp<E, 5>(p, 3));
+            continue;
+        }
+        rep("full", time_pp<E, 0>(p, 20));
+        rep("full + L2 prefetch", time_pp<E, 16>(p, 20));
+        rep("no epi + L2 prefetch", time_pp<E, 20>(p, 20));
+        for (int st : {8, 16, 32, 64, 128}) {
+            GemmParams q = p; q.stagger = st;
+            char nm[64]; snprintf(nm, sizeof nm, "full stagger %d", st);
+            rep(nm, time_pp<E, 0>(q, 20));
+        }
+        rep("no epilogue", time_pp<E, 4>(p, 20));
+        rep("no glds", time_pp<E, 1>(p, 20));
+        rep("no glds, no epi", time_pp<E, 5>(p, 20));
+        rep("no ds_read, no epi", time_pp<E, 6>(p, 20));
+        rep("no glds/ds_read/epi", time_pp<E, 7>(p, 20));
+        rep("mfma only (no barriers)", time_pp<E, 15>(p, 20));
+        rep("no barriers, no epi", time_pp<E, 12>(p, 20));
+        hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dB);
+    }
+    return 0;
+}

@@ -1,0 +1,301 @@
+// Weight-gradient GEMM for gfx950:  C[N,K] (+)= P[M,N]^T . Q[M,K]   (P = dY, Q = X, both bf16 row-major with
+// the contraction index m as the SLOW dimension), fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+// This is the backward of every nn.Linear on the DiT path (autograd's `mm` of grad_output^T with the saved
+// input; SURVEY §2.4 "backward: 14 mm per block").  The operands cannot be fed to the forward kernel without
+// materialising transposes, so the tiles are staged as [32 m][256 cols] slabs (512-B rows, the natural global
+// layout, full-line DMA) and the MFMA fragments (8 consecutive m for a fixed column) are produced by the
+// hardware transpose read ds_read_b64_tr_b16, two per fragment — the same trick the attention kernel uses for V.
+// 16-B chunks of a row are XOR-swizzled with ((m&3)<<1 | ((m>>3)&1)<<3) on the DMA source and on the read side,
+// which makes the transposed reads conflict free.  Schedule: ping-pong wave groups over a 5-slot LDS ring (see
+// gemm_bf16.hip variant 4).  The contraction (tokens) is long and the output small, so the M range is split
+// over `splits` workgroups per tile; partial tiles go to fp32 slabs that bsi_reduce_slabs sums
+// (deterministic, unlike float atomics, and ~5x cheaper than atomics at these shapes).
+#include "common.h"
+
+namespace {
+
+struct TnParams {
+    const __bf16* P;  // [M, ldp]  (n columns)
+    const __bf16* Q;  // [M, ldq]  (k columns)
+    float* out;       // [splits][N, ldc]
+    int M, N, K;
+    int ldp, ldq, ldc;
+    int tiles_n, tiles_k, splits, m_per_split;
+    size_t slab_stride;  // floats between slabs
+};
+
+constexpr int T_RB = 512;                 // bytes per LDS row (256 bf16 columns)
+constexpr int T_TILE = 32 * T_RB;         // one operand stage: 32 m-rows
+constexpr int T_SLOT = 2 * T_TILE;        // 32 KB
+constexpr int T_R = 5, T_D = T_R - 1;
+
+__device__ __forceinline__ int tn_swz(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
+
+__global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave >> 2;   // ping-pong group; also the n half (128 columns) of the tile
+    const int wk = wave & 3;    // 64-wide k slice
+
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 31) / 32;
+
+    // staging: per stage 64 rows of 512 B (Q tile rows 0..31, then P tile rows 0..31); a wave-instruction covers 2 rows;
+    // wave w issues instruction slots q*8 + w, q < 4  (slots 0..15 -> Q tile, 16..31 -> P tile)
+    const int srow = lane >> 5, spos = lane & 31;
+    const char* gsrc[4];
+    int grow[4];  // m row (within the stage) of each slot, for the tail clamp
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = q * 8 + wave;
+        const int r = (slot & 15) * 2 + srow;  // m row within the 32-row stage
+        const int c = spos ^ tn_swz(r);
+        grow[q] = r;
+        if (slot < 16) {
+            int col = k0 + c * 8;
+            col = col < p.K ? col : 0;  // columns beyond K are never stored
+            gsrc[q] = reinterpret_cast<const char*>(p.Q + col);
+        } else {
+            int col = n0 + c * 8;
+            col = col < p.N ? col : 0;
+            gsrc[q] = reinterpret_cast<const char*>(p.P + col);
+        }
+    }
+    auto stage = [&](int v, int slot_i) {
+        char* base = lds + slot_i * T_SLOT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = q * 8 + wave;
+            int m = mbeg + v * 32 + grow[q];
+            m = m < mend ? m : mend - 1;  // tail rows are masked to zero contribution below (nk rounds up)
+            const size_t ld = slot < 16 ? (size_t)p.ldq : (size_t)p.ldp;
+            char* dst = base + slot * 1024;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)m * ld * 2), LDS_PTR(dst), 16, 0, 0);
+        }
+    };
+
+    // fragment addressing: lane = (q, q', pp): q = lane>>4 selects m block 8q..8q+7, q' = (lane&15)>>2 the row inside a
+    // 4-row transpose block, pp = lane&3 the 4-column quad.
+    const int q = lane >> 4, qp = (lane & 15) >> 2, pp = lane & 3;
+    const int mA = 8 * q + qp, mB = mA + 4;
+    const int swA = tn_swz(mA), swB = tn_swz(mB);
+    const int rowA = mA * T_RB, rowB = mB * T_RB;
+    const int half8 = 8 * (pp & 1), chp = pp >> 1;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4], bf[8];
+
+#define TN_BARRIER()                             \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#define TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
+
+    auto load_frags = [&](const char* b) {
+        union U { bf16x8 v; s16x4 h[2]; };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // Q tile, columns 64*wk + 16i + 4pp
+            const int ch = (64 * wk + 16 * i) / 8 + chp;
+            U u;
+            u.h[0] = TR(b + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + rowB + ((ch ^ swB) << 4) + half8);
+            af[i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // P tile, columns 128*wg + 16j + 4pp
+            const int ch = (128 * wg + 16 * j) / 8 + chp;
+            U u;
+            u.h[0] = TR(b + T_TILE + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + T_TILE + rowB + ((ch ^ swB) << 4) + half8);
+            bf[j] = u.v;
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < T_D; ++d)
+        if (d < nk) stage(d, d);
+    if (nk >= T_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T_D - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TN_BARRIER();
+    if (wg == 1) TN_BARRIER();
+
+    int slot = 0, pslot = T_D;
+    for (int v = 0; v < nk; ++v) {
+        load_frags(lds + slot * T_SLOT);
+        if (v + T_D < nk) {
+            stage(v + T_D, pslot);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T_D - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (mbeg + v * 32 + 32 > mend) {
+            // ragged tail: rows >= mend were clamped to a valid address; zero their contribution (element e of a fragment
+            // is contraction row 8q + e)
+            const int valid = mend - (mbeg + v * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (8 * q + e >= valid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i][e] = (__bf16)0.0f;
+                }
+            }
+        }
+        TN_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        TN_BARRIER();
+        slot = (slot == T_R - 1) ? 0 : slot + 1;
+        pslot = (pslot == T_R - 1) ? 0 : pslot + 1;
+    }
+    if (wg == 0) TN_BARRIER();
+#undef TN_BARRIER
+#undef TR
+
+    // D rows = k (4*(lane>>4) + reg inside A tile i), D cols = n (lane & 15 inside B tile j)
+    float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 128 * wg + 16 * j + (lane & 15);
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 64 * wk + 16 * i + 4 * q;
+            if (k < p.K) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(out + (size_t)n * p.ldc + k));
+        }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits, size_t n4,
+                                    int accumulate, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 a = accumulate ? reinterpret_cast<const f32x4*>(out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slabs + (size_t)s * slab_stride) + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = a;
+    }
+}
+
+// column sums of a bf16 [M, ld] matrix (bias gradients): out[n] (+)= sum_m Y[m, n].
+// grid.x covers columns in chunks of 256 (4 per thread... one thread = 1 column pair), grid.y splits rows; fp32 atomics
+// are avoided: each (row-split, column) partial is written to a slab and reduced by reduce_slabs_kernel.
+__global__ void colsum_kernel(const __bf16* __restrict__ Y, int M, int Ncols, int ld, int rows_per_split,
+                              float* __restrict__ slabs, size_t slab_stride) {
+    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;  // pair of columns
+    if (c2 * 2 >= Ncols) return;
+    const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    float a0 = 0.f, a1 = 0.f;
+    const unsigned* base = reinterpret_cast<const unsigned*>(Y) + c2;
+    for (int m = m0; m < m1; ++m) {
+        const unsigned w = base[(size_t)m * (ld / 2)];
+        a0 += __uint_as_float(w << 16);
+        a1 += __uint_as_float(w & 0xffff0000u);
+    }
+    float* o = slabs + (size_t)blockIdx.y * slab_stride + c2 * 2;
+    o[0] = a0;
+    o[1] = a1;
+}
+
+}  // namespace
+
+extern "C" size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K) {
+    // worst case number of splits is 16
+    return (size_t)16 * (size_t)N * (size_t)K * sizeof(float);
+}
+
+static int tn_splits(int M, int N, int K, int num_cus) {
+    const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    int s = (num_cus + tiles - 1) / tiles;
+    if (s > 16) s = 16;
+    const int max_by_m = M / 512 > 0 ? M / 512 : 1;  // keep at least 16 K steps per workgroup
+    if (s > max_by_m) s = max_by_m;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
+                                int accumulate, void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(P && Q && out && M > 0 && N > 0 && K > 0, "bsi_gemm_tn_bf16: bad args");
+    BSI_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldp % 8 == 0 && ldq % 8 == 0 && ldp >= N && ldq >= K,
+                  "bsi_gemm_tn_bf16: N=%d K=%d ldp=%d ldq=%d must be multiples of 8", N, K, ldp, ldq);
+    BSI_CHECK_ARG(ldc == K, "bsi_gemm_tn_bf16: output must be dense (ldc == K)");
+    BSI_CHECK_ARG(K % 4 == 0, "bsi_gemm_tn_bf16: K %% 4");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    TnParams p{};
+    p.P = reinterpret_cast<const __bf16*>(P);
+    p.Q = reinterpret_cast<const __bf16*>(Q);
+    p.M = M; p.N = N; p.K = K; p.ldp = ldp; p.ldq = ldq; p.ldc = ldc;
+    p.tiles_n = (N + 255) / 256;
+    p.tiles_k = (K + 255) / 256;
+    p.splits = tn_splits(M, N, K, cus);
+    const int per = (M + p.splits - 1) / p.splits;
+    p.m_per_split = (per + 31) / 32 * 32;
+    p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+    const bool direct = p.splits == 1 && !accumulate;
+    BSI_CHECK_ARG(direct || workspace, "bsi_gemm_tn_bf16: workspace required");
+    p.out = direct ? out : reinterpret_cast<float*>(workspace);
+    p.slab_stride = (size_t)N * ldc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  T_R * T_SLOT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");
+    if (!direct) {
+        const size_t n4 = (size_t)N * ldc / 4;
+        size_t g = (n4 + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace),
+                           p.slab_stride, p.splits, n4, accumulate, out);
+        BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16(reduce)");
+    }
+    return BSI_OK;
+}
+
+extern "C" size_t bsi_colsum_workspace_bytes(int N) { return (size_t)64 * (size_t)((N + 3) / 4 * 4) * sizeof(float); }
+
+extern "C" int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,
+                               bsi_stream_t stream) {
+    BSI_CHECK_ARG(Y && out && workspace && M > 0 && N > 0 && N % 4 == 0 && ld % 2 == 0 && ld >= N, "bsi_colsum_bf16: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int splits = M / 256;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    const int per = (M + splits - 1) / splits;
+    splits = (M + per - 1) / per;
+    dim3 grid((N / 2 + 255) / 256, splits);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(Y), M, N, ld, per,
+                       reinterpret_cast<float*>(workspace), (size_t)N);
+    BSI_CHECK_LAUNCH("bsi_colsum_bf16");
+    size_t g = ((size_t)N / 4 + 255) / 256;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace),
+                       (size_t)N, splits, (size_t)N / 4, accumulate, out);
+    BSI_CHECK_LAUNCH("bsi_colsum_bf16(reduce)");
+    return BSI_OK;
+}

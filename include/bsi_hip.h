@@ -159,6 +159,18 @@ typedef struct bsi_gemm_args {
     const float* pos; /* [tokens, N] (BIAS_POS) */
 } bsi_gemm_args;
 int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
+/* Weight-gradient GEMM (backward of nn.Linear w.r.t. its weight, autograd `grad_output.T @ input`):
+ *   out[N,K] (+)= P[M,N]^T . Q[M,K],  P = dY and Q = X are bf16 row-major (token index m slow), fp32 result.
+ * The token range is split over workgroups; partial tiles are summed deterministically from `workspace`
+ * (bsi_gemm_tn_workspace_bytes).  accumulate != 0 adds to `out` (gradient accumulation). */
+size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K);
+int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
+                     int accumulate, void* workspace, bsi_stream_t stream);
+/* Bias gradient: out[n] (+)= sum_m Y[m,n] for bf16 Y [M, ld]. */
+size_t bsi_colsum_workspace_bytes(int N);
+int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,
+                    bsi_stream_t stream);
+
 /* Tuning/testing hook: main-loop schedule of the large-tile GEMM. 0 = two-barrier double buffer,
  * 1 = ping-pong wave groups, 2 = two workgroups per CU, 3 = persistent ping-pong (default).  Bits 8.. select the
  * start stagger of variant 3.  Results are bit-identical between variants. */

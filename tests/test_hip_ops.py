@@ -335,3 +335,25 @@ def test_resid_ln_modulate(N, M, d, tokens, mod_rows):
     N.check(N.lib().bsi_resid_ln_modulate(N.ptr(dx2), M, d, 1e-5, N.ptr(dd), dmod.data_ptr() + 4 * 2 * d, None, None,
                                           mod_rows, 6 * d, tokens, None, None, None, N.stream()))
     assert torch.equal(dx2.cpu(), x_ref)
+
+
+@pytest.mark.parametrize("M,Nn,K", [(512, 256, 256), (4096, 1024, 1024), (16384, 3072, 1024), (8192, 1024, 4096),
+                                     (1000 * 32, 128, 384), (544, 512, 128)])
+def test_gemm_tn_and_colsum(N, M, Nn, K):
+    """dW = dY^T X and db = colsum(dY) (backward of nn.Linear) vs fp64 on the same bf16 operands."""
+    gen = torch.Generator().manual_seed(M + Nn + K)
+    dY = bf16r(torch.randn((M, Nn), generator=gen))
+    X = bf16r(torch.randn((M, K), generator=gen))
+    ref = dY.double().t() @ X.double()
+    out = empty(Nn, K)
+    ws = torch.empty(N.lib().bsi_gemm_tn_workspace_bytes(M, Nn, K), dtype=torch.uint8, device=DEV)
+    dP, dQ = dev(dY.to(torch.bfloat16)), dev(X.to(torch.bfloat16))
+    N.check(N.lib().bsi_gemm_tn_bf16(N.ptr(dP), Nn, N.ptr(dQ), K, M, Nn, K, N.ptr(out), K, 0, N.ptr(ws), N.stream()))
+    # exact bf16 products, fp32 accumulation over M terms: error ~ sqrt(M) * 2^-24 of the row scale
+    assert rel_linf(out, ref) < 3e-5, rel_linf(out, ref)
+    N.check(N.lib().bsi_gemm_tn_bf16(N.ptr(dP), Nn, N.ptr(dQ), K, M, Nn, K, N.ptr(out), K, 1, N.ptr(ws), N.stream()))
+    assert rel_linf(out, 2 * ref) < 3e-5  # accumulate
+    cs = empty(Nn)
+    ws2 = torch.empty(N.lib().bsi_colsum_workspace_bytes(Nn), dtype=torch.uint8, device=DEV)
+    N.check(N.lib().bsi_colsum_bf16(N.ptr(dP), Nn, M, Nn, N.ptr(cs), 0, N.ptr(ws2), N.stream()))
+    assert rel_linf(cs, dY.double().sum(0)) < 1e-5

@@ -78,6 +78,12 @@ _PROTOS = {
     "bsi_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_resid_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "bsi_attention_fwd_lse": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "bsi_attention_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "bsi_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_ln_mod_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "bsi_silu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "bsi_cast_transpose_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),

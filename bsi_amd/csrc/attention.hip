@@ -26,7 +26,7 @@ __device__ __forceinline__ int v_block_swz(int row, int blk) {  // 32-B block in
 template <int DH, int KC>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
                                                             int heads, __bf16* __restrict__ out, int ld_out,
-                                                            float scale_log2e) {
+                                                            float scale_log2e, float* __restrict__ lse) {
     constexpr int RB = DH * 2;        // bytes per K/V row
     constexpr int KS = DH / 32;       // k-steps of the QK^T contraction
     constexpr int KT = KC / 16;       // 16-key tiles per chunk
@@ -168,6 +168,8 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
+        // log-sum-exp of the scaled scores (natural log), saved for the backward pass
+        if (lse && g == 0) lse[(size_t)bh * tokens + q0 + 16 * jq + c16] = (m_run[jq] * scale_log2e + __log2f(l)) * 0.6931471805599453f;
         __bf16* orow = out + ((size_t)b * tokens + q0 + 16 * jq + c16) * ld_out + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -180,7 +182,8 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
 }
 
 template <int DH, int KC>
-int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, hipStream_t s) {
+int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, float* lse,
+                hipStream_t s) {
     const size_t lds = 2 * (size_t)KC * DH * 2;
     auto kern = attention_fwd_kernel<DH, KC>;
     static bool attr_set = false;
@@ -190,15 +193,15 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((tokens + 255) / 256, B * heads);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse);
     BSI_CHECK_LAUNCH("bsi_attention_fwd");
     return BSI_OK;
 }
 
 }  // namespace
 
-extern "C" int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
-                                 int ld_out, bsi_stream_t stream) {
+static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
+                              float* lse, bsi_stream_t stream) {
     BSI_CHECK_ARG(qkv && out && B > 0 && heads > 0, "bsi_attention_fwd: bad args");
     BSI_CHECK_ARG(dh == 64 || dh == 128, "bsi_attention_fwd: head dim %d unsupported (64 or 128)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0, "bsi_attention_fwd: tokens=%d must be a multiple of 64", tokens);
@@ -208,9 +211,20 @@ extern "C" int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens,
     __bf16* o = reinterpret_cast<__bf16*>(out);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dh == 64) {
-        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
-        return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
+        return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
     }
-    if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
-    return launch_attn<128, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, s);
+    if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
+    return launch_attn<128, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
+}
+
+extern "C" int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
+                                 int ld_out, bsi_stream_t stream) {
+    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, nullptr, stream);
+}
+
+extern "C" int bsi_attention_fwd_lse(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
+                                     int ld_out, float* lse, bsi_stream_t stream) {
+    BSI_CHECK_ARG(lse, "bsi_attention_fwd_lse: null lse");
+    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, stream);
 }

@@ -1,0 +1,432 @@
+// Memory-bound backward kernels of the DiT block (autograd of bsi/models/dit.py:50-55,87-103 of the reference):
+// gated-residual backward, LayerNorm+modulate backward, final LayerNorm+decoder backward, small helpers.
+// Layout/roles as in dit_ops.hip: one wave per token row, lanes own float4 column groups; the per-sample
+// reductions (gradients of the adaLN chunks) are accumulated over a 32-row slab in registers/LDS and then added
+// with one fp32 atomic per element and slab (8 adds per element for 256 tokens).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;   // 4 waves
+constexpr int RPB = 32;    // rows per block (8 per wave); tokens per sample must be a multiple of it
+
+__device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 w) {
+    return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
+                 __uint_as_float(w[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) {
+    u32x2 w;
+    w[0] = pack_bf16x2(v[0], v[1]);
+    w[1] = pack_bf16x2(v[2], v[3]);
+    return w;
+}
+
+// x2 = x1 + gate*delta (dit.py:93-102).  Given dX = dL/dx2:
+//   d_delta = gate * dX (bf16 out),  d_gate[b] += sum_tokens dX * delta,  x <- x - gate*delta (recovers x1),
+//   dL/dx1 = dX (unchanged).
+template <int VPL>
+__global__ void gate_bwd_kernel(const float* __restrict__ dX, const __bf16* __restrict__ delta, float* __restrict__ x,
+                                const float* __restrict__ gate, int gate_stride, float* __restrict__ dgate,
+                                int dgate_stride, int M, int d, int tokens, __bf16* __restrict__ ddelta) {
+    __shared__ float red[3][1024 * 2];  // [wave 1..3][up to 2048 columns]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * RPB;
+    const int b = row0 / tokens;
+    const int d4 = d >> 2;
+    f32x4 g[VPL], acc[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        g[i] = (c < d4) ? reinterpret_cast<const f32x4*>(gate + (size_t)b * gate_stride)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r = 0; r < RPB / 4; ++r) {
+        const int row = row0 + wave * (RPB / 4) + r;
+        if (row >= M) break;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                const f32x4 dx = reinterpret_cast<const f32x4*>(dX + (size_t)row * d)[c];
+                const f32x4 dl = bf16x4_to_f32(reinterpret_cast<const u32x2*>(delta + (size_t)row * d)[c]);
+                f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
+                f32x4 dd;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dd[k] = g[i][k] * dx[k];
+                    acc[i][k] = __fmaf_rn(dx[k], dl[k], acc[i][k]);
+                    xv[k] = __fmaf_rn(-g[i][k], dl[k], xv[k]);
+                }
+                reinterpret_cast<u32x2*>(ddelta + (size_t)row * d)[c] = f32x4_to_bf16(dd);
+                reinterpret_cast<f32x4*>(x + (size_t)row * d)[c] = xv;
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) reinterpret_cast<f32x4*>(red[wave - 1])[c] = acc[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 t = acc[i];
+                for (int w = 0; w < 3; ++w) {
+                    const f32x4 o = reinterpret_cast<const f32x4*>(red[w])[c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] += o[k];
+                }
+                float* dst = dgate + (size_t)b * dgate_stride + c * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(dst + k, t[k]);
+            }
+        }
+    }
+}
+
+// xn = LN(x) * (1 + scale) + shift (dit.py:50-55).  Given dxn (bf16) and the residual-path gradient dX (fp32, in/out):
+//   n = (x - mean) * rstd;  d_shift[b] += sum_t dxn;  d_scale[b] += sum_t dxn * n;  dn = dxn * (1 + scale)
+//   dX += rstd * (dn - mean(dn) - n * mean(dn * n))
+template <int VPL>
+__global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* __restrict__ x,
+                                  const float* __restrict__ scale, int mod_stride, float* __restrict__ dshift,
+                                  float* __restrict__ dscale, int dmod_stride, float* __restrict__ dX, int M, int d,
+                                  int tokens, float eps) {
+    __shared__ float red[3][2][1024 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * RPB;
+    const int b = row0 / tokens;
+    const int d4 = d >> 2;
+    f32x4 sc1[VPL], ash[VPL], asc[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        const f32x4 s = (c < d4) ? reinterpret_cast<const f32x4*>(scale + (size_t)b * mod_stride)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc1[i][k] = s[k] + 1.0f;
+        ash[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r = 0; r < RPB / 4; ++r) {
+        const int row = row0 + wave * (RPB / 4) + r;
+        if (row >= M) break;
+        f32x4 v[VPL], dv[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[i] = (c < d4) ? bf16x4_to_f32(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d)[c])
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = v[i][k] - mean;
+                    q = __fmaf_rn(dd, dd, q);
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float n = (v[i][k] - mean) * rstd;
+                    const float g = dv[i][k];
+                    ash[i][k] += g;
+                    asc[i][k] = __fmaf_rn(g, n, asc[i][k]);
+                    const float dn = g * sc1[i][k];
+                    v[i][k] = n;
+                    dv[i][k] = dn;
+                    s1 += dn;
+                    s2 = __fmaf_rn(dn, n, s2);
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 o = reinterpret_cast<const f32x4*>(dX + (size_t)row * d)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += rstd * (dv[i][k] - m1 - v[i][k] * m2);
+                reinterpret_cast<f32x4*>(dX + (size_t)row * d)[c] = o;
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                reinterpret_cast<f32x4*>(red[wave - 1][0])[c] = ash[i];
+                reinterpret_cast<f32x4*>(red[wave - 1][1])[c] = asc[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 t0 = ash[i], t1 = asc[i];
+                for (int w = 0; w < 3; ++w) {
+                    const f32x4 o0 = reinterpret_cast<const f32x4*>(red[w][0])[c];
+                    const f32x4 o1 = reinterpret_cast<const f32x4*>(red[w][1])[c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { t0[k] += o0[k]; t1[k] += o1[k]; }
+                }
+                float* d0 = dshift + (size_t)b * dmod_stride + c * 4;
+                float* d1 = dscale + (size_t)b * dmod_stride + c * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { atomicAdd(d0 + k, t0[k]); atomicAdd(d1 + k, t1[k]); }
+            }
+        }
+    }
+}
+
+// Backward of dit.py:163-172,181 + bsi.py:382-386: given g_xhat [B,C,H,W] (gradient of x_hat = c_skip*mu + c_out*f):
+//   dY[token, o] = c_out[b] * g_xhat[b, ch, hh, ww]  (patchify order), y = LN_affine(x) (fp32)
+//   dWdec[o,:] += dY[o] * y,  dbdec[o] += dY[o],  dy = sum_o dY[o] * Wdec[o,:]
+//   dlnw += dy * n, dlnb += dy,  dX = LN_bwd(dy * lnw)     (dX is WRITTEN, it starts the residual gradient)
+// Parameter gradients are accumulated per workgroup in LDS ([P+2][d] fp32) and flushed with atomics.
+template <int VPL>
+__global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int d, int P, const float* __restrict__ ln_w,
+                                     const float* __restrict__ ln_b, const float* __restrict__ dec_w, int C, int H, int W,
+                                     int ps, const float* __restrict__ g_xhat, const float* __restrict__ c_out,
+                                     int coef_stride, float* __restrict__ dX, float* __restrict__ d_dec_w,
+                                     float* __restrict__ d_dec_b, float* __restrict__ d_ln_w, float* __restrict__ d_ln_b) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [P][d] weights, then [P+2][d] gradient accumulators
+    float* wsm = sm;
+    float* gsm = sm + (size_t)P * d;
+    const int d4 = d >> 2;
+    for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
+        reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
+    for (int i = threadIdx.x; i < (P + 2) * d4; i += blockDim.x)
+        reinterpret_cast<f32x4*>(gsm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int nw = W / ps, tokens = (H / ps) * nw, HW = H * W;
+    float db_acc = 0.f;  // lane o accumulates d_dec_b[o]
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Mtok; row += gridDim.x * wpb) {
+        const int b_idx = row / tokens, tok = row % tokens;
+        const int th = tok / nw, tw = tok % nw;
+        float dy_o = 0.f;  // lane o holds dY[o]
+        if (lane < P) {
+            const int intra = lane / C, ch = lane % C;
+            const int hh = th * ps + intra / ps, ww = tw * ps + intra % ps;
+            dy_o = g_xhat[((size_t)b_idx * C + ch) * HW + (size_t)hh * W + ww];
+            if (c_out) dy_o *= c_out[(size_t)b_idx * coef_stride];
+            db_acc += dy_o;
+        }
+        f32x4 v[VPL], lw[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            lw[i] = (c < d4) ? reinterpret_cast<const f32x4*>(ln_w)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = v[i][k] - mean;
+                    q = __fmaf_rn(dd, dd, q);
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+        f32x4 dy[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            dy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = (v[i][k] - mean) * rstd;  // n
+        }
+        for (int o = 0; o < P; ++o) {
+            const float g = __shfl(dy_o, o, 64);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+                    const f32x4 wv = reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c];
+                    const f32x4 lb = reinterpret_cast<const f32x4*>(ln_b)[c];
+                    float* ga = gsm + (size_t)o * d + c * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dy[i][k] = __fmaf_rn(g, wv[k], dy[i][k]);
+                        atomicAdd(ga + k, g * __fmaf_rn(v[i][k], lw[i][k], lb[k]));  // LDS atomic: dWdec[o] += dY[o]*y
+                    }
+                }
+            }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                float* g_lw = gsm + (size_t)P * d + c * 4;
+                float* g_lb = gsm + (size_t)(P + 1) * d + c * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    atomicAdd(g_lw + k, dy[i][k] * v[i][k]);
+                    atomicAdd(g_lb + k, dy[i][k]);
+                    const float dn = dy[i][k] * lw[i][k];
+                    dy[i][k] = dn;
+                    s1 += dn;
+                    s2 = __fmaf_rn(dn, v[i][k], s2);
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = rstd * (dy[i][k] - m1 - v[i][k] * m2);
+                reinterpret_cast<f32x4*>(dX + (size_t)row * d)[c] = o;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P * d; i += blockDim.x) atomicAdd(d_dec_w + i, gsm[i]);
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        atomicAdd(d_ln_w + i, gsm[(size_t)P * d + i]);
+        atomicAdd(d_ln_b + i, gsm[(size_t)(P + 1) * d + i]);
+    }
+    if (lane < P) atomicAdd(d_dec_b + lane, db_acc);
+}
+
+// out_bf16 = in_f32 elementwise (optionally * silu'(pre) with pre fp32): used for the adaLN MLP backward
+__global__ void silu_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pre, size_t n, __bf16* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float g = ds[i];
+        if (pre) {
+            const float p = pre[i];
+            const float sg = 1.0f / (1.0f + __expf(-p));
+            g *= sg * (1.0f + p * (1.0f - sg));
+        }
+        out[i] = (__bf16)g;
+    }
+}
+
+// fp32 [rows, cols] -> bf16 [cols, ld_out] transposed (weight shadows W^T for the input-gradient GEMMs)
+__global__ void cast_transpose_kernel(const float* __restrict__ in, int rows, int cols, __bf16* __restrict__ out, int ld) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        tile[ty + k][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;  // out[c][r]
+        if (c < cols && r < ld) out[(size_t)c * ld + r] = (__bf16)tile[tx][ty + k];
+    }
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int bsi_gate_bwd(const float* dX, const void* delta, float* x, const float* gate, int gate_stride, float* dgate,
+                            int dgate_stride, int M, int d, int tokens, void* ddelta, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dX && delta && x && gate && dgate && ddelta, "bsi_gate_bwd: null pointer");
+    BSI_CHECK_ARG(M > 0 && d % 4 == 0 && d <= 2048 && tokens % RPB == 0 && M % tokens == 0,
+                  "bsi_gate_bwd: M=%d d=%d tokens=%d (tokens must be a multiple of %d)", M, d, tokens, RPB);
+    dim3 grid(M / RPB);
+    const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
+    __bf16* dd = reinterpret_cast<__bf16*>(ddelta);
+    if (d <= 256) hipLaunchKernelGGL(gate_bwd_kernel<1>, grid, dim3(TPB), 0, S(stream), dX, dl, x, gate, gate_stride, dgate, dgate_stride, M, d, tokens, dd);
+    else if (d <= 1024) hipLaunchKernelGGL(gate_bwd_kernel<4>, grid, dim3(TPB), 0, S(stream), dX, dl, x, gate, gate_stride, dgate, dgate_stride, M, d, tokens, dd);
+    else hipLaunchKernelGGL(gate_bwd_kernel<8>, grid, dim3(TPB), 0, S(stream), dX, dl, x, gate, gate_stride, dgate, dgate_stride, M, d, tokens, dd);
+    BSI_CHECK_LAUNCH("bsi_gate_bwd");
+    return BSI_OK;
+}
+
+extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
+                              float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps,
+                              bsi_stream_t stream) {
+    BSI_CHECK_ARG(dxn && x && scale && dshift && dscale && dX, "bsi_ln_mod_bwd: null pointer");
+    BSI_CHECK_ARG(M > 0 && d % 4 == 0 && d <= 2048 && tokens % RPB == 0 && M % tokens == 0,
+                  "bsi_ln_mod_bwd: M=%d d=%d tokens=%d", M, d, tokens);
+    dim3 grid(M / RPB);
+    const __bf16* g = reinterpret_cast<const __bf16*>(dxn);
+    if (d <= 256) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
+    else if (d <= 1024) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
+    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
+    BSI_CHECK_LAUNCH("bsi_ln_mod_bwd");
+    return BSI_OK;
+}
+
+int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
+                             const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
+                             int coef_stride, float* dX, float* d_dec_w, float* d_dec_b, float* d_ln_w, float* d_ln_b,
+                             hipStream_t s) {
+    const size_t lds = ((size_t)P * d + (size_t)(P + 2) * d) * sizeof(float);
+    if (lds > 160 * 1024 || P > 64) {
+        bsi_set_error("bsi_dit_final_bwd: P=%d d=%d needs %zu B of LDS", P, d, lds);
+        return BSI_EINVAL;
+    }
+    int grid = (Mtok + 4 * 16 - 1) / (4 * 16);
+    if (grid < 1) grid = 1;
+    if (grid > 512) grid = 512;
+#define LAUNCH_FB(V)                                                                                                   \
+    do {                                                                                                               \
+        auto kern = dit_final_bwd_kernel<V>;                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, ln_w, ln_b, dec_w, C, H, W, ps, g_xhat,   \
+                           c_out, coef_stride, dX, d_dec_w, d_dec_b, d_ln_w, d_ln_b);                                   \
+    } while (0)
+    if (d <= 256) LAUNCH_FB(1);
+    else if (d <= 1024) LAUNCH_FB(4);
+    else LAUNCH_FB(8);
+#undef LAUNCH_FB
+    BSI_CHECK_LAUNCH("bsi_dit_final_bwd");
+    return BSI_OK;
+}
+
+extern "C" int bsi_silu_bwd_bf16(const float* ds, const float* pre, size_t n, void* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(ds && out && n > 0, "bsi_silu_bwd_bf16: bad args");
+    size_t g = (n + TPB - 1) / TPB;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((int)g), dim3(TPB), 0, S(stream), ds, pre, n, reinterpret_cast<__bf16*>(out));
+    BSI_CHECK_LAUNCH("bsi_silu_bwd_bf16");
+    return BSI_OK;
+}
+
+extern "C" int bsi_cast_transpose_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_out >= rows, "bsi_cast_transpose_bf16: bad args");
+    dim3 grid((cols + 31) / 32, (ld_out + 31) / 32);
+    hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(TPB), 0, S(stream), in, rows, cols, reinterpret_cast<__bf16*>(out), ld_out);
+    BSI_CHECK_LAUNCH("bsi_cast_transpose_bf16");
+    return BSI_OK;
+}

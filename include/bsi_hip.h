@@ -197,6 +197,27 @@ int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, 
 int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
                       bsi_stream_t stream);
 
+/* As bsi_attention_fwd, additionally saving lse[b,h,q] = log sum_k exp(q.k/sqrt(dh)) (fp32 [B,heads,tokens]). */
+int bsi_attention_fwd_lse(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
+                          float* lse, bsi_stream_t stream);
+/* Backward of the attention (autograd of dit.py:43-44): dqkv (bf16, layout of qkv) from qkv, the forward output
+ * `out`, its gradient `dout` (both bf16 [B,tokens,heads*dh], row stride ld_o) and lse.  dh = 64, tokens <= 256. */
+int bsi_attention_bwd(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
+                      int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, bsi_stream_t stream);
+
+/* Backward building blocks of the DiT block (autograd of dit.py:50-55,87-103):
+ * bsi_gate_bwd: for x2 = x1 + gate*delta and dX = dL/dx2: ddelta = bf16(gate*dX), dgate[b] += sum_tokens dX*delta,
+ *   and x is rewound in place to x1 = x2 - gate*delta (the forward keeps only the final residual stream).
+ * bsi_ln_mod_bwd: for xn = LN(x)*(1+scale)+shift and dxn: dshift[b] += sum dxn, dscale[b] += sum dxn*LN(x),
+ *   dX += LayerNorm-backward(dxn*(1+scale)).  Per-sample rows: gate/scale/dgate/... indexed [b*stride]. */
+int bsi_gate_bwd(const float* dX, const void* delta, float* x, const float* gate, int gate_stride, float* dgate,
+                 int dgate_stride, int M, int d, int tokens, void* ddelta, bsi_stream_t stream);
+int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift, float* dscale,
+                   int dmod_stride, float* dX, int M, int d, int tokens, float eps, bsi_stream_t stream);
+/* out_bf16[i] = ds[i] * silu'(pre[i]) (pre == NULL: plain cast); fp32 [rows,cols] -> bf16 [cols, ld] transposed. */
+int bsi_silu_bwd_bf16(const float* ds, const float* pre, size_t n, void* out, bsi_stream_t stream);
+int bsi_cast_transpose_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DenoisingDiT engine — bsi/models/dit.py:106-233
  * ---------------------------------------------------------------------------------------- */

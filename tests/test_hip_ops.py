@@ -357,3 +357,87 @@ def test_gemm_tn_and_colsum(N, M, Nn, K):
     ws2 = torch.empty(N.lib().bsi_colsum_workspace_bytes(Nn), dtype=torch.uint8, device=DEV)
     N.check(N.lib().bsi_colsum_bf16(N.ptr(dP), Nn, M, Nn, N.ptr(cs), 0, N.ptr(ws2), N.stream()))
     assert rel_linf(cs, dY.double().sum(0)) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# backward kernels (checked against torch autograd of the oracle expressions in fp64)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,tokens,heads", [(2, 64, 2), (2, 256, 3), (1, 128, 1)])
+def test_attention_backward(N, B, tokens, heads):
+    dh, d = 64, heads * 64
+    gen = torch.Generator().manual_seed(B * 5 + tokens + heads)
+    qkv = bf16r(torch.randn((B, tokens, 3, heads, dh), generator=gen) * 1.2)
+    dout = bf16r(torch.randn((B, tokens, d), generator=gen))
+    dq_ = dev(qkv.to(torch.bfloat16))
+    out = empty(B, tokens, d, dtype=torch.bfloat16)
+    lse = empty(B, heads, tokens)
+    N.check(N.lib().bsi_attention_fwd_lse(N.ptr(dq_), 3 * d, B, tokens, heads, dh, N.ptr(out), d, N.ptr(lse), N.stream()))
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    ref_o = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, tokens, d)
+    assert rel_linf(lse, torch.logsumexp(sc, -1).detach()) < 1e-5
+    ref_o.backward(dout.double())
+    dqkv = empty(B, tokens, 3 * d, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_attention_bwd(N.ptr(dq_), 3 * d, N.ptr(out), N.ptr(dev(dout.to(torch.bfloat16))), d, N.ptr(lse),
+                                      B, tokens, heads, dh, N.ptr(dqkv), 3 * d, N.stream()))
+    got = dqkv.cpu().float().reshape(B, tokens, 3, heads, dh)
+    # P and dS are rounded to bf16 before the second products, O and the outputs are bf16: 1e-2 relative to the max
+    for i, nm in enumerate("qkv"):
+        assert rel_linf(got[:, :, i], x.grad[:, :, i]) < 1.5e-2, (nm, rel_linf(got[:, :, i], x.grad[:, :, i]))
+        assert float((got[:, :, i].double() - x.grad[:, :, i]).abs().mean() / x.grad[:, :, i].abs().mean()) < 6e-3
+
+
+@pytest.mark.parametrize("Bs,tokens,d", [(3, 64, 128), (2, 256, 1024)])
+def test_gate_and_ln_backward(N, Bs, tokens, d):
+    gen = torch.Generator().manual_seed(Bs + tokens + d)
+    M = Bs * tokens
+    x1 = torch.randn((M, d), generator=gen) * 2
+    delta = bf16r(torch.randn((M, d), generator=gen))
+    mod = torch.randn((Bs, 6 * d), generator=gen) * 0.3
+    dX = torch.randn((M, d), generator=gen)
+    rows = torch.arange(M) // tokens
+    gate = mod[:, 2 * d:3 * d]
+    x2 = torch.addcmul(x1, gate[rows], delta)
+    # --- gate backward
+    dx2, dmod = dev(x2.clone()), dev(torch.zeros_like(mod))
+    dd = empty(M, d, dtype=torch.bfloat16)
+    dmod_in = dev(mod)
+    N.check(N.lib().bsi_gate_bwd(N.ptr(dev(dX)), N.ptr(dev(delta.to(torch.bfloat16))), N.ptr(dx2), dmod_in.data_ptr() + 8 * d,
+                                 6 * d, dmod.data_ptr() + 8 * d, 6 * d, M, d, tokens, N.ptr(dd), N.stream()))
+    assert rel_linf(dx2, x1) < 1e-6                     # residual stream rewound to x1
+    assert rel_linf(dd.cpu().float(), gate[rows] * dX) < 4e-3
+    ref_dg = torch.zeros(Bs, d, dtype=torch.float64).index_add_(0, rows, (dX * delta).double())
+    assert rel_linf(dmod.cpu()[:, 2 * d:3 * d], ref_dg) < 1e-5
+    assert float(dmod.cpu()[:, :2 * d].abs().max()) == 0.0
+    # --- LayerNorm + modulate backward
+    xr = x1.double().requires_grad_(True)
+    sh = mod[:, 3 * d:4 * d].double().requires_grad_(True)
+    sc = mod[:, 4 * d:5 * d].double().requires_grad_(True)
+    xn = do.layer_norm(xr) * (1 + sc[rows]) + sh[rows]
+    dxn = bf16r(torch.randn((M, d), generator=gen))
+    xn.backward(dxn.double())
+    dXacc = dev(dX.clone())
+    dmod2 = dev(torch.zeros_like(mod))
+    N.check(N.lib().bsi_ln_mod_bwd(N.ptr(dev(dxn.to(torch.bfloat16))), N.ptr(dev(x1)), dmod_in.data_ptr() + 16 * d, 6 * d,
+                                   dmod2.data_ptr() + 12 * d, dmod2.data_ptr() + 16 * d, 6 * d, N.ptr(dXacc), M, d, tokens,
+                                   1e-5, N.stream()))
+    assert rel_linf(dXacc, dX.double() + xr.grad) < 2e-5
+    assert rel_linf(dmod2.cpu()[:, 3 * d:4 * d], sh.grad) < 1e-5
+    assert rel_linf(dmod2.cpu()[:, 4 * d:5 * d], sc.grad) < 1e-5
+
+
+def test_cast_transpose_and_silu_bwd(N):
+    gen = torch.Generator().manual_seed(9)
+    w = torch.randn((300, 84), generator=gen)
+    out = empty(84, 320, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_cast_transpose_bf16(N.ptr(dev(w)), 300, 84, N.ptr(out), 320, N.stream()))
+    ref = torch.zeros(84, 320)
+    ref[:, :300] = w.t()
+    assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    ds, pre = torch.randn(1000, generator=gen), torch.randn(1000, generator=gen) * 3
+    o = empty(1000, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_silu_bwd_bf16(N.ptr(dev(ds)), N.ptr(dev(pre)), 1000, N.ptr(o), N.stream()))
+    p = pre.double().requires_grad_(True)
+    do.silu(p).backward(ds.double())
+    assert rel_linf(o.cpu().float(), p.grad) < 5e-3

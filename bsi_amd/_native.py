@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int),
                 ("gate", C.c_void_p), ("gate_rows", C.c_int), ("gate_stride", C.c_int),
-                ("tokens", C.c_int), ("pos", C.c_void_p)]
+                ("tokens", C.c_int), ("pos", C.c_void_p), ("aux", C.c_void_p), ("out2", C.c_void_p)]
 
 
 class DitConfig(C.Structure):
@@ -46,7 +46,27 @@ class DitWeights(C.Structure):
                 ("blocks", C.POINTER(DitBlockWeights))]
 
 
-EPI_BIAS_F32, EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SILU_BF16, EPI_GATE_RESID, EPI_BIAS_POS_F32 = range(6)
+class DitBlockWeightsT(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_wT", "out_wT", "fc1_wT", "fc2_wT", "ada2_wT")]
+
+
+class DitWeightsT(C.Structure):
+    _fields_ = [("blocks", C.POINTER(DitBlockWeightsT))]
+
+
+class DitBlockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "out_w", "out_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                          "ada0_w", "ada0_b", "ada2_w", "ada2_b")]
+
+
+class DitGrads(C.Structure):
+    _fields_ = [("enc_w_padded", C.c_void_p), ("enc_b", C.c_void_p), ("dec_ln_w", C.c_void_p),
+                ("dec_ln_b", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p),
+                ("blocks", C.POINTER(DitBlockGrads))]
+
+
+(EPI_BIAS_F32, EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SILU_BF16, EPI_GATE_RESID, EPI_BIAS_POS_F32,
+ EPI_BIAS_GELU_DUAL, EPI_MUL_GELUGRAD_BF16) = range(8)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
@@ -84,6 +104,13 @@ _PROTOS = {
     "bsi_ln_mod_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "bsi_silu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bsi_cast_transpose_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "bsi_cast_rows_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "bsi_silu_bf16": (_i, [_vp, _sz, _vp, _vp]),
+    "bsi_dit_tape_bytes": (_sz, [C.POINTER(DitConfig), _i]),
+    "bsi_dit_backward_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),
+    "bsi_dit_train_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_dit_backward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), C.POINTER(DitWeightsT), C.POINTER(DitGrads), _i,
+                              _vp, _vp, _vp, _vp, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),

@@ -390,6 +390,9 @@ class BSI(nn.Module):
             if native is not None and not needs_grad:
                 mod = native.adaln_table(t)
                 return native.forward_native(mu, mod, c_in=c_in, c_skip=c_skip, c_out=c_out, coef_stride=1)
+            if native is not None and hasattr(native, "forward_train"):
+                # training: fused preconditioning + tape-recording forward, hand-written backward
+                return native.forward_train(mu, t, c_in, c_skip, c_out)
             rows, D = mu.shape[0], self._D
             inp = torch.empty_like(mu)
             N.check(N.lib().bsi_scale_rows(N.ptr(mu), N.ptr(c_in), 1, rows, D, N.ptr(inp), N.stream()))

@@ -75,6 +75,16 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// d/dx of the tanh-GELU: with s = sigmoid(2u), u = k0*(x + k1 x^3):  gelu = x*s,  gelu' = s + x*s*(1-s)*2*k0*(1+3*k1*x^2)
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float a = -2.0f * k0 * 1.4426950408889634f;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(x * (a + a * k1 * x2));
+    const float s = __builtin_amdgcn_rcpf(1.0f + e);
+    return s + x * s * (1.0f - s) * (2.0f * k0) * (1.0f + 3.0f * k1 * x2);
+}
+
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

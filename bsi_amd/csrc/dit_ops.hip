@@ -11,9 +11,14 @@ namespace {
 
 constexpr int TPB = 256;
 
-__global__ void cast_bf16_kernel(const float* __restrict__ in, int rows, int cols, __bf16* __restrict__ out, int ld) {
+__global__ void silu_bf16_kernel(const float* __restrict__ pre, size_t n, __bf16* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (__bf16)silu_f(pre[i]);
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, int ld_in, int rows, int cols, __bf16* __restrict__ out, int ld) {
     const int r = blockIdx.y;
-    const float* ir = in + (size_t)r * cols;
+    const float* ir = in + (size_t)r * ld_in;
     __bf16* orow = out + (size_t)r * ld;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4; c < ld; c += gridDim.x * blockDim.x * 4) {
         float v[4];
@@ -273,14 +278,28 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
 
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
 
-extern "C" int bsi_cast_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream) {
-    BSI_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_out >= cols && ld_out % 4 == 0,
-                  "bsi_cast_bf16: bad args rows=%d cols=%d ld=%d", rows, cols, ld_out);
+extern "C" int bsi_cast_rows_bf16(const float* in, int ld_in, int rows, int cols, void* out, int ld_out,
+                                  bsi_stream_t stream) {
+    BSI_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= cols && ld_out % 4 == 0,
+                  "bsi_cast_rows_bf16: bad args rows=%d cols=%d ld_in=%d ld_out=%d", rows, cols, ld_in, ld_out);
     int gx = (ld_out / 4 + TPB - 1) / TPB;
     if (gx > 16) gx = 16;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(gx, rows), dim3(TPB), 0, S(stream), in, rows, cols,
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(gx, rows), dim3(TPB), 0, S(stream), in, ld_in, rows, cols,
                        reinterpret_cast<__bf16*>(out), ld_out);
     BSI_CHECK_LAUNCH("bsi_cast_bf16");
+    return BSI_OK;
+}
+
+extern "C" int bsi_cast_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream) {
+    return bsi_cast_rows_bf16(in, cols, rows, cols, out, ld_out, stream);
+}
+
+extern "C" int bsi_silu_bf16(const float* pre, size_t n, void* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(pre && out && n > 0, "bsi_silu_bf16: bad args");
+    size_t g = (n + TPB - 1) / TPB;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(silu_bf16_kernel, dim3((int)g), dim3(TPB), 0, S(stream), pre, n, reinterpret_cast<__bf16*>(out));
+    BSI_CHECK_LAUNCH("bsi_silu_bf16");
     return BSI_OK;
 }
 

@@ -1,0 +1,280 @@
+// Training engine of the DenoisingDiT: forward that records a tape, and the hand-written backward
+// (replaces torch autograd over bsi/models/dit.py:87-103,174-181 of the reference in `BSI.train_loss(...).mean().backward()`,
+// bsi/tasks/bsi.py:187-194).  Host-side sequencing only; no allocation, no synchronisation.
+//
+// Tape per block and token row (bf16 unless noted): xn1 [d], qkv [3d], lse (fp32 per head), ao [d], d1 [d], xn2 [d],
+// hp [4d] (pre-GELU), h [4d], d2 [d]  = 16 d elements = 32 KB per token at d = 1024 (8 MB per image per block).
+// Only the FINAL residual stream is kept in fp32: the backward rewinds it block by block (x1 = x2 - gate*d2, ...).
+#include "common.h"
+#include "dit_ops.h"
+#include "prof.h"
+
+int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
+                             const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
+                             int coef_stride, float* dX, float* d_dec_w, float* d_dec_b, float* d_ln_w, float* d_ln_b,
+                             hipStream_t s);
+
+namespace {
+
+inline size_t au(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Dims {
+    int tokens, kin, kpad, P, nfreq, cin, dim, depth, heads;
+    size_t M;
+};
+
+inline Dims dims_of(const bsi_dit_config* c, int B) {
+    Dims d;
+    d.nfreq = (c->ff_nmax >= c->ff_nmin) ? (c->ff_nmax - c->ff_nmin + 1) : 0;
+    d.cin = c->C + c->C * d.nfreq * 2;
+    d.tokens = (c->H / c->patch) * (c->W / c->patch);
+    d.kin = c->patch * c->patch * d.cin;
+    d.kpad = (int)au((size_t)d.kin, 64);
+    d.P = c->patch * c->patch * c->C;
+    d.dim = c->dim; d.depth = c->depth; d.heads = c->heads;
+    d.M = (size_t)B * d.tokens;
+    return d;
+}
+
+struct BlockTape {
+    char *xn1, *qkv, *ao, *d1, *xn2, *hp, *h, *d2;
+    float* lse;
+};
+
+struct Tape {
+    char* a0;       // bf16 [M, kpad]
+    float* x;       // fp32 [M, dim]  final residual stream
+    float* mod;     // fp32 [B, depth, 6 dim]
+    char* emb;      // bf16 [B, dim]
+    float* ada_pre; // fp32 [depth, B, dim]
+    char* ada_s;    // bf16 [depth, B, dim]
+    char* blocks;   // per block region
+    size_t block_bytes, total;
+};
+
+inline Tape carve_tape(const Dims& d, int B, void* base) {
+    Tape t;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    const size_t M = d.M, dim = d.dim;
+    t.a0 = p + off; off += au(M * d.kpad * 2);
+    t.x = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
+    t.mod = reinterpret_cast<float*>(p + off); off += au((size_t)B * d.depth * 6 * dim * 4);
+    t.emb = p + off; off += au((size_t)B * dim * 2);
+    t.ada_pre = reinterpret_cast<float*>(p + off); off += au((size_t)d.depth * B * dim * 4);
+    t.ada_s = p + off; off += au((size_t)d.depth * B * dim * 2);
+    t.blocks = p + off;
+    t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4);
+    off += t.block_bytes * d.depth;
+    t.total = off;
+    return t;
+}
+
+inline BlockTape block_tape(const Tape& t, const Dims& d, int B, int l) {
+    BlockTape b;
+    char* p = t.blocks + (size_t)l * t.block_bytes;
+    const size_t M = d.M, dim = d.dim;
+    size_t off = 0;
+    b.xn1 = p + off; off += au(M * dim * 2);
+    b.qkv = p + off; off += au(M * 3 * dim * 2);
+    b.ao = p + off; off += au(M * dim * 2);
+    b.d1 = p + off; off += au(M * dim * 2);
+    b.xn2 = p + off; off += au(M * dim * 2);
+    b.hp = p + off; off += au(M * 4 * dim * 2);
+    b.h = p + off; off += au(M * 4 * dim * 2);
+    b.d2 = p + off; off += au(M * dim * 2);
+    b.lse = reinterpret_cast<float*>(p + off);
+    return b;
+}
+
+struct BwdWs {
+    float* dX;     // fp32 [M, dim]
+    char* dd;      // bf16 [M, dim]     gradient of a branch delta
+    char* dbig;    // bf16 [M, 4 dim]   dhp / dqkv
+    char* dsmall;  // bf16 [M, dim]     dxn / dao
+    float* dmod;   // fp32 [B, depth, 6 dim]
+    char* dmod_bf; // bf16 [B, 6 dim]
+    float* ds;     // fp32 [B, dim]
+    char* dpre_bf; // bf16 [B, dim]
+    char* tn;      // TN GEMM slabs
+    char* cs;      // colsum slabs
+    size_t total;
+};
+
+inline BwdWs carve_bwd(const Dims& d, int B, void* base) {
+    BwdWs w;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    const size_t M = d.M, dim = d.dim;
+    w.dX = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
+    w.dd = p + off; off += au(M * dim * 2);
+    w.dbig = p + off; off += au(M * 4 * dim * 2);
+    w.dsmall = p + off; off += au(M * dim * 2);
+    w.dmod = reinterpret_cast<float*>(p + off); off += au((size_t)B * d.depth * 6 * dim * 4);
+    w.dmod_bf = p + off; off += au((size_t)B * 6 * dim * 2);
+    w.ds = reinterpret_cast<float*>(p + off); off += au((size_t)B * dim * 4);
+    w.dpre_bf = p + off; off += au((size_t)B * dim * 2);
+    w.tn = p + off; off += au(bsi_gemm_tn_workspace_bytes((int)M, 4 * (int)dim, (int)dim));
+    w.cs = p + off; off += au(bsi_colsum_workspace_bytes(6 * (int)dim));
+    w.total = off;
+    return w;
+}
+
+int gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo, int M, int N, int K, int epi,
+         const void* aux, void* out2, const float* pos, int tokens, bsi_stream_t stream) {
+    bsi_gemm_args g{};
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+    g.epilogue = epi; g.aux = aux; g.out2 = out2; g.pos = pos; g.tokens = tokens;
+    return bsi_gemm_bf16(&g, stream);
+}
+
+#define TRY(expr)            \
+    do {                     \
+        int rc__ = (expr);   \
+        if (rc__) return rc__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" size_t bsi_dit_tape_bytes(const bsi_dit_config* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return carve_tape(dims_of(cfg, B), B, nullptr).total;
+}
+
+extern "C" size_t bsi_dit_backward_workspace_bytes(const bsi_dit_config* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return carve_bwd(dims_of(cfg, B), B, nullptr).total;
+}
+
+extern "C" int bsi_silu_bf16(const float* pre, size_t n, void* out, bsi_stream_t stream);
+
+extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w, int B, const float* mu,
+                                     const float* t, const float* c_in, const float* c_skip, const float* c_out,
+                                     float* out, void* tape_mem, bsi_stream_t stream) {
+    BSI_CHECK_ARG(cfg && w && w->blocks && mu && t && out && tape_mem && B > 0, "bsi_dit_train_forward: bad args");
+    BSI_CHECK_ARG((c_in == nullptr) == (c_skip == nullptr) && (c_in == nullptr) == (c_out == nullptr),
+                  "bsi_dit_train_forward: c_in/c_skip/c_out must be given together");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Dims d = dims_of(cfg, B);
+    BSI_CHECK_ARG(d.tokens % 64 == 0 && d.dim % 64 == 0 && d.dim / d.heads == 64 && d.tokens <= 256,
+                  "bsi_dit_train_forward: unsupported geometry (tokens %d, head dim %d)", d.tokens, d.dim / d.heads);
+    const int dim = d.dim, M = (int)d.M;
+    const int mod_stride = d.depth * 6 * dim;
+    Tape tp = carve_tape(d, B, tape_mem);
+
+    // adaLN tables, keeping the intermediate activations (dit.py:77-81)
+    TRY(bsi_nyquist_embed(t, B, w->t_scale, w->t_bias, dim, nullptr, tp.emb, stream));
+    for (int l = 0; l < d.depth; ++l) {
+        const bsi_dit_block_weights& bw = w->blocks[l];
+        float* pre = tp.ada_pre + (size_t)l * B * dim;
+        char* sl = tp.ada_s + (size_t)l * B * dim * 2;
+        TRY(gemm(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
+        TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
+        TRY(gemm(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, BSI_EPI_BIAS_F32,
+                 nullptr, nullptr, nullptr, 0, stream));
+    }
+    TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin, d.nfreq, d.kpad, tp.a0, s));
+    TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, tp.x, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32, nullptr, nullptr,
+             w->pos, d.tokens, stream));
+    const void* pend_delta = nullptr;
+    const float* pend_gate = nullptr;
+    for (int l = 0; l < d.depth; ++l) {
+        const bsi_dit_block_weights& bw = w->blocks[l];
+        BlockTape bt = block_tape(tp, d, B, l);
+        const float* ml = tp.mod + (size_t)l * 6 * dim;
+        TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, B, mod_stride, d.tokens, nullptr,
+                                  nullptr, bt.xn1, stream));
+        TRY(gemm(bt.xn1, dim, bw.qkv_w, dim, bw.qkv_b, bt.qkv, 3 * dim, M, 3 * dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
+        TRY(bsi_attention_fwd_lse(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse, stream));
+        TRY(gemm(bt.ao, dim, bw.out_w, dim, bw.out_b, bt.d1, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
+        TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride, d.tokens,
+                                  nullptr, nullptr, bt.xn2, stream));
+        TRY(gemm(bt.xn2, dim, bw.fc1_w, dim, bw.fc1_b, bt.h, 4 * dim, M, 4 * dim, dim, BSI_EPI_BIAS_GELU_DUAL, nullptr, bt.hp, nullptr, 0, stream));
+        TRY(gemm(bt.h, 4 * dim, bw.fc2_w, 4 * dim, bw.fc2_b, bt.d2, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
+        pend_delta = bt.d2;
+        pend_gate = ml + 5 * dim;
+    }
+    // materialise the final residual stream (kept for the backward), then the decoder
+    TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, pend_delta, pend_gate, nullptr, nullptr, B, mod_stride, d.tokens, nullptr,
+                              nullptr, nullptr, stream));
+    return bsi_dit_final_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, w->dec_b, cfg->C, cfg->H, cfg->W,
+                                cfg->patch, mu, c_skip, c_out, 1, nullptr, nullptr, 1, 0, out, s);
+}
+
+extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w, const bsi_dit_weights_t* wT,
+                                const bsi_dit_grads* g, int B, const float* g_out, const float* c_out, void* tape_mem,
+                                void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(cfg && w && w->blocks && wT && wT->blocks && g && g->blocks && g_out && tape_mem && workspace && B > 0,
+                  "bsi_dit_backward: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Dims d = dims_of(cfg, B);
+    const int dim = d.dim, M = (int)d.M;
+    const int mod_stride = d.depth * 6 * dim;
+    Tape tp = carve_tape(d, B, tape_mem);
+    BwdWs ws = carve_bwd(d, B, workspace);
+
+    if (hipMemsetAsync(ws.dmod, 0, (size_t)B * mod_stride * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(g->dec_w, 0, (size_t)d.P * dim * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(g->dec_b, 0, (size_t)d.P * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(g->dec_ln_w, 0, (size_t)dim * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(g->dec_ln_b, 0, (size_t)dim * sizeof(float), s) != hipSuccess) {
+        bsi_set_error("bsi_dit_backward: memset failed");
+        return BSI_ELAUNCH;
+    }
+    // decoder: dX = d/dx_final, parameter gradients of patch_decoder (dit.py:163-165)
+    TRY(bsi_dit_final_bwd_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, cfg->C, cfg->H, cfg->W, cfg->patch,
+                                 g_out, c_out, 1, ws.dX, g->dec_w, g->dec_b, g->dec_ln_w, g->dec_ln_b, s));
+
+    for (int l = d.depth - 1; l >= 0; --l) {
+        const bsi_dit_block_weights& bw = w->blocks[l];
+        const bsi_dit_block_weights_t& bT = wT->blocks[l];
+        const bsi_dit_block_grads& bg = g->blocks[l];
+        BlockTape bt = block_tape(tp, d, B, l);
+        const float* ml = tp.mod + (size_t)l * 6 * dim;
+        float* dml = ws.dmod + (size_t)l * 6 * dim;
+        (void)bw;
+        // ---- MLP branch: x2 = x1 + g_m * d2
+        TRY(bsi_gate_bwd(ws.dX, bt.d2, tp.x, ml + 5 * dim, mod_stride, dml + 5 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
+        // dh = dd2 . W2, times gelu'(hp)  -> dhp
+        TRY(gemm(ws.dd, dim, bT.fc2_wT, dim, nullptr, ws.dbig, 4 * dim, M, 4 * dim, dim, BSI_EPI_MUL_GELUGRAD_BF16, bt.hp, nullptr, nullptr, 0, stream));
+        TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, bg.fc2_b, 0, ws.cs, stream));
+        // dxn2 = dhp . W1
+        TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
+        TRY(bsi_gemm_tn_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dbig, 4 * dim, M, 4 * dim, bg.fc1_b, 0, ws.cs, stream));
+        TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX, M, dim,
+                           d.tokens, 1e-5f, stream));
+        // ---- attention branch: x1 = x0 + g_a * d1
+        TRY(bsi_gate_bwd(ws.dX, bt.d1, tp.x, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
+        TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
+        TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, bg.out_b, 0, ws.cs, stream));
+        TRY(bsi_attention_bwd(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim, stream));
+        TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
+        TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dbig, 3 * dim, M, 3 * dim, bg.qkv_b, 0, ws.cs, stream));
+        TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, M, dim, d.tokens, 1e-5f, stream));
+    }
+    // patch encoder (dit.py:154,178): x0 = A0 . Wenc^T + b + pos
+    TRY(bsi_silu_bwd_bf16(ws.dX, nullptr, (size_t)M * dim, ws.dd, stream));  // bf16 copy of dX
+    TRY(bsi_gemm_tn_bf16(ws.dd, dim, tp.a0, d.kpad, M, dim, d.kpad, g->enc_w_padded, d.kpad, 0, ws.tn, stream));
+    TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, g->enc_b, 0, ws.cs, stream));
+
+    // adaLN MLPs (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2 with rows = samples
+    for (int l = 0; l < d.depth; ++l) {
+        const bsi_dit_block_weights_t& bT = wT->blocks[l];
+        const bsi_dit_block_grads& bg = g->blocks[l];
+        const float* pre = tp.ada_pre + (size_t)l * B * dim;
+        const char* sl = tp.ada_s + (size_t)l * B * dim * 2;
+        // contiguous bf16 copy of dmod[:, l, :]
+        TRY(bsi_cast_rows_bf16(ws.dmod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
+        TRY(bsi_gemm_tn_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dmod_bf, 6 * dim, B, 6 * dim, bg.ada2_b, 0, ws.cs, stream));
+        TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
+        TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));
+        TRY(bsi_gemm_tn_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, 0, ws.tn, stream));
+        TRY(bsi_colsum_bf16(ws.dpre_bf, dim, B, dim, bg.ada0_b, 0, ws.cs, stream));
+    }
+    return BSI_OK;
+}

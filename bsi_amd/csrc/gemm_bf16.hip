@@ -39,6 +39,8 @@ struct GemmParams {
     int gate_rows, gate_stride;
     int tokens;
     const float* pos;
+    const void* aux;  // MUL_GELUGRAD: pre-activation (bf16, layout of out)
+    void* out2;       // BIAS_GELU_DUAL: pre-activation output (bf16, layout of out)
     int tiles_m, tiles_n;
     int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
@@ -58,7 +60,8 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm,
 template <int EPI>
 struct EpiTraits {
     static constexpr bool out_bf16 = (EPI == BSI_EPI_BIAS_BF16 || EPI == BSI_EPI_BIAS_GELU_BF16 ||
-                                      EPI == BSI_EPI_BIAS_SILU_BF16);
+                                      EPI == BSI_EPI_BIAS_SILU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL ||
+                                      EPI == BSI_EPI_MUL_GELUGRAD_BF16);
 };
 
 // XCD-aware bijective remap of the linear workgroup id (guide §5.5 T1).
@@ -87,14 +90,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mw0 + 16 * j + (lane & 15);
-        if ((m >= p.M || !nb_ok) && !(EpiTraits<EPI>::out_bf16 && scratch)) continue;
+        if ((m >= p.M || !nb_ok) && !(EpiTraits<EPI>::out_bf16 && scratch && EPI != BSI_EPI_BIAS_GELU_DUAL &&
+                                      EPI != BSI_EPI_MUL_GELUGRAD_BF16))
+            continue;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
 
-        if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
+        if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // generic path: direct stores of the pre-activation
+            if (m < p.M && nb_ok) {
+                u32x4 a0, a1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                    a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                }
+                __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
+                __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
+                __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
+            }
+        }
+        if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+            if (m < p.M && nb_ok) {
+                const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
+                const u32x4 x0 = *reinterpret_cast<const u32x4*>(ax), x1 = *reinterpret_cast<const u32x4*>(ax + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
+                    v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
+                    v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
+                    v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
+                }
+            }
+        }
+        if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
         } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
@@ -109,7 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
                 w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
             }
-            if (scratch) {
+            if (scratch && EPI != BSI_EPI_BIAS_GELU_DUAL && EPI != BSI_EPI_MUL_GELUGRAD_BF16) {
                 // row r of the wave's [16*TM][128 B] image, 16-B chunks XOR-swizzled by (r & 7)
                 const int r = 16 * j + (lane & 15), q2 = (lane >> 4) * 2;
                 *reinterpret_cast<u32x4*>(scratch + r * 128 + (((q2) ^ (r & 7)) << 4)) = w0;
@@ -148,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         }
     }
-    if constexpr (EpiTraits<EPI>::out_bf16) {
+    if constexpr (EpiTraits<EPI>::out_bf16 && EPI != BSI_EPI_BIAS_GELU_DUAL && EPI != BSI_EPI_MUL_GELUGRAD_BF16) {
         if (scratch) {
             // the wave reads back its own writes: LDS accesses of one wave are ordered, only the counter must drain
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -982,7 +1013,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
-                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
+                    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+                        const int m = mw0 + 16 * j + rho;
+                        if (m < p.M && nb_ok) {
+                            const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
+                            const u32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax));
+                            const u32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + 8));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
+                                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
+                                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
+                                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
+                            }
+                        }
+                    }
+                    if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // pre-activation: direct 32-B stores (training only)
+                        const int m = mw0 + 16 * j + rho;
+                        if (m < p.M && nb_ok) {
+                            u32x4 a0, a1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                                a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                            }
+                            __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
+                            __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
+                            __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
+                        }
+                    }
+                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
                     } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
@@ -1065,7 +1125,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             // the stage of step v+1 must have landed; younger stages (and, right after an epilogue, its 16
             // stores) may stay in flight
             if (issued) {
-                if (BF16_OUT && after_e > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1) + 16) : "memory");
+                if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1) + 16) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1275,6 +1336,8 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
     p.gate = a->gate; p.gate_rows = a->gate_rows; p.gate_stride = a->gate_stride;
     p.tokens = a->tokens > 0 ? a->tokens : 1;
     p.pos = a->pos;
+    p.aux = a->aux;
+    p.out2 = a->out2;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (a->epilogue) {
         case BSI_EPI_BIAS_F32: return launch_epi<BSI_EPI_BIAS_F32>(p, s);
@@ -1287,6 +1350,12 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
         case BSI_EPI_BIAS_POS_F32:
             BSI_CHECK_ARG(a->pos && a->tokens > 0, "bsi_gemm_bf16: BIAS_POS needs pos/tokens");
             return launch_epi<BSI_EPI_BIAS_POS_F32>(p, s);
+        case BSI_EPI_BIAS_GELU_DUAL:
+            BSI_CHECK_ARG(a->out2, "bsi_gemm_bf16: GELU_DUAL needs out2");
+            return launch_epi<BSI_EPI_BIAS_GELU_DUAL>(p, s);
+        case BSI_EPI_MUL_GELUGRAD_BF16:
+            BSI_CHECK_ARG(a->aux, "bsi_gemm_bf16: MUL_GELUGRAD needs aux");
+            return launch_epi<BSI_EPI_MUL_GELUGRAD_BF16>(p, s);
         default:
             bsi_set_error("bsi_gemm_bf16: unknown epilogue %d", a->epilogue);
             return BSI_EINVAL;

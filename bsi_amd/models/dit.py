@@ -96,6 +96,8 @@ class DenoisingDiT(nn.Module):
         self._pack = None       # cached bf16 weight shadows + ctypes tables
         self._pack_key = None
         self._ws = None         # cached workspace tensor
+        self._pack_t = None     # cached transposed shadows (training)
+        self._pack_t_key = None
 
     # ------------------------------------------------------------------------------------------------
     # native plumbing
@@ -198,6 +200,11 @@ class DenoisingDiT(nn.Module):
                                     N.ptr(c_in), N.ptr(c_skip), N.ptr(c_out), coef_stride, N.ptr(out), N.ptr(ws),
                                     N.ptr(tokens), N.stream()))
         return (out, tokens) if return_tokens else out
+
+    def forward_train(self, mu: Tensor, t: Tensor, c_in=None, c_skip=None, c_out=None) -> Tensor:
+        """Differentiable evaluation (parameters only): tape-recording HIP forward + hand-written HIP backward."""
+        from .dit_train import dit_forward_train
+        return dit_forward_train(self, mu, t, c_in, c_skip, c_out)
 
     def forward(self, mu: Tensor, t: Tensor) -> Tensor:
         """f(mu, t): mu [B, *data_shape] fp32, t [B] in [0, 1]  (dit.py:225-233)."""

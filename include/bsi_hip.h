@@ -123,6 +123,9 @@ int bsi_to_uint8(const float* x, float lo, float hi, size_t n, uint8_t* out, bsi
 /* fp32 -> bf16 (round to nearest even); used to refresh the bf16 weight shadows.
  * Copies `rows` rows of `cols` floats into rows of `ld_out` bf16 (zero-filling cols..ld_out). */
 int bsi_cast_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream);
+/* same with an input row stride (ld_in floats); out_bf16 = bf16(silu(pre)) elementwise */
+int bsi_cast_rows_bf16(const float* in, int ld_in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream);
+int bsi_silu_bf16(const float* pre, size_t n, void* out, bsi_stream_t stream);
 
 /* fourier_features.py:21-36 (FourierFeatures.forward): x fp32 viewed as [outer, C, inner] ->
  * out [outer, C*nf*2, inner], nf = n_max-n_min+1, channel (c*nf + n)*2 + o = sin(o*pi/2 + fl32(2*pi*2^n) * x[c]). */
@@ -143,6 +146,8 @@ enum {
     BSI_EPI_BIAS_SILU_BF16 = 3, /* out_bf16 = bf16(silu(acc + bias))       (adaLN_modulation.0-1, :79-81) */
     BSI_EPI_GATE_RESID = 4,     /* out_f32[m,n] += gate[row(m), n] * (acc + bias[n])    (dit.py:93-102) */
     BSI_EPI_BIAS_POS_F32 = 5,   /* out_f32[m,n] = acc + bias[n] + pos[m % tokens, n]     (dit.py:178)  */
+    BSI_EPI_BIAS_GELU_DUAL = 6, /* training: out2_bf16 = bf16(acc + bias) (saved for backward), out_bf16 = bf16(gelu(.)) */
+    BSI_EPI_MUL_GELUGRAD_BF16 = 7, /* backward: out_bf16 = bf16((acc + bias) * gelu_tanh'(aux[m,n])), aux bf16 like out */
 };
 typedef struct bsi_gemm_args {
     const void* A;  /* bf16 [M, lda] */
@@ -157,6 +162,8 @@ typedef struct bsi_gemm_args {
     int gate_rows, gate_stride;
     int tokens;       /* tokens per sample (GATE_RESID, BIAS_POS) */
     const float* pos; /* [tokens, N] (BIAS_POS) */
+    const void* aux;  /* bf16 [M, ldo] (MUL_GELUGRAD) */
+    void* out2;       /* bf16 [M, ldo] (BIAS_GELU_DUAL) */
 } bsi_gemm_args;
 int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
 /* Weight-gradient GEMM (backward of nn.Linear w.r.t. its weight, autograd `grad_output.T @ input`):
@@ -268,6 +275,40 @@ int bsi_dit_adaln(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, 
 int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, int B, const float* mu,
                     const float* mod, int mod_rows, const float* c_in, const float* c_skip, const float* c_out,
                     int coef_stride, float* out, void* workspace, float* tokens_out, bsi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DenoisingDiT training engine — forward with a tape + hand-written backward (replaces torch autograd over
+ * dit.py:87-103,174-181 inside `BSI.train_loss(...).mean().backward()`, bsi/tasks/bsi.py:187-194).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bsi_dit_block_weights_t { /* transposed bf16 shadows W^T ([in][out] row-major) for the input gradients */
+    const void *qkv_wT, *out_wT, *fc1_wT, *fc2_wT, *ada2_wT;
+} bsi_dit_block_weights_t;
+typedef struct bsi_dit_weights_t {
+    const bsi_dit_block_weights_t* blocks; /* host array [depth] */
+} bsi_dit_weights_t;
+
+typedef struct bsi_dit_block_grads { /* fp32 gradient buffers, shapes of the parameters */
+    float *qkv_w, *qkv_b, *out_w, *out_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ada0_w, *ada0_b, *ada2_w, *ada2_b;
+} bsi_dit_block_grads;
+typedef struct bsi_dit_grads {
+    float* enc_w_padded; /* [dim, kpad]: the caller keeps columns 0..patch*patch*Cin-1 */
+    float* enc_b;
+    float *dec_ln_w, *dec_ln_b, *dec_w, *dec_b;
+    const bsi_dit_block_grads* blocks; /* host array [depth] */
+} bsi_dit_grads;
+
+size_t bsi_dit_tape_bytes(const bsi_dit_config* cfg, int B);
+size_t bsi_dit_backward_workspace_bytes(const bsi_dit_config* cfg, int B);
+/* out = c_skip*mu + c_out*f(c_in*mu, t) (or f(mu, t) with NULL coefficients), per-sample t/coefficients [B];
+ * records the activations the backward needs in `tape` (bsi_dit_tape_bytes). */
+int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, int B, const float* mu,
+                          const float* t, const float* c_in, const float* c_skip, const float* c_out, float* out,
+                          void* tape, bsi_stream_t stream);
+/* Gradients of every parameter given g_out = dL/d(out) [B,C,H,W].  Overwrites the buffers of `g`; consumes the tape
+ * (the residual stream in it is rewound in place). */
+int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, const bsi_dit_weights_t* wT /*host*/,
+                     const bsi_dit_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
+                     void* workspace, bsi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class timing with HIP events on the launch stream.

@@ -222,3 +222,25 @@ def test_full_size_dit_l2_one_forward_vs_oracle():
         a = bsi.sample(4, torch.Generator(DEV).manual_seed(5), t=torch.linspace(0, 1, 5, device=DEV))
         b = bsi.sample(4, torch.Generator(DEV).manual_seed(5), t=torch.linspace(0, 1, 5, device=DEV))
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_train_loss_gradients_vs_golden():
+    """BSI.train_loss(...).mean().backward() through the HIP training engine vs the reference's gradients (G4)."""
+    for case, tag, ff in [("g4_train_dit", "dit_ff", True), ("g4_train_dit_noff", "dit_noff", False)]:
+        g = golden(case)
+        model = make_model(tag, ff).train()
+        bsi = make_bsi(model)
+        with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+            loss = bsi.train_loss(g["x"].to(DEV))
+        assert max_rel(loss.detach(), g["loss"]) < 1e-2
+        loss.mean().backward()
+        sq, worst = 0.0, (0.0, None)
+        for name, p in model.named_parameters():
+            ref = g["G." + name]
+            assert p.grad is not None and p.grad.shape == ref.shape, name
+            sq += float((p.grad.double() ** 2).sum())
+            err = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+            worst = max(worst, (err, name))
+            # bf16 operands in every product of the backward chain: relative L2 error per tensor below 3e-2
+            assert err < 3e-2, (name, err)
+        assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)

@@ -111,6 +111,10 @@ _PROTOS = {
     "bsi_dit_train_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bsi_dit_backward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), C.POINTER(DitWeightsT), C.POINTER(DitGrads), _i,
                               _vp, _vp, _vp, _vp, _vp]),
+    "bsi_dit_backward_set_events": (_i, [_vp, _i]),
+    "bsi_sqnorm_workspace_bytes": (_sz, []),
+    "bsi_grad_sqnorm": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "bsi_clip_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),

@@ -128,6 +128,9 @@ int gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void
     return bsi_gemm_bf16(&g, stream);
 }
 
+void* const* g_block_events = nullptr;
+int g_block_events_n = 0;
+
 #define TRY(expr)            \
     do {                     \
         int rc__ = (expr);   \
@@ -135,6 +138,12 @@ int gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void
     } while (0)
 
 }  // namespace
+
+extern "C" int bsi_dit_backward_set_events(void* const* events, int depth) {
+    g_block_events = events;
+    g_block_events_n = events ? depth : 0;
+    return BSI_OK;
+}
 
 extern "C" size_t bsi_dit_tape_bytes(const bsi_dit_config* cfg, int B) {
     if (!cfg || B <= 0) return 0;
@@ -255,26 +264,24 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
         TRY(bsi_colsum_bf16(ws.dbig, 3 * dim, M, 3 * dim, bg.qkv_b, 0, ws.cs, stream));
         TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, M, dim, d.tokens, 1e-5f, stream));
+        {   // adaLN MLP of this block (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2, rows = samples
+            const float* pre = tp.ada_pre + (size_t)l * B * dim;
+            const char* sl = tp.ada_s + (size_t)l * B * dim * 2;
+            // contiguous bf16 copy of dmod[:, l, :]
+            TRY(bsi_cast_rows_bf16(ws.dmod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
+            TRY(bsi_gemm_tn_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, 0, ws.tn, stream));
+            TRY(bsi_colsum_bf16(ws.dmod_bf, 6 * dim, B, 6 * dim, bg.ada2_b, 0, ws.cs, stream));
+            TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
+            TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));
+            TRY(bsi_gemm_tn_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, 0, ws.tn, stream));
+            TRY(bsi_colsum_bf16(ws.dpre_bf, dim, B, dim, bg.ada0_b, 0, ws.cs, stream));
+        }
+        if (g_block_events && l < g_block_events_n && g_block_events[l]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(g_block_events[l]), s);
     }
     // patch encoder (dit.py:154,178): x0 = A0 . Wenc^T + b + pos
     TRY(bsi_silu_bwd_bf16(ws.dX, nullptr, (size_t)M * dim, ws.dd, stream));  // bf16 copy of dX
     TRY(bsi_gemm_tn_bf16(ws.dd, dim, tp.a0, d.kpad, M, dim, d.kpad, g->enc_w_padded, d.kpad, 0, ws.tn, stream));
     TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, g->enc_b, 0, ws.cs, stream));
 
-    // adaLN MLPs (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2 with rows = samples
-    for (int l = 0; l < d.depth; ++l) {
-        const bsi_dit_block_weights_t& bT = wT->blocks[l];
-        const bsi_dit_block_grads& bg = g->blocks[l];
-        const float* pre = tp.ada_pre + (size_t)l * B * dim;
-        const char* sl = tp.ada_s + (size_t)l * B * dim * 2;
-        // contiguous bf16 copy of dmod[:, l, :]
-        TRY(bsi_cast_rows_bf16(ws.dmod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
-        TRY(bsi_gemm_tn_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dmod_bf, 6 * dim, B, 6 * dim, bg.ada2_b, 0, ws.cs, stream));
-        TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));
-        TRY(bsi_gemm_tn_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dpre_bf, dim, B, dim, bg.ada0_b, 0, ws.cs, stream));
-    }
     return BSI_OK;
 }

@@ -1,0 +1,167 @@
+"""Data-parallel training step for the native BSI/DiT path: one process per GPU, gradients averaged with an RCCL
+all-reduce (torch.distributed backend "nccl" on ROCm) on per-block buckets that start as soon as the HIP backward
+has produced a block's gradients, then one fused clip + AdamW + EMA pass over flat fp32 buffers.
+
+Replaces, for this path, what the reference obtains from Lightning: `DistributedDataParallel(model,
+static_graph=True)` (bsi/tasks/bsi.py:163-166), `gradient_clip_val: 1.0` (config/train.yaml:40), fused
+`torch.optim.AdamW` (config/task/optimizer/adamw.yaml, config/experiment/imagenet32.yaml:27-30), the warm-up/cosine
+LR schedule stepped every optimizer step (bsi/lr_scheduler.py:35-58, bsi/tasks/bsi.py:303-308) and `EMA.update()`
+after every batch (bsi/tasks/bsi.py:196-198, bsi/tasks/ema_pytorch.py:308-340).
+"""
+import copy
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+
+def split_batch(batch_size: int, world_size: int, rank: int) -> int:
+    """Per-rank share of a global batch (bsi/data/h5image.py:309-312)."""
+    return batch_size // world_size + int(rank < (batch_size % world_size))
+
+
+def rank_indices(n: int, world_size: int, rank: int):
+    """Indices a rank evaluates out of n samples (DistributedNonPaddingSampler, bsi/data/sampler.py:63)."""
+    return list(range(rank, n, world_size))
+
+
+def warmup_cosine_lr(step: int, *, base_lr: float, warmup_steps: int, max_steps: int, start_lr: float, end_lr: float) -> float:
+    """Learning rate in effect for optimizer step `step` (0-based) under WarmUpCosineAnnealing
+    (bsi/lr_scheduler.py:10-58, config/task/lr_scheduler/cosine.yaml): linear from start_lr to base_lr over
+    warmup_steps, then cosine from base_lr to end_lr over max_steps - warmup_steps."""
+    if step < warmup_steps:
+        return start_lr + (base_lr - start_lr) * (step / warmup_steps)
+    t_max = max_steps - warmup_steps
+    s = min(step - warmup_steps, t_max)
+    return end_lr + (base_lr - end_lr) * (1 + math.cos(math.pi * s / t_max)) / 2
+
+
+def ema_weight(call_index: int, *, beta: float = 0.9999, update_after_step: int = 1000, inv_gamma: float = 1.0,
+               power: float = 2.0 / 3.0, min_value: float = 0.0) -> float:
+    """Lerp weight (1 - decay) of the `call_index`-th (0-based) call of EMA.update() (ema_pytorch.py:308-340):
+    the first call and every call with step <= update_after_step copy the online weights (weight 1.0)."""
+    if call_index <= update_after_step:
+        return 1.0
+    epoch = (call_index + 1) - update_after_step - 1
+    value = 1 - (1 + epoch / inv_gamma) ** -power
+    decay = max(min_value, min(value, beta))
+    return 1.0 - decay
+
+
+def allreduce_sum_buckets(buckets, group=None, async_op=False):
+    """Sum-all-reduce every tensor of `buckets` (device agnostic: RCCL on GPUs, gloo in the CPU tests)."""
+    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for b in buckets]
+    return works
+
+
+class FlatParams:
+    """Re-homes all parameters of a module into one flat fp32 buffer (parameters become views), so that the
+    optimizer, the EMA and the gradient all-reduce work on contiguous memory."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.names = [n for n, _ in module.named_parameters()]
+        params = [p for _, p in module.named_parameters()]
+        self.sizes = [p.numel() for p in params]
+        self.offsets = [0]
+        for s in self.sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        dev = params[0].device
+        self.flat = torch.empty(self.offsets[-1], dtype=torch.float32, device=dev)
+        for p, o, s in zip(params, self.offsets, self.sizes):
+            self.flat[o:o + s].copy_(p.detach().reshape(-1))
+            p.data = self.flat[o:o + s].view_as(p)
+
+    def span(self, prefix: str):
+        """[begin, end) of the parameters whose name starts with `prefix` (they are contiguous)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), f"parameters under {prefix} are not contiguous"
+        return self.offsets[idx[0]], self.offsets[idx[-1] + 1]
+
+
+class DPTrainer:
+    """Native data-parallel train step around a `bsi_amd.BSI` whose model is a `bsi_amd.models.dit.DenoisingDiT`."""
+
+    def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
+                 ema_update_after_step: int = 1000, lr_schedule=None, process_group=None):
+        self.bsi = bsi
+        self.model = bsi.model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.lr_schedule = lr_schedule  # callable step -> lr, or None for constant lr
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.step_count = 0
+        self.ema_beta, self.ema_after = ema_beta, ema_update_after_step
+        self._invalidate(self.model)
+        self.model._ws = None
+        self.ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
+        self.fp = FlatParams(self.model)
+        self.ema_fp = FlatParams(self.ema_model) if ema else None
+        dev = self.fp.flat.device
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sq_ws = torch.empty(N.lib().bsi_sqnorm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        depth = len(self.model.dit.blocks)
+        self.block_spans = [self.fp.span(f"dit.blocks.{i}.") for i in range(depth)]
+        self.head_span = (0, self.block_spans[0][0])                     # patch encoder
+        self.tail_span = (self.block_spans[-1][1], self.fp.flat.numel())  # decoder
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.events = None
+        if self.world > 1:
+            self.events = [torch.cuda.Event() for _ in range(depth)]
+            for e in self.events:
+                e.record()  # instantiate the underlying hipEvent_t
+            self._ev_arr = (C.c_void_p * depth)(*[C.c_void_p(e.cuda_event) for e in self.events])
+        self.last_grad_norm = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _invalidate(self, model):
+        model._pack = None
+        model._pack_t = None
+
+    def train_step(self, x: torch.Tensor, generator=None) -> torch.Tensor:
+        """One optimizer step on this rank's shard `x`; returns the (local) mean loss (detached)."""
+        lib = N.lib()
+        for p in self.model.parameters():
+            p.grad = None
+        self.model._last_flat_grad = None
+        if self.world > 1:
+            N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
+        loss = self.bsi.train_loss(x, generator).mean()
+        loss.backward()
+        flat_g = self.model._last_flat_grad
+        assert flat_g is not None, "the HIP training engine did not run (model is not a native DenoisingDiT?)"
+        if self.world > 1:
+            N.check(lib.bsi_dit_backward_set_events(None, 0))
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self.comm_stream):
+                # blocks finish last-to-first; each bucket starts when its event fires, overlapping the backward
+                for l in reversed(range(len(self.events))):
+                    self.comm_stream.wait_event(self.events[l])
+                    b, e = self.block_spans[l]
+                    dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                self.comm_stream.wait_stream(cur)  # encoder/decoder gradients are complete when the backward is
+                for b, e in (self.head_span, self.tail_span):
+                    if e > b:
+                        dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+            cur.wait_stream(self.comm_stream)
+        n = flat_g.numel()
+        lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
+        N.check(lib.bsi_grad_sqnorm(N.ptr(flat_g), n, N.ptr(self.sq), N.ptr(self.sq_ws), N.stream()))
+        w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
+        self.step_count += 1
+        N.check(lib.bsi_clip_adamw_ema(N.ptr(self.fp.flat), N.ptr(flat_g), N.ptr(self.m), N.ptr(self.v),
+                                       N.ptr(self.ema_fp.flat) if self.ema_fp else None, n, N.ptr(self.sq),
+                                       float(self.max_grad_norm or 0.0), 1.0 / self.world, lr, self.betas[0],
+                                       self.betas[1], self.eps, self.weight_decay, self.step_count, w, N.stream()))
+        self._invalidate(self.model)
+        if self.ema_model is not None:
+            self._invalidate(self.ema_model)
+        self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
+        return loss.detach()

@@ -101,6 +101,7 @@ class _DitTrainFn(torch.autograd.Function):
         N.check(lib.bsi_dit_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
                                      N.ptr(ctx.tape), N.ptr(ws), N.stream()))
         ctx.tape = None
+        model._last_flat_grad = flat  # the data-parallel trainer all-reduces and consumes this buffer directly
         kin = named["dit.patch_encoder.weight"].shape[1]
         views["dit.patch_encoder.weight"].copy_(enc_pad[:, :kin])
         return (None, None, None, None, None, None, *[views[n] for n in order])

@@ -309,6 +309,25 @@ int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*
 int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, const bsi_dit_weights_t* wT /*host*/,
                      const bsi_dit_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
                      void* workspace, bsi_stream_t stream);
+/* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
+ * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that
+ * block's gradient all-reduce on another stream while the backward continues.  Pass NULL to clear. */
+int bsi_dit_backward_set_events(void* const* events, int depth);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-step tail on flat fp32 buffers (bsi/tasks/bsi.py:187-198 + Lightning's clip/optimizer/EMA hooks):
+ * config/train.yaml:40 gradient_clip_val, config/task/optimizer/adamw.yaml (torch.optim.AdamW),
+ * bsi/tasks/ema_pytorch.py:316-434 (EMA.update -> copy while step <= update_after_step, else lerp_).
+ * ---------------------------------------------------------------------------------------- */
+size_t bsi_sqnorm_workspace_bytes(void);
+/* out_sq[0] = sum g[i]^2 (device scalar). */
+int bsi_grad_sqnorm(const float* g, size_t n, float* out_sq, void* workspace, bsi_stream_t stream);
+/* g' = grad_scale*g (e.g. 1/world after a sum all-reduce); clip: g' *= min(1, max_norm/(grad_scale*sqrt(sqnorm)+1e-6))
+ * (max_norm <= 0: off); AdamW step `step` (1-based) with decoupled weight decay; EMA: ema_weight in [0,1) -> ema +=
+ * ema_weight*(p-ema), ema_weight >= 1 -> ema = p (warm-up copy), ema_weight < 0 or ema NULL -> untouched. */
+int bsi_clip_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* sqnorm,
+                       float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, float ema_weight, bsi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class timing with HIP events on the launch stream.

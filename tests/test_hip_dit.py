@@ -244,3 +244,66 @@ def test_train_loss_gradients_vs_golden():
             # bf16 operands in every product of the backward chain: relative L2 error per tensor below 3e-2
             assert err < 3e-2, (name, err)
         assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)
+
+
+def test_fused_clip_adamw_ema_vs_golden():
+    """bsi_grad_sqnorm + bsi_clip_adamw_ema against torch.optim.AdamW + clip_grad_norm_ recorded from torch (G8)."""
+    import ctypes as C
+    from bsi_amd import _native as N
+    g = golden("g8_optimizer")
+    names = sorted(k[3:] for k in g if k.startswith("p0."))
+    flat_p = torch.cat([g["p0." + n].reshape(-1) for n in names]).to(DEV)
+    m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+    ema = torch.zeros_like(flat_p)
+    sq = torch.zeros(1, device=DEV)
+    ws = torch.empty(N.lib().bsi_sqnorm_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    for step in (1, 2, 3):
+        fg = torch.cat([g[f"g{step}.{n}"].reshape(-1) for n in names]).to(DEV)
+        N.check(N.lib().bsi_grad_sqnorm(N.ptr(fg), fg.numel(), N.ptr(sq), N.ptr(ws), N.stream()))
+        assert abs(float(sq.sqrt()) / float(g[f"norm{step}"]) - 1) < 1e-6
+        N.check(N.lib().bsi_clip_adamw_ema(N.ptr(flat_p), N.ptr(fg), N.ptr(m), N.ptr(v), N.ptr(ema), fg.numel(), N.ptr(sq),
+                                           1.0, 1.0, 5e-4, 0.9, 0.99, 1e-8, 1e-2, step, 1.0 if step < 3 else 0.25,
+                                           N.stream()))
+        ref = torch.cat([g[f"p{step}.{n}"].reshape(-1) for n in names])
+        assert rel_linf(flat_p, ref) < 1e-6, (step, rel_linf(flat_p, ref))
+        if step == 2:
+            ema2 = ema.clone()
+            assert torch.equal(ema, flat_p)                       # warm-up: copy
+    assert rel_linf(ema, ema2 + 0.25 * (flat_p - ema2)) < 1e-6    # lerp_(p, 1 - decay)
+
+
+def test_dp_trainer_single_gpu_step():
+    """DPTrainer.train_step on one GPU: parameters after one step equal clip+AdamW applied to the engine's own
+    gradients, EMA copies the weights during warm-up, and the bf16 shadows are refreshed for the next forward."""
+    from bsi_amd.dp import DPTrainer
+    g = golden("g4_train_dit")
+    model = make_model("dit_ff", True).train()
+    bsi = make_bsi(model)
+    p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = tr.train_step(g["x"].to(DEV))
+    assert abs(float(loss) / float(g["loss_mean"]) - 1) < 2e-3
+    gn = float(tr.last_grad_norm.sqrt())
+    assert abs(gn / float(g["grad_norm"]) - 1) < 1e-2
+    # reference update from the golden gradients (oracle restatement of clip + AdamW)
+    from oracle.bsi_oracle import clip_adamw_step
+    names = [n for n, _ in model.named_parameters()]
+    P = [p0[n].cpu().clone() for n in names]
+    G = [g["G." + n].clone() for n in names]
+    M = [torch.zeros_like(p) for p in P]
+    V = [torch.zeros_like(p) for p in P]
+    clip_adamw_step(P, G, M, V, 1, lr=5e-4, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=1e-2, max_norm=1.0)
+    for n, ref, gref in zip(names, P, G):
+        got = dict(model.named_parameters())[n].detach().cpu()
+        # the first Adam step moves every weight by ~lr*sign(g): compare the update where the reference gradient is
+        # not numerical noise (e.g. the key bias has an analytically zero gradient: softmax is shift invariant)
+        mask = gref.abs() > 1e-2 * gref.abs().max()
+        du, dr = (got - p0[n].cpu())[mask], (ref - p0[n].cpu())[mask]
+        assert float((du - dr).abs().mean() / dr.abs().mean()) < 5e-2, n
+    for (n, p), (_, e) in zip(model.named_parameters(), tr.ema_model.named_parameters()):
+        assert torch.equal(p.detach(), e.detach()), n
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss2 = tr.train_step(g["x"].to(DEV))
+    assert float(loss2) < float(loss) * 1.05 and torch.isfinite(loss2)
+    assert tr.step_count == 2

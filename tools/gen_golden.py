@@ -364,7 +364,19 @@ def g8_optimizer():
     rec["lerp_tgt"], rec["lerp_src"] = a.clone(), bq
     a.lerp_(bq, 1.0 - 0.9)
     rec["lerp_out_0.9"] = a
-    save("g8_optimizer", ema_steps=np.array(steps), ema_decays=np.array(decays), **rec)
+    # LR schedule of the reference (bsi/lr_scheduler.py:35-58) stepped once per optimizer step
+    spec = importlib.util.spec_from_file_location("ref_lr", os.path.join(ref_shim.REF_ROOT, "bsi", "lr_scheduler.py"))
+    lr_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr_mod)
+    prm = torch.nn.Parameter(torch.zeros(1))
+    o2 = torch.optim.AdamW([prm], lr=5e-4)
+    sch = lr_mod.WarmUpCosineAnnealing(o2, warmup_steps=10, max_steps=60, start_lr=1e-8, end_lr=5e-5)
+    lrs = []
+    for _ in range(60):
+        lrs.append(o2.param_groups[0]["lr"])
+        o2.step()
+        sch.step()
+    save("g8_optimizer", ema_steps=np.array(steps), ema_decays=np.array(decays), lr_schedule=np.array(lrs), **rec)
 
 
 def kat_reference_tests():

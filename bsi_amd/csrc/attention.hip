@@ -9,6 +9,7 @@
 // ds_read_b64_tr_b16.  Online softmax over chunks makes the kernel independent of the sequence length
 // (DiT: 256 tokens = one chunk; UNet centre attention: 1024 positions, dh 128).
 #include "common.h"
+#include "dit_ops.h"
 
 namespace {
 
@@ -26,7 +27,7 @@ __device__ __forceinline__ int v_block_swz(int row, int blk) {  // 32-B block in
 template <int DH, int KC>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
                                                             int heads, __bf16* __restrict__ out, int ld_out,
-                                                            float scale_log2e, float* __restrict__ lse) {
+                                                            float scale_log2e, float* __restrict__ lse, DropCfg dc) {
     constexpr int RB = DH * 2;        // bytes per K/V row
     constexpr int KS = DH / 32;       // k-steps of the QK^T contraction
     constexpr int KT = KC / 16;       // 16-key tiles per chunk
@@ -113,9 +114,14 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
+                    float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
+                    ps += pv;  // the normaliser uses the undropped probabilities
+                    if (dc.thr) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only
+                        const unsigned long long e = ((unsigned long long)bh * tokens + (q0 + 16 * jq + c16)) * tokens +
+                                                     (kc0 + 16 * kt + 4 * g + r);
+                        pv = drop_keep(dc, e) ? pv * dc.scale : 0.0f;
+                    }
                     s[kt][jq][r] = pv;
-                    ps += pv;
                 }
             l_run[jq] = l_run[jq] * alpha[jq] + ps;
 #pragma unroll
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
 
 template <int DH, int KC>
 int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, float* lse,
-                hipStream_t s) {
+                DropCfg dc, hipStream_t s) {
     const size_t lds = 2 * (size_t)KC * DH * 2;
     auto kern = attention_fwd_kernel<DH, KC>;
     static bool attr_set = false;
@@ -193,7 +199,7 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((tokens + 255) / 256, B * heads);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse, dc);
     BSI_CHECK_LAUNCH("bsi_attention_fwd");
     return BSI_OK;
 }
@@ -201,7 +207,7 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
 }  // namespace
 
 static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
-                              float* lse, bsi_stream_t stream) {
+                              float* lse, DropCfg dc, bsi_stream_t stream) {
     BSI_CHECK_ARG(qkv && out && B > 0 && heads > 0, "bsi_attention_fwd: bad args");
     BSI_CHECK_ARG(dh == 64 || dh == 128, "bsi_attention_fwd: head dim %d unsupported (64 or 128)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0, "bsi_attention_fwd: tokens=%d must be a multiple of 64", tokens);
@@ -211,20 +217,25 @@ static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, in
     __bf16* o = reinterpret_cast<__bf16*>(out);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dh == 64) {
-        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
-        return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
+        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
+        return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
     }
-    if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
-    return launch_attn<128, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, s);
+    if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
+    return launch_attn<128, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
 }
 
 extern "C" int bsi_attention_fwd(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
                                  int ld_out, bsi_stream_t stream) {
-    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, nullptr, stream);
+    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, nullptr, DropCfg{}, stream);
 }
 
 extern "C" int bsi_attention_fwd_lse(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out,
                                      int ld_out, float* lse, bsi_stream_t stream) {
     BSI_CHECK_ARG(lse, "bsi_attention_fwd_lse: null lse");
-    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, stream);
+    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, DropCfg{}, stream);
+}
+
+int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
+                            float* lse, DropCfg dc, bsi_stream_t stream) {
+    return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, dc, stream);
 }

@@ -11,6 +11,7 @@
 //           of dV^T = dO^T . P and dK^T = Q^T . dS.  No cross-wave reduction, no atomics, deterministic.
 // S is recomputed in both passes (7 matrix products instead of 5); attention is 4 % of the model's FLOPs.
 #include "common.h"
+#include "dit_ops.h"
 
 namespace {
 
@@ -24,7 +25,7 @@ __device__ __forceinline__ const char* row_chunk(const char* tile, int r, int c)
 __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv,
                                                             const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
                                                             int ld_o, const float* __restrict__ lse, int T, int heads,
-                                                            __bf16* __restrict__ dqkv, int ld_dqkv, float scale) {
+                                                            __bf16* __restrict__ dqkv, int ld_dqkv, float scale, DropCfg dc) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Ql = lds;
     char* Kl = Ql + T * RB;
@@ -121,7 +122,13 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], sl2, -lq[jq]));
-                        s[kt][jq][r] = scale * pv * (dp[kt][jq][r] - dq_delta[jq]);
+                        float dpv = dp[kt][jq][r];
+                        if (dc.thr) {
+                            const unsigned long long e = ((unsigned long long)bh * T + (r0 + 16 * jq + c16)) * T +
+                                                         (kc + 16 * kt + 4 * g + r);
+                            dpv = drop_keep(dc, e) ? dpv * dc.scale : 0.0f;
+                        }
+                        s[kt][jq][r] = scale * pv * (dpv - dq_delta[jq]);
                     }
             // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
@@ -200,8 +207,16 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[qt][jk][r], sl2, -lr[r]));
-                        s[qt][jk][r] = pv;                                   // P
-                        dp[qt][jk][r] = scale * pv * (dp[qt][jk][r] - dr[r]);  // dS
+                        float dpv = dp[qt][jk][r], pd = pv;
+                        if (dc.thr) {
+                            const unsigned long long e = ((unsigned long long)bh * T + (qc + 16 * qt + 4 * g + r)) * T +
+                                                         (r0 + 16 * jk + c16);
+                            const bool keep = drop_keep(dc, e);
+                            dpv = keep ? dpv * dc.scale : 0.0f;
+                            pd = keep ? pv * dc.scale : 0.0f;
+                        }
+                        s[qt][jk][r] = pd;                          // dropped P (for dV)
+                        dp[qt][jk][r] = scale * pv * (dpv - dr[r]);  // dS
                     }
             }
 #pragma unroll
@@ -252,9 +267,8 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
 
 }  // namespace
 
-extern "C" int bsi_attention_bwd(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o,
-                                 const float* lse, int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv,
-                                 bsi_stream_t stream) {
+int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
+                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream) {
     BSI_CHECK_ARG(qkv && out && dout && lse && dqkv && B > 0 && heads > 0, "bsi_attention_bwd: bad args");
     BSI_CHECK_ARG(dh == 64, "bsi_attention_bwd: head dim %d unsupported (64)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
@@ -269,7 +283,13 @@ extern "C" int bsi_attention_bwd(const void* qkv, int ld_qkv, const void* out, c
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(512), lds, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const __bf16*>(qkv), ld_qkv, reinterpret_cast<const __bf16*>(out),
                        reinterpret_cast<const __bf16*>(dout), ld_o, lse, tokens, heads, reinterpret_cast<__bf16*>(dqkv),
-                       ld_dqkv, 1.0f / sqrtf((float)dh));
+                       ld_dqkv, 1.0f / sqrtf((float)dh), dc);
     BSI_CHECK_LAUNCH("bsi_attention_bwd");
     return BSI_OK;
+}
+
+extern "C" int bsi_attention_bwd(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o,
+                                 const float* lse, int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv,
+                                 bsi_stream_t stream) {
+    return bsi_attention_bwd_drop(qkv, ld_qkv, out, dout, ld_o, lse, B, tokens, heads, dh, dqkv, ld_dqkv, DropCfg{}, stream);
 }

@@ -88,3 +88,30 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+
+// Counter-based dropout (training only): element `idx` of site `seed` is kept iff hash(seed, idx) >= p * 2^32.
+// The same function is evaluated in the forward and the backward kernels, so no mask is stored.
+struct DropCfg {
+    unsigned thr;      // p * 2^32 (0 = dropout off)
+    unsigned s0, s1;   // seed words
+    float scale;       // 1 / (1 - p)
+};
+__host__ __device__ __forceinline__ unsigned bsi_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned long long idx) {
+    const unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
+    return bsi_mix32(lo ^ bsi_mix32(hi + c.s0) ^ c.s1) >= c.thr;
+}
+inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
+    DropCfg c{};
+    if (p <= 0.f) return c;
+    const unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
+    double t = (double)p * 4294967296.0;
+    c.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    c.s0 = bsi_mix32((unsigned)s);
+    c.s1 = bsi_mix32((unsigned)(s >> 32) ^ 0x85ebca6bu);
+    c.scale = 1.0f / (1.0f - p);
+    return c;
+}

@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "dit_ops.h"
 
 namespace {
 
@@ -98,7 +99,7 @@ template <int VPL>
 __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* __restrict__ x,
                                   const float* __restrict__ scale, int mod_stride, float* __restrict__ dshift,
                                   float* __restrict__ dscale, int dmod_stride, float* __restrict__ dX, int M, int d,
-                                  int tokens, float eps) {
+                                  int tokens, float eps, DropCfg dc) {
     __shared__ float red[3][2][1024 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * RPB;
@@ -125,6 +126,11 @@ __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* _
             v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
             dv[i] = (c < d4) ? bf16x4_to_f32(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d)[c])
                              : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dc.thr && c < d4) {  // gradient through the forward's dropout mask
+                const unsigned long long e0 = (unsigned long long)row * d + (unsigned long long)c * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[i][k] = drop_keep(dc, e0 + k) ? dv[i][k] * dc.scale : 0.0f;
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         const float mean = wave_sum(s) / (float)d;
@@ -372,19 +378,25 @@ extern "C" int bsi_gate_bwd(const float* dX, const void* delta, float* x, const 
     return BSI_OK;
 }
 
-extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
-                              float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps,
-                              bsi_stream_t stream) {
+int bsi_ln_mod_bwd_drop(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
+                        float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps, DropCfg dc,
+                        bsi_stream_t stream) {
     BSI_CHECK_ARG(dxn && x && scale && dshift && dscale && dX, "bsi_ln_mod_bwd: null pointer");
     BSI_CHECK_ARG(M > 0 && d % 4 == 0 && d <= 2048 && tokens % RPB == 0 && M % tokens == 0,
                   "bsi_ln_mod_bwd: M=%d d=%d tokens=%d", M, d, tokens);
     dim3 grid(M / RPB);
     const __bf16* g = reinterpret_cast<const __bf16*>(dxn);
-    if (d <= 256) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
-    else if (d <= 1024) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
-    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps);
+    if (d <= 256) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps, dc);
+    else if (d <= 1024) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps, dc);
+    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, grid, dim3(TPB), 0, S(stream), g, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps, dc);
     BSI_CHECK_LAUNCH("bsi_ln_mod_bwd");
     return BSI_OK;
+}
+
+extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
+                              float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps,
+                              bsi_stream_t stream) {
+    return bsi_ln_mod_bwd_drop(dxn, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps, DropCfg{}, stream);
 }
 
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,

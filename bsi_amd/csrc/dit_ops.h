@@ -8,3 +8,15 @@ int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln
                          const float* dec_w, const float* dec_b, int C, int H, int W, int ps, const float* mu,
                          const float* c_skip, const float* c_out, int coef_stride, const void* delta, const float* gate,
                          int gate_rows, int gate_stride, float* out, hipStream_t s);
+
+#include "common.h"
+int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
+                               const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
+                               const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream);
+int bsi_ln_mod_bwd_drop(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
+                        float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps, DropCfg dc,
+                        bsi_stream_t stream);
+int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
+                            float* lse, DropCfg dc, bsi_stream_t stream);
+int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
+                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream);

@@ -58,7 +58,7 @@ template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
 __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
                                    const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                   const __bf16* delta, const float* __restrict__ gate, __bf16* out) {
+                                   const __bf16* delta, const float* __restrict__ gate, __bf16* out, DropCfg dc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -117,6 +117,11 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
                 const f32x4 b = reinterpret_cast<const f32x4*>(ln_b)[c];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) y[k] = __fmaf_rn(y[k], a[k], b[k]);
+            }
+            if (dc.thr) {  // nn.Dropout in front of the MLP (dit.py:70,101), training only
+                const unsigned long long e0 = (unsigned long long)row * d + (unsigned long long)c * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = drop_keep(dc, e0 + k) ? y[k] * dc.scale : 0.0f;
             }
             u32x2 w;
             w[0] = pack_bf16x2(y[0], y[1]);
@@ -326,9 +331,9 @@ extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, c
     return BSI_OK;
 }
 
-extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, const float* gate,
-                                     const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
-                                     const float* ln_w, const float* ln_b, void* out_bf16, bsi_stream_t stream) {
+int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
+                               const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
+                               const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream) {
     BSI_CHECK_ARG(x && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_resid_ln_modulate: bad args M=%d d=%d", M, d);
     BSI_CHECK_ARG(out_bf16 || delta, "bsi_resid_ln_modulate: nothing to do");
     BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_resid_ln_modulate: shift and scale go together");
@@ -342,14 +347,36 @@ extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const vo
     const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
     else if (d <= 1024)
         hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
     else
         hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
     BSI_CHECK_LAUNCH("bsi_resid_ln_modulate");
+    return BSI_OK;
+}
+
+extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, const float* gate,
+                                     const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
+                                     const float* ln_w, const float* ln_b, void* out_bf16, bsi_stream_t stream) {
+    return bsi_resid_ln_modulate_drop(x, M, d, eps, delta, gate, shift, scale, mod_rows, mod_stride, tokens, ln_w, ln_b,
+                                      out_bf16, DropCfg{}, stream);
+}
+
+__global__ void dropout_mask_kernel(DropCfg dc, unsigned long long idx0, size_t n, uint8_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = drop_keep(dc, idx0 + i) ? 1 : 0;
+}
+
+extern "C" int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned long long idx0, size_t n,
+                                uint8_t* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f, "bsi_dropout_mask: bad args");
+    size_t g = (n + TPB - 1) / TPB;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)g), dim3(TPB), 0, S(stream), make_drop(p, seed, site), idx0, n, out);
+    BSI_CHECK_LAUNCH("bsi_dropout_mask");
     return BSI_OK;
 }
 

@@ -159,7 +159,8 @@ extern "C" int bsi_silu_bf16(const float* pre, size_t n, void* out, bsi_stream_t
 
 extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w, int B, const float* mu,
                                      const float* t, const float* c_in, const float* c_skip, const float* c_out,
-                                     float* out, void* tape_mem, bsi_stream_t stream) {
+                                     float* out, void* tape_mem, float dropout_p, unsigned long long seed,
+                                     bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && mu && t && out && tape_mem && B > 0, "bsi_dit_train_forward: bad args");
     BSI_CHECK_ARG((c_in == nullptr) == (c_skip == nullptr) && (c_in == nullptr) == (c_out == nullptr),
                   "bsi_dit_train_forward: c_in/c_skip/c_out must be given together");
@@ -194,10 +195,11 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, B, mod_stride, d.tokens, nullptr,
                                   nullptr, bt.xn1, stream));
         TRY(gemm(bt.xn1, dim, bw.qkv_w, dim, bw.qkv_b, bt.qkv, 3 * dim, M, 3 * dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_attention_fwd_lse(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse, stream));
+        TRY(bsi_attention_fwd_train(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse,
+                                    make_drop(dropout_p, seed, 2 * l), stream));
         TRY(gemm(bt.ao, dim, bw.out_w, dim, bw.out_b, bt.d1, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride, d.tokens,
-                                  nullptr, nullptr, bt.xn2, stream));
+        TRY(bsi_resid_ln_modulate_drop(tp.x, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride,
+                                       d.tokens, nullptr, nullptr, bt.xn2, make_drop(dropout_p, seed, 2 * l + 1), stream));
         TRY(gemm(bt.xn2, dim, bw.fc1_w, dim, bw.fc1_b, bt.h, 4 * dim, M, 4 * dim, dim, BSI_EPI_BIAS_GELU_DUAL, nullptr, bt.hp, nullptr, 0, stream));
         TRY(gemm(bt.h, 4 * dim, bw.fc2_w, 4 * dim, bw.fc2_b, bt.d2, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         pend_delta = bt.d2;
@@ -212,7 +214,7 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
 
 extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w, const bsi_dit_weights_t* wT,
                                 const bsi_dit_grads* g, int B, const float* g_out, const float* c_out, void* tape_mem,
-                                void* workspace, bsi_stream_t stream) {
+                                void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && wT && wT->blocks && g && g->blocks && g_out && tape_mem && workspace && B > 0,
                   "bsi_dit_backward: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -252,14 +254,15 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_gemm_tn_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, 0, ws.tn, stream));
         TRY(bsi_colsum_bf16(ws.dbig, 4 * dim, M, 4 * dim, bg.fc1_b, 0, ws.cs, stream));
-        TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX, M, dim,
-                           d.tokens, 1e-5f, stream));
+        TRY(bsi_ln_mod_bwd_drop(ws.dsmall, tp.x, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX, M,
+                                dim, d.tokens, 1e-5f, make_drop(dropout_p, seed, 2 * l + 1), stream));
         // ---- attention branch: x1 = x0 + g_a * d1
         TRY(bsi_gate_bwd(ws.dX, bt.d1, tp.x, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
         TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
         TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, bg.out_b, 0, ws.cs, stream));
-        TRY(bsi_attention_bwd(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim, stream));
+        TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
+                                   make_drop(dropout_p, seed, 2 * l), stream));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
         TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
         TRY(bsi_colsum_bf16(ws.dbig, 3 * dim, M, 3 * dim, bg.qkv_b, 0, ws.cs, stream));

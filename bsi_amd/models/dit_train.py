@@ -53,7 +53,7 @@ def transposed_pack(model):
 
 class _DitTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, mu, t, c_in, c_skip, c_out, *params):
+    def forward(ctx, model, drop_p, seed, mu, t, c_in, c_skip, c_out, *params):
         lib = N.lib()
         cfg, w, _, _ = model.native_pack()
         mu = mu.contiguous()
@@ -62,8 +62,9 @@ class _DitTrainFn(torch.autograd.Function):
         out = torch.empty_like(mu)
         tape = torch.empty(lib.bsi_dit_tape_bytes(C.byref(cfg), B), dtype=torch.uint8, device=mu.device)
         N.check(lib.bsi_dit_train_forward(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(t), N.ptr(c_in), N.ptr(c_skip),
-                                          N.ptr(c_out), N.ptr(out), N.ptr(tape), N.stream()))
+                                          N.ptr(c_out), N.ptr(out), N.ptr(tape), drop_p, seed, N.stream()))
         ctx.model, ctx.tape, ctx.c_out, ctx.B = model, tape, c_out, B
+        ctx.drop = (drop_p, seed)
         return out
 
     @staticmethod
@@ -99,22 +100,27 @@ class _DitTrainFn(torch.autograd.Function):
         g.blocks = C.cast(blocks, C.POINTER(N.DitBlockGrads))
         ws = torch.empty(lib.bsi_dit_backward_workspace_bytes(C.byref(cfg), B), dtype=torch.uint8, device=dev)
         N.check(lib.bsi_dit_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
-                                     N.ptr(ctx.tape), N.ptr(ws), N.stream()))
+                                     N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
         ctx.tape = None
         model._last_flat_grad = flat  # the data-parallel trainer all-reduces and consumes this buffer directly
         kin = named["dit.patch_encoder.weight"].shape[1]
         views["dit.patch_encoder.weight"].copy_(enc_pad[:, :kin])
-        return (None, None, None, None, None, None, *[views[n] for n in order])
+        return (None, None, None, None, None, None, None, None, *[views[n] for n in order])
 
 
 def dit_forward_train(model, mu: Tensor, t: Tensor, c_in=None, c_skip=None, c_out=None) -> Tensor:
-    """x_hat = c_skip*mu + c_out*f(c_in*mu, t) (or f(mu, t)) with gradients w.r.t. the model parameters."""
-    if any(isinstance(m, torch.nn.Dropout) and m.p > 0 and m.training for m in model.modules()) or any(
-            getattr(m, "dropout", 0.0) and m.training for m in model.modules() if hasattr(m, "to_qkv")):
-        raise NotImplementedError("bsi_amd.DenoisingDiT: dropout > 0 in training mode is not implemented in the HIP "
-                                  "training engine yet; construct the model with dropout=None or call .eval()")
-    params = [p for _, p in model.named_parameters()]
-    return _DitTrainFn.apply(model, mu, t, c_in, c_skip, c_out, *params)
+    """x_hat = c_skip*mu + c_out*f(c_in*mu, t) (or f(mu, t)) with gradients w.r.t. the model parameters.
+    In `train()` mode the blocks' dropout (attention weights and MLP input, dit.py:43-44,70,101) is applied with a
+    counter-based mask whose seed derives from `torch.initial_seed()` and a per-model call counter (the reference
+    draws these masks from the device's global generator, which cannot be reproduced bit for bit anyway)."""
+    blk = model.dit.blocks[0]
+    p = float(blk.attn.dropout) if model.training else 0.0
+    seed = 0
+    if p > 0.0:
+        model._drop_calls = getattr(model, "_drop_calls", 0) + 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + model._drop_calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+    params = [q for _, q in model.named_parameters()]
+    return _DitTrainFn.apply(model, p, seed, mu, t, c_in, c_skip, c_out, *params)
 
 
 def dit_forward_autograd(model, mu: Tensor, t: Tensor) -> Tensor:

@@ -303,12 +303,18 @@ size_t bsi_dit_backward_workspace_bytes(const bsi_dit_config* cfg, int B);
  * records the activations the backward needs in `tape` (bsi_dit_tape_bytes). */
 int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, int B, const float* mu,
                           const float* t, const float* c_in, const float* c_skip, const float* c_out, float* out,
-                          void* tape, bsi_stream_t stream);
+                          void* tape, float dropout_p, unsigned long long seed, bsi_stream_t stream);
 /* Gradients of every parameter given g_out = dL/d(out) [B,C,H,W].  Overwrites the buffers of `g`; consumes the tape
  * (the residual stream in it is rewound in place). */
 int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, const bsi_dit_weights_t* wT /*host*/,
                      const bsi_dit_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
-                     void* workspace, bsi_stream_t stream);
+                     void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream);
+/* Dropout of the DiT blocks in training (dit.py:43-44 attention-weight dropout, dit.py:70,101 nn.Dropout before the
+ * MLP) is a counter-based mask: element idx of site s is kept iff hash(seed, s, idx) >= p*2^32, re-evaluated in the
+ * backward kernels (nothing stored).  Sites: 2*block (attention, idx = ((b*heads+h)*T + q)*T + key) and 2*block+1
+ * (MLP input, idx = row*dim + col).  bsi_dropout_mask exposes the mask (uint8 keep flags) for tests. */
+int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned long long idx0, size_t n, uint8_t* out,
+                     bsi_stream_t stream);
 /* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
  * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that
  * block's gradient all-reduce on another stream while the backward continues.  Pass NULL to clear. */

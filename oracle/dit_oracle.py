@@ -95,7 +95,7 @@ def linear(x, w, b, md=None):
     return _rt(x, md) @ _rt(w, md).t() + b
 
 
-def attention(x, w_qkv, b_qkv, w_out, b_out, heads, md=None):
+def attention(x, w_qkv, b_qkv, w_out, b_out, heads, md=None, drop=None):
     """dit.py:36-47: qkv split '(qkv h c)', softmax(q k^T / sqrt(c)) v, merge '(h c)'."""
     B, N, d = x.shape
     c = d // heads
@@ -103,12 +103,14 @@ def attention(x, w_qkv, b_qkv, w_out, b_out, heads, md=None):
     q, k, v = _rt(qkv[0], md), _rt(qkv[1], md), _rt(qkv[2], md)
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(c))
     p = torch.softmax(s, dim=-1)
+    if drop is not None:  # F.scaled_dot_product_attention(dropout_p): keep-mask * 1/(1-p) on the weights
+        p = p * drop
     o = _rt(p, md) @ v
     o = o.permute(0, 2, 1, 3).reshape(B, N, d)
     return linear(_rt(o, md), w_out, b_out, md)
 
 
-def dit_block(x, c, W, pre, heads, md=None):
+def dit_block(x, c, W, pre, heads, md=None, drop_attn=None, drop_mlp=None):
     """dit.py:87-103."""
     h = linear(c, W[pre + "adaLN_modulation.0.weight"], W[pre + "adaLN_modulation.0.bias"], md)
     mod = linear(silu(h), W[pre + "adaLN_modulation.2.weight"], W[pre + "adaLN_modulation.2.bias"], md)
@@ -117,14 +119,16 @@ def dit_block(x, c, W, pre, heads, md=None):
     # with md set, branch outputs are rounded once more: the HIP engine hands them to the residual update as bf16
     x = torch.addcmul(x, g_a[:, None], _rt(attention(
         a_in, W[pre + "attn.to_qkv.weight"], W[pre + "attn.to_qkv.bias"],
-        W[pre + "attn.to_out.weight"], W[pre + "attn.to_out.bias"], heads, md), md))
+        W[pre + "attn.to_out.weight"], W[pre + "attn.to_out.bias"], heads, md, drop_attn), md))
     m_in = torch.addcmul(sh_m[:, None], sc_m[:, None] + 1, layer_norm(x))
+    if drop_mlp is not None:  # nn.Dropout in front of the MLP (dit.py:70,101)
+        m_in = m_in * drop_mlp
     hdn = gelu_tanh(linear(m_in, W[pre + "mlp.0.weight"], W[pre + "mlp.0.bias"], md))
     x = torch.addcmul(x, g_m[:, None], _rt(linear(_rt(hdn, md), W[pre + "mlp.2.weight"], W[pre + "mlp.2.bias"], md), md))
     return x
 
 
-def dit_forward(W, mu, t, *, patch_size, dim, depth, heads, ff=None, md=None, return_tokens=False):
+def dit_forward(W, mu, t, *, patch_size, dim, depth, heads, ff=None, md=None, return_tokens=False, drop=None):
     """DenoisingDiT.forward (dit.py:225-233) + DiT.forward (dit.py:174-181).
     ``ff``: None or (n_min, n_max)."""
     B, C, H, Wd = mu.shape
@@ -136,7 +140,8 @@ def dit_forward(W, mu, t, *, patch_size, dim, depth, heads, ff=None, md=None, re
     pos = patch_pos_embedding(dim, H, Wd, patch_size).to(mu.dtype)
     x = linear(patchify(x, patch_size), W["dit.patch_encoder.weight"], W["dit.patch_encoder.bias"], md) + pos
     for i in range(depth):
-        x = dit_block(x, c, W, f"dit.blocks.{i}.", heads, md)
+        x = dit_block(x, c, W, f"dit.blocks.{i}.", heads, md,
+                      None if drop is None else drop.get(("attn", i)), None if drop is None else drop.get(("mlp", i)))
     if return_tokens:
         return x
     y = layer_norm(x, 1e-5, W["dit.patch_decoder.0.weight"], W["dit.patch_decoder.0.bias"])

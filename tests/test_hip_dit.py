@@ -307,3 +307,46 @@ def test_dp_trainer_single_gpu_step():
         loss2 = tr.train_step(g["x"].to(DEV))
     assert float(loss2) < float(loss) * 1.05 and torch.isfinite(loss2)
     assert tr.step_count == 2
+
+
+def test_training_dropout_matches_oracle_with_same_masks():
+    """Dropout sites of the training engine (attention weights, MLP input): the counter-based masks are exported with
+    bsi_dropout_mask and applied in the CPU oracle; loss and gradients must agree as in the dropout-free case."""
+    from bsi_amd import _native as N
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    p, B, T, d, heads, depth = 0.3, 4, 64, 128, 2, 2
+    g = golden("g4_train_dit")
+    W = weights("dit_ff")
+    model = DenoisingDiT((3, 16, 16), 2, d, depth, heads, dropout=p, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    model.load_state_dict(W)
+    model = model.to(DEV).train()
+    bsi = make_bsi(model)
+    torch.manual_seed(123)
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = bsi.train_loss(g["x"].to(DEV))
+    loss.mean().backward()
+    seed = (torch.initial_seed() * 0x9E3779B1 + model._drop_calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+    drop = {}
+    for l in range(depth):
+        ma = torch.empty(B * heads * T * T, dtype=torch.uint8, device=DEV)
+        mm = torch.empty(B * T * d, dtype=torch.uint8, device=DEV)
+        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l, 0, ma.numel(), N.ptr(ma), N.stream()))
+        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l + 1, 0, mm.numel(), N.ptr(mm), N.stream()))
+        drop[("attn", l)] = ma.cpu().float().reshape(B, heads, T, T) / (1 - p)
+        drop[("mlp", l)] = mm.cpu().float().reshape(B, T, d) / (1 - p)
+        assert abs(float(ma.float().mean()) - (1 - p)) < 0.01 and abs(float(mm.float().mean()) - (1 - p)) < 0.01
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    f = lambda a, b: do.dit_forward(Wr, a, b, patch_size=2, dim=d, depth=depth, heads=heads, ff=(6, 8), drop=drop)  # noqa: E731
+    o = bo.BSIOracle(f, data_shape=(3, 16, 16), k=16)
+    ref = o.train_loss(g["x"], g["offset"], g["perm"], g["eps"])
+    assert max_rel(loss.detach(), ref.detach()) < 2e-2, max_rel(loss.detach(), ref.detach())
+    ref.mean().backward()
+    for name, q in model.named_parameters():
+        r = Wr[name].grad
+        err = float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
+        assert err < 4e-2, (name, err)
+    # eval() switches dropout off: same loss as the dropout-free golden
+    model.eval()
+    with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        assert max_rel(bsi.train_loss(g["x"].to(DEV)).cpu(), g["loss"]) < 1e-2

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--k", type=int, default=128, help="sampling steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")
+    ap.add_argument("--train-steps", type=int, default=2, help="timed optimizer steps of the train benchmark (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=512, help="GLOBAL batch of the train benchmark (split over ranks)")
     return ap.parse_args()
 
 
@@ -99,6 +101,41 @@ def cpu_baseline(k):
                       f"steps in {dt:.1f} s, extrapolated to k+1={k + 1} evaluations per image"}
 
 
+def train_bench(a, bsi, model, dev, world, rank, barrier):
+    """Second half of the BASELINE metric: optimizer steps/s of the ImageNet32 DiT-L/2 recipe
+    (config/experiment/imagenet32.yaml: global batch 512, AdamW lr 5e-4 betas (0.9, 0.99) wd 1e-2, dropout 0.05,
+    clip 1.0, EMA, warm-up + cosine LR) — BSI.train_loss forward + hand-written backward + gradient all-reduce over
+    RCCL + fused clip/AdamW/EMA.  The global batch is split per rank as bsi/data/h5image.py:312 (strong scaling)."""
+    from bsi_amd.dp import DPTrainer, split_batch, warmup_cosine_lr
+
+    nb = split_batch(a.train_batch, world, rank)
+    model.train()
+    sched = lambda s: warmup_cosine_lr(s, base_lr=5e-4, warmup_steps=1000, max_steps=1000000, start_lr=1e-8, end_lr=5e-5)  # noqa: E731
+    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, lr_schedule=sched)
+    g = torch.Generator(dev).manual_seed(99 + rank)
+    u = torch.rand((nb, 3, 32, 32), device=dev, generator=g)
+    x = (torch.round(255 * u) / 255) * 2 - 1           # synthetic 8-bit images in [-1, 1]
+    loss = tr.train_step(x, g)                          # warm-up (also builds the transposed weight shadows)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.train_steps):
+        loss = tr.train_step(x, g)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tm.item())
+    assert torch.isfinite(loss)
+    model.eval()
+    steps_per_s = a.train_steps / dt
+    return {"metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+all-reduce+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
+            "value": steps_per_s, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.train_steps, "global_batch": a.train_batch,
+            "per_gpu_batch": nb, "images_per_s": steps_per_s * a.train_batch, "scaling": "strong",
+            "model_tflops_per_gpu": steps_per_s * a.train_batch * 3 * FWD_GFLOP_PER_IMG / 1e3 / world,
+            "loss": float(loss)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +185,10 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    train = None
+    if a.train_steps > 0:
+        train = train_bench(a, bsi, model, dev, world, rank, barrier)
+
     if a.breakdown and rank == 0:
         names = list(N.PROF_CLASSES)
         N.prof_enable(names)
@@ -182,6 +223,8 @@ def main():
                          "kernel": "gemm_bf16_kernel<8,2,4,BIAS_GELU_BF16> (fc1)",
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }
+        if train is not None:
+            line["train"] = train
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.k)
         print(json.dumps(line))

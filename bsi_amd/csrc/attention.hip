@@ -24,7 +24,7 @@ __device__ __forceinline__ int v_block_swz(int row, int blk) {  // 32-B block in
     else return blk ^ (row & 7);
 }
 
-template <int DH, int KC>
+template <int DH, int KC, bool DROP>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
                                                             int heads, __bf16* __restrict__ out, int ld_out,
                                                             float scale_log2e, float* __restrict__ lse, DropCfg dc) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
                 for (int r = 0; r < 4; ++r) {
                     float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
                     ps += pv;  // the normaliser uses the undropped probabilities
-                    if (dc.thr) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only
+                    if constexpr (DROP) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only
                         const unsigned long long e = ((unsigned long long)bh * tokens + (q0 + 16 * jq + c16)) * tokens +
                                                      (kc0 + 16 * kt + 4 * g + r);
                         pv = drop_keep(dc, e) ? pv * dc.scale : 0.0f;
@@ -191,15 +191,18 @@ template <int DH, int KC>
 int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, float* lse,
                 DropCfg dc, hipStream_t s) {
     const size_t lds = 2 * (size_t)KC * DH * 2;
-    auto kern = attention_fwd_kernel<DH, KC>;
+    auto kern = attention_fwd_kernel<DH, KC, false>;
+    auto kern_d = attention_fwd_kernel<DH, KC, true>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((tokens + 255) / 256, B * heads);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse, dc);
+    if (dc.thr) hipLaunchKernelGGL(kern_d, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse, dc);
+    else hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse, dc);
     BSI_CHECK_LAUNCH("bsi_attention_fwd");
     return BSI_OK;
 }
@@ -217,7 +220,8 @@ static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, in
     __bf16* o = reinterpret_cast<__bf16*>(out);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dh == 64) {
-        if (tokens % 256 == 0) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
+        // with dropout the 256-key variant exceeds the register file: use 64-key chunks (online softmax)
+        if (tokens % 256 == 0 && !dc.thr) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
         return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
     }
     if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);

@@ -198,23 +198,50 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, size_t slab
 }
 
 // column sums of a bf16 [M, ld] matrix (bias gradients): out[n] (+)= sum_m Y[m, n].
-// grid.x covers columns in chunks of 256 (4 per thread... one thread = 1 column pair), grid.y splits rows; fp32 atomics
-// are avoided: each (row-split, column) partial is written to a slab and reduced by reduce_slabs_kernel.
-__global__ void colsum_kernel(const __bf16* __restrict__ Y, int M, int Ncols, int ld, int rows_per_split,
-                              float* __restrict__ slabs, size_t slab_stride) {
-    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;  // pair of columns
-    if (c2 * 2 >= Ncols) return;
+// A block owns a 256-column strip and a row range: 32 threads x 16 B cover the strip, 8 row lanes run in parallel and
+// each walks its rows with 4 independent 16-B loads in flight; partial sums go to a slab per row split and are summed
+// by reduce_slabs_kernel (deterministic, no atomics).  HBM-bound: one pass over Y.
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ Y, int M, int Ncols, int ld,
+                                                     int rows_per_split, float* __restrict__ slabs, size_t slab_stride) {
+    __shared__ float red[8][256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + tx * 8;
     const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
-    float a0 = 0.f, a1 = 0.f;
-    const unsigned* base = reinterpret_cast<const unsigned*>(Y) + c2;
-    for (int m = m0; m < m1; ++m) {
-        const unsigned w = base[(size_t)m * (ld / 2)];
-        a0 += __uint_as_float(w << 16);
-        a1 += __uint_as_float(w & 0xffff0000u);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < Ncols) {
+        const __bf16* base = Y + c0;
+        int m = m0 + ty;
+        for (; m + 24 < m1; m += 32) {
+            u32x4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)(m + 8 * u) * ld));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[2 * e] += __uint_as_float(w[u][e] << 16);
+                    a[2 * e + 1] += __uint_as_float(w[u][e] & 0xffff0000u);
+                }
+        }
+        for (; m < m1; m += 8) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(base + (size_t)m * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[2 * e] += __uint_as_float(w[e] << 16);
+                a[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
     }
-    float* o = slabs + (size_t)blockIdx.y * slab_stride + c2 * 2;
-    o[0] = a0;
-    o[1] = a1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = a[e];
+    __syncthreads();
+    const int c = threadIdx.x;  // one column per thread
+    if (blockIdx.x * 256 + c < Ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][c];
+        slabs[(size_t)blockIdx.y * slab_stride + blockIdx.x * 256 + c] = t;
+    }
 }
 
 }  // namespace
@@ -282,14 +309,14 @@ extern "C" size_t bsi_colsum_workspace_bytes(int N) { return (size_t)64 * (size_
 
 extern "C" int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,
                                bsi_stream_t stream) {
-    BSI_CHECK_ARG(Y && out && workspace && M > 0 && N > 0 && N % 4 == 0 && ld % 2 == 0 && ld >= N, "bsi_colsum_bf16: bad args");
+    BSI_CHECK_ARG(Y && out && workspace && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && ld >= N, "bsi_colsum_bf16: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int splits = M / 256;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
     const int per = (M + splits - 1) / splits;
     splits = (M + per - 1) / per;
-    dim3 grid((N / 2 + 255) / 256, splits);
+    dim3 grid((N + 255) / 256, splits);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(Y), M, N, ld, per,
                        reinterpret_cast<float*>(workspace), (size_t)N);
     BSI_CHECK_LAUNCH("bsi_colsum_bf16");

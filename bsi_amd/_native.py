@@ -27,6 +27,16 @@ class GemmArgs(C.Structure):
                 ("tokens", C.c_int), ("pos", C.c_void_p), ("aux", C.c_void_p), ("out2", C.c_void_p)]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("zeros", C.c_void_p),
+                ("out", C.c_void_p), ("film", C.c_void_p), ("resid", C.c_void_p), ("film_rows", C.c_int),
+                ("film_stride", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
+                ("Cin2", C.c_int), ("Cout", C.c_int), ("taps", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int)]
+
+
+CONV_BIAS_BF16, CONV_FILM_SILU_BF16, CONV_BIAS_RESID_F32 = range(3)
+
+
 class DitConfig(C.Structure):
     _fields_ = [("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("patch", C.c_int),
                 ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
@@ -117,6 +127,10 @@ _PROTOS = {
     "bsi_sqnorm_workspace_bytes": (_sz, []),
     "bsi_grad_sqnorm": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "bsi_clip_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "bsi_conv_nhwc_bf16": (_i, [C.POINTER(ConvArgs), _vp]),
+    "bsi_conv_weight_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "bsi_unet_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),

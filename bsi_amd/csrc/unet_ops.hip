@@ -1,0 +1,163 @@
+// Memory-bound kernels of the VDM-UNet path (bsi/models/vdm_unet.py, bsi/nn/residual_block.py of the reference):
+// GroupNorm(32) (+ SiLU) producer for the convolutions' A operand, the 1x1 decode convolution fused with the
+// preconditioning epilogue, NCHW <-> NHWC helpers.
+#include <math.h>
+
+#include "common.h"
+#include "dit_ops.h"
+
+namespace {
+
+// GroupNorm over one image (H*W pixels x C channels, NHWC fp32; optionally the channel-concatenation of two tensors,
+// simplified_unet.py:45-46 `cat((x, x_skip), dim=-3)`), 32 groups, affine, optional SiLU  ->  bf16 NHWC.
+// One workgroup of 1024 threads per image.  Thread t owns the float4 channel chunk (t % CH4) of pixels t / CH4 + k*PPI:
+// every load instruction of a wave covers whole pixels (coalesced), and a thread's chunk always belongs to one group.
+// Two passes over the image (statistics, then normalise); `raw` optionally receives the un-normalised bf16 copy
+// (A operand of the 1x1 skip convolution, residual_block.py:40).
+__global__ __launch_bounds__(1024) void groupnorm_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
+                                                         int C2, int HW, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int silu,
+                                                         __bf16* __restrict__ out, __bf16* __restrict__ raw) {
+    __shared__ float red_s[2048], red_q[2048];  // [pixel row][2-channel sub-chunk]: PPI * CH4 * 2 = 2048
+    __shared__ float mean_s[32], rstd_s[32];
+    const int C = C1 + C2, CH4 = C / 4;           // float4 chunks per pixel (16, 32 or 64)
+    const int cpg = C / 32;                       // channels per group (2, 4 or 8)
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ch = t % CH4, prow = t / CH4, PPI = 1024 / CH4;  // pixel rows handled in parallel
+    const int c0 = ch * 4;
+    const bool second = c0 >= C1;
+    const float* src = second ? x2 + (size_t)b * HW * C2 + (c0 - C1) : x1 + (size_t)b * HW * C1 + c0;
+    const int sstride = second ? C2 : C1;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // channel pairs (c0, c0+1) and (c0+2, c0+3)
+    for (int p = prow; p < HW; p += PPI) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+        s0 += v[0] + v[1];
+        q0 += v[0] * v[0] + v[1] * v[1];
+        s1 += v[2] + v[3];
+        q1 += v[2] * v[2] + v[3] * v[3];
+    }
+    const int NS = CH4 * 2;  // sub-chunks per pixel
+    red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+    red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+    __syncthreads();
+    if (t < 32) {  // group t: sub-chunks [t*cpg/2, (t+1)*cpg/2)
+        const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < PPI; ++r)
+            for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+        const float n = (float)HW * cpg;
+        const float mean = ts / n;
+        const float var = fmaxf(tq / n - mean * mean, 0.f);
+        mean_s[t] = mean;
+        rstd_s[t] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(c0 + k) / cpg]; rstd[k] = rstd_s[(c0 + k) / cpg]; }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    for (int p = prow; p < HW; p += PPI) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+        f32x4 y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y[k] = __fmaf_rn((v[k] - mean[k]) * rstd[k], ga[k], be[k]);
+            if (silu) y[k] = y[k] / (1.0f + __expf(-y[k]));
+        }
+        const size_t o = ((size_t)b * HW + p) * C + c0;
+        u32x2 w;
+        w[0] = pack_bf16x2(y[0], y[1]);
+        w[1] = pack_bf16x2(y[2], y[3]);
+        *reinterpret_cast<u32x2*>(out + o) = w;
+        if (raw) {
+            u32x2 r;
+            r[0] = pack_bf16x2(v[0], v[1]);
+            r[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(raw + o) = r;
+        }
+    }
+}
+
+// decode: Conv2d(C -> Cout, 1x1) in fp32 on the NHWC fp32 feature map, written NCHW, fused with
+// x_hat = c_skip*mu + c_out*f (vdm_unet.py:72,100; bsi.py:382-386).  One thread per pixel.
+__global__ void unet_decode_kernel(const float* __restrict__ h, int M, int C, int HW, const float* __restrict__ w,
+                                   const float* __restrict__ bias, int Cout, const float* __restrict__ mu,
+                                   const float* __restrict__ c_skip, const float* __restrict__ c_out, int coef_stride,
+                                   float* __restrict__ out) {
+    extern __shared__ float wsm[];  // [Cout][C]
+    for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) wsm[i] = w[i];
+    __syncthreads();
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int b = m / HW, pix = m % HW;
+    const float* hr = h + (size_t)m * C;
+    for (int o = 0; o < Cout; ++o) {
+        float a = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hr + c);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(wsm + o * C + c);
+            a = __fmaf_rn(v[0], ww[0], a); a = __fmaf_rn(v[1], ww[1], a); a = __fmaf_rn(v[2], ww[2], a); a = __fmaf_rn(v[3], ww[3], a);
+        }
+        a += bias[o];
+        const size_t gi = ((size_t)b * Cout + o) * HW + pix;
+        if (c_skip) a = __fmaf_rn(c_out[(size_t)b * coef_stride], a, __fmul_rn(c_skip[(size_t)b * coef_stride], mu[gi]));
+        out[gi] = a;
+    }
+}
+
+// weight re-arrangement for the implicit GEMM: fp32 [Cout][Cin][kh][kw] -> bf16 [Cout][ld] with K index (tap, channel),
+// Cin zero-padded to cin_pad, written at column offset col0 (so a 1x1 skip weight can be appended behind a 3x3 one).
+__global__ void conv_weight_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0,
+                                        __bf16* __restrict__ out) {
+    const size_t total = (size_t)Cout * taps * cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cin_pad);
+        const int tap = (int)((i / cin_pad) % taps);
+        const int o = (int)(i / ((size_t)cin_pad * taps));
+        const float v = c < Cin ? w[((size_t)o * Cin + c) * taps + tap] : 0.0f;
+        out[(size_t)o * ld + col0 + tap * cin_pad + c] = (__bf16)v;
+    }
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                                  const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16,
+                                  bsi_stream_t stream) {
+    BSI_CHECK_ARG(x1 && gamma && beta && out_bf16 && B > 0 && HW > 0, "bsi_groupnorm_nhwc: bad args");
+    const int C = C1 + C2;
+    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 4 == 0 && C2 % 4 == 0 && (C2 == 0 || x2),
+                  "bsi_groupnorm_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(B), dim3(1024), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps, silu,
+                       reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<__bf16*>(raw_bf16));
+    BSI_CHECK_LAUNCH("bsi_groupnorm_nhwc");
+    return BSI_OK;
+}
+
+extern "C" int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout,
+                               const float* mu, const float* c_skip, const float* c_out, int coef_stride, float* out,
+                               bsi_stream_t stream) {
+    BSI_CHECK_ARG(h && w && bias && out && B > 0 && HW > 0 && C % 4 == 0 && Cout > 0 && Cout * C * 4 <= 64 * 1024,
+                  "bsi_unet_decode: bad args");
+    BSI_CHECK_ARG((c_skip == nullptr) == (c_out == nullptr) && (!c_skip || mu), "bsi_unet_decode: coefficients incomplete");
+    const int M = B * HW;
+    hipLaunchKernelGGL(unet_decode_kernel, dim3((M + 255) / 256), dim3(256), (size_t)Cout * C * sizeof(float), S(stream), h, M, C,
+                       HW, w, bias, Cout, mu, c_skip, c_out, coef_stride, out);
+    BSI_CHECK_LAUNCH("bsi_unet_decode");
+    return BSI_OK;
+}
+
+extern "C" int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, void* out,
+                                    bsi_stream_t stream) {
+    BSI_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && (taps == 1 || taps == 9) && cin_pad >= Cin && ld >= col0 + taps * cin_pad,
+                  "bsi_conv_weight_pack: bad args");
+    const size_t total = (size_t)Cout * taps * cin_pad;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3((int)g), dim3(256), 0, S(stream), w, Cout, Cin, taps, cin_pad, ld, col0,
+                       reinterpret_cast<__bf16*>(out));
+    BSI_CHECK_LAUNCH("bsi_conv_weight_pack");
+    return BSI_OK;
+}

@@ -277,6 +277,40 @@ int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/
                     int coef_stride, float* out, void* workspace, float* tokens_out, bsi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * VDM-UNet building blocks — bsi/models/vdm_unet.py, bsi/nn/residual_block.py, bsi/nn/attention.py.
+ * Activations are NHWC: [B*H*W pixels][channels].
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    BSI_CONV_BIAS_BF16 = 0,      /* out_bf16 = bf16(conv + bias)                                   (attention.py:29) */
+    BSI_CONV_FILM_SILU_BF16 = 1, /* out_bf16 = bf16(silu((conv + bias)*(scale+1) + shift))  (residual_block.py:44-46) */
+    BSI_CONV_BIAS_RESID_F32 = 2, /* out_f32 = conv + bias (+ resid)                    (residual_block.py:48,63) */
+};
+typedef struct bsi_conv_args {
+    const void* x;     /* bf16 NHWC [B*H*W, Cin] */
+    const void* x2;    /* optional bf16 NHWC [B*H*W, Cin2]: extra 1x1 K steps (skip conv folded in) */
+    const void* w;     /* bf16 [Cout][taps*Cin + Cin2] from bsi_conv_weight_pack */
+    const float* bias; /* [Cout] */
+    const void* zeros; /* >= 64 bytes of zeros (padding taps read it) */
+    void* out;         /* bf16 or fp32 [B*H*W, ldo] */
+    const float* film; /* FILM: fp32 [film_rows][film_stride], scale at [0, Cout), shift at [Cout, 2 Cout) */
+    const float* resid;/* BIAS_RESID_F32: fp32 [B*H*W, ldo] or NULL */
+    int film_rows, film_stride;
+    int B, H, W, Cin, Cin2, Cout, taps /* 9 = 3x3 pad 1, 1 = 1x1 */, ldo, epilogue;
+} bsi_conv_args;
+/* Conv2d(stride 1, zero padding) as implicit GEMM on bf16 MFMA; Cin, Cin2 multiples of 32, Cout of 16. */
+int bsi_conv_nhwc_bf16(const bsi_conv_args* a /*host*/, bsi_stream_t stream);
+/* fp32 Conv2d weight [Cout][Cin][kh][kw] -> bf16 [Cout][ld] at column col0 with K index (tap, channel), Cin padded. */
+int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, void* out,
+                         bsi_stream_t stream);
+/* GroupNorm(32 groups, affine, eps) over cat(x1, x2) channels (x2 nullable) per image, optional SiLU -> bf16 NHWC
+ * (residual_block.py:42-43, vdm_unet.py:52,84); raw_bf16 (nullable) receives the un-normalised bf16 copy. */
+int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                       const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16, bsi_stream_t stream);
+/* decode Conv2d(C -> Cout, 1x1) in fp32 on NHWC fp32 h, NCHW output, fused x_hat = c_skip*mu + c_out*f. */
+int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout, const float* mu,
+                    const float* c_skip, const float* c_out, int coef_stride, float* out, bsi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * DenoisingDiT training engine — forward with a tape + hand-written backward (replaces torch autograd over
  * dit.py:87-103,174-181 inside `BSI.train_loss(...).mean().backward()`, bsi/tasks/bsi.py:187-194).
  * ---------------------------------------------------------------------------------------- */

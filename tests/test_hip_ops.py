@@ -441,3 +441,79 @@ def test_cast_transpose_and_silu_bwd(N):
     p = pre.double().requires_grad_(True)
     do.silu(p).backward(ds.double())
     assert rel_linf(o.cpu().float(), p.grad) < 5e-3
+
+
+# ----------------------------------------------------------------------------------------------
+# VDM-UNet building blocks
+# ----------------------------------------------------------------------------------------------
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cin2,Cout,taps,epi", [
+    (2, 8, 64, 0, 64, 9, "bias"), (3, 32, 128, 0, 128, 9, "film"), (2, 32, 128, 0, 128, 9, "resid"),
+    (2, 32, 128, 256, 128, 9, "resid_skip"), (2, 32, 32, 0, 128, 9, "resid0"), (2, 32, 128, 0, 384, 9, "bias"),
+    (9, 8, 256, 0, 64, 1, "bias")])
+def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
+    gen = torch.Generator().manual_seed(B + H + Cin + Cout)
+    ks = 3 if taps == 9 else 1
+    x = bf16r(torch.randn((B, Cin, H, H), generator=gen))
+    w = bf16r(torch.randn((Cout, Cin, ks, ks), generator=gen) / math.sqrt(Cin * taps))
+    bias = torch.randn(Cout, generator=gen)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=ks // 2)
+    K = taps * Cin + Cin2
+    wp = empty(Cout, K, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w)), Cout, Cin, taps, Cin, K, 0, N.ptr(wp), N.stream()))
+    zeros = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    a = N.ConvArgs(x=dev(_nhwc(x).to(torch.bfloat16)).data_ptr(), w=wp.data_ptr(), bias=dev(bias).data_ptr(),
+                   zeros=zeros.data_ptr(), B=B, H=H, W=H, Cin=Cin, Cin2=Cin2, Cout=Cout, taps=taps, ldo=Cout)
+    if Cin2:
+        x2 = bf16r(torch.randn((B, Cin2, H, H), generator=gen))
+        w2 = bf16r(torch.randn((Cout, Cin2, 1, 1), generator=gen) / math.sqrt(Cin2))
+        N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w2)), Cout, Cin2, 1, Cin2, K, taps * Cin, N.ptr(wp), N.stream()))
+        a.x2 = dev(_nhwc(x2).to(torch.bfloat16)).data_ptr()
+        ref = ref + torch.nn.functional.conv2d(x2.double(), w2.double())
+    if epi == "bias":
+        out = empty(B * H * H, Cout, dtype=torch.bfloat16)
+        a.out, a.epilogue = out.data_ptr(), N.CONV_BIAS_BF16
+        N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+        assert rel_linf(out.cpu().float(), _nhwc(ref).reshape(-1, Cout)) < 5e-3
+    elif epi == "film":
+        film = torch.randn((B, 2 * Cout), generator=gen) * 0.5
+        out = empty(B * H * H, Cout, dtype=torch.bfloat16)
+        a.out, a.epilogue, a.film, a.film_rows, a.film_stride = out.data_ptr(), N.CONV_FILM_SILU_BF16, dev(film).data_ptr(), B, 2 * Cout
+        N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+        y = ref * (film[:, :Cout, None, None].double() + 1) + film[:, Cout:, None, None].double()
+        assert rel_linf(out.cpu().float(), _nhwc(do.silu(y)).reshape(-1, Cout)) < 5e-3
+    else:
+        res = torch.randn((B * H * H, Cout), generator=gen) if epi == "resid" else None
+        out = empty(B * H * H, Cout)
+        a.out, a.epilogue = out.data_ptr(), N.CONV_BIAS_RESID_F32
+        if res is not None:
+            a.resid = dev(res).data_ptr()
+        N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+        want = _nhwc(ref).reshape(-1, Cout) + (res.double() if res is not None else 0)
+        assert rel_linf(out, want) < 3e-5, rel_linf(out, want)
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(3, 64, 64, 0, 1), (2, 1024, 128, 0, 1), (2, 1024, 128, 128, 1), (2, 1024, 128, 0, 0)])
+def test_groupnorm_nhwc(N, B, HW, C1, C2, silu):
+    gen = torch.Generator().manual_seed(B + HW + C1 + C2)
+    Cc = C1 + C2
+    x1 = torch.randn((B, HW, C1), generator=gen) * 2 + 0.5
+    x2 = torch.randn((B, HW, C2), generator=gen) if C2 else None
+    ga, be = torch.randn(Cc, generator=gen), torch.randn(Cc, generator=gen)
+    xc = torch.cat([x1, x2], 2) if C2 else x1
+    side = int(math.isqrt(HW))
+    xn = xc.permute(0, 2, 1).reshape(B, Cc, side, side).double()
+    from oracle.unet_oracle import group_norm
+    ref = group_norm(xn, 32, ga.double(), be.double())
+    if silu:
+        ref = do.silu(ref)
+    ref = ref.reshape(B, Cc, HW).permute(0, 2, 1)
+    out = empty(B, HW, Cc, dtype=torch.bfloat16)
+    raw = empty(B, HW, Cc, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_groupnorm_nhwc(N.ptr(dev(x1)), C1, N.ptr(dev(x2)) if C2 else None, C2, B, HW, N.ptr(dev(ga)),
+                                       N.ptr(dev(be)), 1e-5, silu, N.ptr(out), N.ptr(raw), N.stream()))
+    assert float((out.cpu().double() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8 + 1e-3
+    assert torch.equal(raw.cpu(), xc.to(torch.bfloat16))

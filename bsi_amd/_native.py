@@ -37,6 +37,21 @@ class ConvArgs(C.Structure):
 CONV_BIAS_BF16, CONV_FILM_SILU_BF16, CONV_BIAS_RESID_F32 = range(3)
 
 
+class UNetConfig(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("C", "H", "W", "dim", "levels", "heads", "ff_nmin", "ff_nmax", "emb_size", "c_dim")]
+
+
+class UNetResBlockWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("gn_w", "gn_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b")]
+
+
+class UNetWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("enc_w", "enc_b", "dec_w", "dec_b", "pe_scale", "pe_bias", "pm1_w", "pm1_b", "pm3_w",
+                                          "pm3_b", "film_w", "film_b")] + \
+               [("blocks", C.POINTER(UNetResBlockWeights))] + \
+               [(k, C.c_void_p) for k in ("agn_w", "agn_b", "aqkv_w", "aqkv_b", "aout_w", "aout_b")]
+
+
 class DitConfig(C.Structure):
     _fields_ = [("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("patch", C.c_int),
                 ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
@@ -131,6 +146,11 @@ _PROTOS = {
     "bsi_conv_weight_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "bsi_unet_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "bsi_unet_cin_pad": (_i, [C.POINTER(UNetConfig)]),
+    "bsi_unet_workspace_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
+    "bsi_unet_film_scratch_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
+    "bsi_unet_film": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), _vp, _i, _vp, _vp, _vp]),
+    "bsi_unet_forward": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_workspace_bytes": (_sz, [C.POINTER(DitConfig), _i]),

@@ -1,0 +1,187 @@
+// Host-side sequencing of one DenoisingVDMUNet evaluation (bsi/models/vdm_unet.py:92-100,
+// bsi/nn/simplified_unet.py:33-48, bsi/nn/residual_block.py:61-64 of the reference) on a HIP stream.
+// No allocation, no synchronisation: the caller owns the workspace.  Activations are NHWC.
+#include "common.h"
+#include "dit_ops.h"
+
+namespace {
+
+inline size_t au(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct UDims {
+    int nfreq, cin, cin_pad, HW, nblocks, dh;
+    size_t M;
+};
+
+inline UDims udims(const bsi_unet_config* c, int B) {
+    UDims d;
+    d.nfreq = (c->ff_nmax >= c->ff_nmin) ? (c->ff_nmax - c->ff_nmin + 1) : 0;
+    d.cin = c->C + c->C * d.nfreq * 2;
+    d.cin_pad = (int)au((size_t)d.cin, 32);
+    d.HW = c->H * c->W;
+    d.nblocks = 2 * c->levels + 2;
+    d.dh = c->dim / c->heads;
+    d.M = (size_t)B * d.HW;
+    return d;
+}
+
+struct UWs {
+    char* zeros;
+    char* xin;    // bf16 [M, cin_pad]
+    char* a;      // bf16 [M, 2 dim]   GroupNorm output
+    char* raw;    // bf16 [M, 2 dim]   un-normalised copy (skip conv operand)
+    char* y;      // bf16 [M, dim]     conv1 output / attention output
+    char* qkv;    // bf16 [M, 3 dim]
+    float* h[3];  // fp32 [M, dim] rotating feature maps
+    float* skips; // fp32 [levels][M, dim]
+    size_t total;
+};
+
+inline UWs carve(const bsi_unet_config* c, int B, void* base) {
+    const UDims d = udims(c, B);
+    UWs w;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    const size_t M = d.M, dim = c->dim;
+    w.zeros = p + off; off += 256;
+    w.xin = p + off; off += au(M * d.cin_pad * 2);
+    w.a = p + off; off += au(M * 2 * dim * 2);
+    w.raw = p + off; off += au(M * 2 * dim * 2);
+    w.y = p + off; off += au(M * dim * 2);
+    w.qkv = p + off; off += au(M * 3 * dim * 2);
+    for (int i = 0; i < 3; ++i) { w.h[i] = reinterpret_cast<float*>(p + off); off += au(M * dim * 4); }
+    w.skips = reinterpret_cast<float*>(p + off); off += au(M * dim * 4) * c->levels;
+    w.total = off;
+    return w;
+}
+
+#define TRY(expr)              \
+    do {                       \
+        int rc__ = (expr);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+int conv(const void* x, const void* x2, const void* w, const float* bias, const void* zeros, void* out, const float* film,
+         int film_rows, int film_stride, const float* resid, int B, int H, int W, int Cin, int Cin2, int Cout, int taps, int epi,
+         bsi_stream_t s) {
+    bsi_conv_args a{};
+    a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.zeros = zeros; a.out = out; a.film = film; a.film_rows = film_rows;
+    a.film_stride = film_stride; a.resid = resid; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cin2 = Cin2; a.Cout = Cout;
+    a.taps = taps; a.ldo = Cout; a.epilogue = epi;
+    return bsi_conv_nhwc_bf16(&a, s);
+}
+
+}  // namespace
+
+extern "C" size_t bsi_unet_workspace_bytes(const bsi_unet_config* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return carve(cfg, B, nullptr).total;
+}
+
+extern "C" int bsi_unet_cin_pad(const bsi_unet_config* cfg) { return cfg ? udims(cfg, 1).cin_pad : 0; }
+
+extern "C" size_t bsi_unet_film_scratch_bytes(const bsi_unet_config* cfg, int rows) {
+    if (!cfg || rows <= 0) return 0;
+    return 3 * au((size_t)rows * (cfg->c_dim > 64 ? cfg->c_dim : 64) * 2) + au((size_t)rows * cfg->emb_size * 4);
+}
+
+// c = pos_map(t) (vdm_unet.py:62-69) and the FiLM table of every residual block (residual_block.py:39,62):
+// film[r, blk, 0:2dim] = Linear_blk(c[r]).  film: fp32 [rows, nblocks, 2*dim].
+extern "C" int bsi_unet_film(const bsi_unet_config* cfg, const bsi_unet_weights* w, const float* t, int rows, float* film,
+                             void* scratch, bsi_stream_t stream) {
+    BSI_CHECK_ARG(cfg && w && t && film && scratch && rows > 0, "bsi_unet_film: bad args");
+    BSI_CHECK_ARG(cfg->emb_size <= 64 && cfg->emb_size % 2 == 0 && cfg->c_dim % 64 == 0, "bsi_unet_film: emb_size=%d c_dim=%d unsupported",
+                  cfg->emb_size, cfg->c_dim);
+    const UDims d = udims(cfg, 1);
+    char* p = reinterpret_cast<char*>(scratch);
+    const size_t cb = au((size_t)rows * (cfg->c_dim > 64 ? cfg->c_dim : 64) * 2);
+    char* emb = p;            // bf16 [rows, 64] (zero padded)
+    char* c1 = p + cb;        // bf16 [rows, c_dim]
+    char* c2 = p + 2 * cb;    // bf16 [rows, c_dim]
+    float* embf = reinterpret_cast<float*>(p + 3 * cb);
+    TRY(bsi_nyquist_embed(t, rows, w->pe_scale, w->pe_bias, cfg->emb_size, embf, nullptr, stream));
+    TRY(bsi_cast_rows_bf16(embf, cfg->emb_size, rows, cfg->emb_size, emb, 64, stream));
+    bsi_gemm_args g{};
+    g.A = emb; g.W = w->pm1_w; g.bias = w->pm1_b; g.out = c1; g.M = rows; g.N = cfg->c_dim; g.K = 64; g.lda = 64; g.ldw = 64;
+    g.ldo = cfg->c_dim; g.epilogue = BSI_EPI_BIAS_SILU_BF16;
+    TRY(bsi_gemm_bf16(&g, stream));
+    bsi_gemm_args g2{};
+    g2.A = c1; g2.W = w->pm3_w; g2.bias = w->pm3_b; g2.out = c2; g2.M = rows; g2.N = cfg->c_dim; g2.K = cfg->c_dim;
+    g2.lda = cfg->c_dim; g2.ldw = cfg->c_dim; g2.ldo = cfg->c_dim; g2.epilogue = BSI_EPI_BIAS_SILU_BF16;
+    TRY(bsi_gemm_bf16(&g2, stream));
+    bsi_gemm_args g3{};
+    g3.A = c2; g3.W = w->film_w; g3.bias = w->film_b; g3.out = film; g3.M = rows; g3.N = d.nblocks * 2 * cfg->dim; g3.K = cfg->c_dim;
+    g3.lda = cfg->c_dim; g3.ldw = cfg->c_dim; g3.ldo = g3.N; g3.epilogue = BSI_EPI_BIAS_F32;
+    return bsi_gemm_bf16(&g3, stream);
+}
+
+extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weights* w, int B, const float* mu, const float* film,
+                                int film_rows, const float* c_in, const float* c_skip, const float* c_out, int coef_stride,
+                                float* out, void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(cfg && w && w->blocks && mu && film && out && workspace && B > 0, "bsi_unet_forward: bad args");
+    BSI_CHECK_ARG(film_rows == 1 || film_rows == B, "bsi_unet_forward: film_rows=%d must be 1 or B=%d", film_rows, B);
+    BSI_CHECK_ARG((c_in == nullptr) == (c_skip == nullptr) && (c_in == nullptr) == (c_out == nullptr),
+                  "bsi_unet_forward: c_in/c_skip/c_out must be given together");
+    const UDims d = udims(cfg, B);
+    const int dim = cfg->dim, H = cfg->H, W = cfg->W, L = cfg->levels;
+    BSI_CHECK_ARG(dim % 32 == 0 && (dim == 64 || dim == 128) && dim % cfg->heads == 0 && (d.dh == 64 || d.dh == 128) && d.HW % 64 == 0,
+                  "bsi_unet_forward: unsupported geometry dim=%d heads=%d HW=%d", dim, cfg->heads, d.HW);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UWs ws = carve(cfg, B, workspace);
+    const int fstride = d.nblocks * 2 * dim;
+    if (hipMemsetAsync(ws.zeros, 0, 256, s) != hipSuccess) {
+        bsi_set_error("bsi_unet_forward: memset failed");
+        return BSI_ELAUNCH;
+    }
+    // c_in*mu, Fourier features, NHWC bf16 with the channels padded to a multiple of 32 (vdm_unet.py:95-99)
+    TRY(bsi_dit_prologue_launch(mu, c_in, coef_stride, B, cfg->C, H, W, 1, cfg->ff_nmin, d.nfreq, d.cin_pad, ws.xin, s));
+    float* h = ws.h[0];
+    TRY(conv(ws.xin, nullptr, w->enc_w, w->enc_b, ws.zeros, h, nullptr, 0, 0, nullptr, B, H, W, d.cin_pad, 0, dim, 9,
+             BSI_CONV_BIAS_RESID_F32, stream));
+    int cur = 0;
+    auto skip_buf = [&](int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws.skips) + (size_t)i * au(d.M * dim * 4)); };
+    // residual block (residual_block.py:61-64): out = skip(x) + conv2(silu(film(conv1(silu(gn(x))))))
+    auto resblock = [&](int blk, const float* x1, const float* x2, float* dst) -> int {
+        const bsi_unet_resblock_weights& rb = w->blocks[blk];
+        const int cin2 = x2 ? dim : 0;
+        TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, ws.a, x2 ? ws.raw : nullptr, stream));
+        TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.y, film + (size_t)blk * 2 * dim, film_rows, fstride, nullptr, B,
+                 H, W, dim + cin2, 0, dim, 9, BSI_CONV_FILM_SILU_BF16, stream));
+        // conv2 (+ the 1x1 skip conv of cat(x, x_skip) folded in as extra K steps; its bias is folded into conv2_b)
+        return conv(ws.y, x2 ? ws.raw : nullptr, rb.conv2_w, rb.conv2_b, ws.zeros, dst, nullptr, 0, 0, x2 ? nullptr : x1, B, H, W, dim,
+                    x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream);
+    };
+    for (int i = 0; i < L; ++i) {  // down path: every block's output is also a skip tensor (simplified_unet.py:36-39)
+        float* dst = skip_buf(i);
+        TRY(resblock(i, h, nullptr, dst));
+        h = dst;
+    }
+    // centre: ResBlock, Residual(GroupNorm -> Attention2D), ResBlock (vdm_unet.py:80-89)
+    TRY(resblock(L, h, nullptr, ws.h[cur]));
+    h = ws.h[cur];
+    TRY(bsi_groupnorm_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, ws.a, nullptr, stream));
+    TRY(conv(ws.a, nullptr, w->aqkv_w, w->aqkv_b, ws.zeros, ws.qkv, nullptr, 0, 0, nullptr, B, H, W, dim, 0, 3 * dim, 9,
+             BSI_CONV_BIAS_BF16, stream));
+    TRY(bsi_attention_fwd(ws.qkv, 3 * dim, B, d.HW, cfg->heads, d.dh, ws.y, dim, stream));
+    {
+        float* dst = ws.h[cur ^ 1];
+        TRY(conv(ws.y, nullptr, w->aout_w, w->aout_b, ws.zeros, dst, nullptr, 0, 0, h, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_RESID_F32,
+                 stream));
+        h = dst;
+        cur ^= 1;
+    }
+    {
+        float* dst = ws.h[2];
+        TRY(resblock(L + 1, h, nullptr, dst));
+        h = dst;
+    }
+    // up path: block(cat(x, skips.pop()))  (simplified_unet.py:43-46)
+    int pp = 0;
+    for (int i = 0; i < L; ++i) {
+        float* dst = ws.h[pp];
+        TRY(resblock(L + 2 + i, h, skip_buf(L - 1 - i), dst));
+        h = dst;
+        pp ^= 1;
+    }
+    return bsi_unet_decode(h, B, d.HW, dim, w->dec_w, w->dec_b, cfg->C, mu, c_skip, c_out, coef_stride, out, stream);
+}

@@ -310,6 +310,43 @@ int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, 
 int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout, const float* mu,
                     const float* c_skip, const float* c_out, int coef_stride, float* out, bsi_stream_t stream);
 
+/* DenoisingVDMUNet engine — bsi/models/vdm_unet.py:20-100 (no down/up-sampling; levels residual blocks down, centre
+ * [ResBlock, Residual(GroupNorm -> Attention2D), ResBlock], levels blocks up on cat(x, skip)). */
+typedef struct bsi_unet_config {
+    int C, H, W;      /* data_shape */
+    int dim, levels, heads;
+    int ff_nmin, ff_nmax;
+    int emb_size;     /* pos_emb.size (32) */
+    int c_dim;        /* pos_emb.size * pos_emb_mult (128) */
+} bsi_unet_config;
+typedef struct bsi_unet_resblock_weights {
+    const float *gn_w, *gn_b;                  /* layers.0: GroupNorm(32, Cin) */
+    const void* conv1_w; const float* conv1_b; /* layers.2: bf16 [dim][9*Cin] (bsi_conv_weight_pack) */
+    const void* conv2_w; const float* conv2_b; /* layers.5|6 (+ skip 1x1 appended as K columns, its bias added): bf16 [dim][9*dim (+2*dim)] */
+} bsi_unet_resblock_weights;
+typedef struct bsi_unet_weights {
+    const void* enc_w; const float* enc_b;     /* encode: bf16 [dim][9*cin_pad] */
+    const float *dec_w, *dec_b;                /* decode: fp32 [C][dim], [C] */
+    const float *pe_scale, *pe_bias;           /* NyquistPositionalEmbedding tables [emb_size] */
+    const void* pm1_w; const float* pm1_b;     /* pos_map.1: bf16 [c_dim][64] (K zero padded) */
+    const void* pm3_w; const float* pm3_b;     /* pos_map.3: bf16 [c_dim][c_dim] */
+    const void* film_w; const float* film_b;   /* all project_onto_scale_shift stacked: bf16 [nblocks*2*dim][c_dim], fp32 [nblocks*2*dim] */
+    const bsi_unet_resblock_weights* blocks;   /* host array [2*levels+2]: down 0..L-1, centre 0, centre 2, up 0..L-1 */
+    const float *agn_w, *agn_b;                /* center_block.1.fn.0 */
+    const void* aqkv_w; const float* aqkv_b;   /* center_block.1.fn.1.to_qkv: bf16 [3*dim][9*dim] */
+    const void* aout_w; const float* aout_b;   /* center_block.1.fn.1.to_out: bf16 [dim][9*dim] */
+} bsi_unet_weights;
+int bsi_unet_cin_pad(const bsi_unet_config* cfg);
+size_t bsi_unet_workspace_bytes(const bsi_unet_config* cfg, int B);
+size_t bsi_unet_film_scratch_bytes(const bsi_unet_config* cfg, int rows);
+/* film[r, blk, 0:2*dim] = project_onto_scale_shift_blk(pos_map(t[r]))  (fp32 [rows, nblocks, 2*dim]). */
+int bsi_unet_film(const bsi_unet_config* cfg, const bsi_unet_weights* w /*host*/, const float* t, int rows, float* film,
+                  void* scratch, bsi_stream_t stream);
+/* out = c_skip*mu + c_out*f(c_in*mu, t) (or f(mu,t) with NULL coefficients); film rows: 1 (shared t) or B. */
+int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weights* w /*host*/, int B, const float* mu, const float* film,
+                     int film_rows, const float* c_in, const float* c_skip, const float* c_out, int coef_stride, float* out,
+                     void* workspace, bsi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DenoisingDiT training engine — forward with a tape + hand-written backward (replaces torch autograd over
  * dit.py:87-103,174-181 inside `BSI.train_loss(...).mean().backward()`, bsi/tasks/bsi.py:187-194).

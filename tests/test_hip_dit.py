@@ -350,3 +350,73 @@ def test_training_dropout_matches_oracle_with_same_masks():
     model.eval()
     with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
         assert max_rel(bsi.train_loss(g["x"].to(DEV)).cpu(), g["loss"]) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------------
+# VDM-UNet on the native engine
+# ----------------------------------------------------------------------------------------------
+def make_unet(tag="unet_ff", ff=True):
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+    m = DenoisingVDMUNet((3, 8, 8), NyquistPositionalEmbedding(32, 100), "silu", 64, 1, 4, n_attention_heads=1,
+                         dropout=0.1, fourier_features=FourierFeatures(n_min=6, n_max=8) if ff else None)
+    m.load_state_dict(weights(tag))
+    return m.to(DEV).eval()
+
+
+def test_unet_forward_vs_golden():
+    from oracle import unet_oracle as uo
+    g = golden("g7_unet_fwd")
+    m = make_unet()
+    with torch.no_grad():
+        y = m(g["mu"].to(DEV), g["t"].to(DEV)).cpu()
+        W = weights("unet_ff")
+        yb = uo.unet_forward(W, g["mu"], g["t"], levels=1, ff=(6, 8), has_dropout_slot=True, md=torch.bfloat16)
+    assert rel_linf(y, g["out"]) < 2e-2, rel_linf(y, g["out"])
+    assert rel_linf(y, yb) < 1e-2, rel_linf(y, yb)
+
+
+def test_unet_sampling_vs_golden():
+    # teacher-forced with Fourier features
+    g = golden("g5_hist_unet_ff")
+    bsi = make_bsi(make_unet("unet_ff", True), (3, 8, 8), k=int(g["k"]))
+    k = int(g["k"])
+    t = bsi.default_schedule
+    t_eval = torch.cat([t[:k], t.new_ones(1)])
+    with torch.no_grad():
+        for i in range(k + 1):
+            mu_i = g["mus"][i].to(DEV)
+            xh = bsi._predict_x(mu_i, t_eval[i].repeat(mu_i.shape[0]))
+            assert rel_linf(xh, g["x_hats"][i]) < 2e-2, (i, rel_linf(xh, g["x_hats"][i]))
+    # free-running without Fourier features through BSI.sample_history (fused native path)
+    g = golden("g5_hist_unet_noff")
+    bsi = make_bsi(make_unet("unet_noff", False), (3, 8, 8), k=k)
+    with torch.no_grad(), replay_noise(randn=[g["eps0"]] + list(g["eps"])):
+        mus, xhs, ys = bsi.sample_history(2)
+    for i in range(k + 1):
+        assert rel_linf(xhs[i], g["x_hats"][i]) < 5e-2, (i, rel_linf(xhs[i], g["x_hats"][i]))
+        assert rel_linf(mus[i], g["mus"][i]) < 5e-2
+
+
+def test_full_size_unet_one_forward_vs_oracle():
+    """VDM-UNet of the CIFAR-10 config (dim 128, levels 32, 1 head) at B=2 against the fp32 CPU oracle."""
+    from oracle import unet_oracle as uo
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+    shape = (3, 32, 32)
+    W = uo.unet_random_weights(shape, 128, 32, seed=0, ff=(6, 8))
+    m = DenoisingVDMUNet(shape, NyquistPositionalEmbedding(32, 100), "silu", 128, 32, 4, n_attention_heads=1, dropout=0.1,
+                         fourier_features=FourierFeatures(n_min=6, n_max=8))
+    m.load_state_dict(W)
+    m = m.to(DEV).eval()
+    bsi = make_bsi(m, shape, k=128)
+    gen = torch.Generator().manual_seed(0)
+    mu = torch.randn((2, *shape), generator=gen) * 2
+    t = torch.tensor([0.2, 0.9])
+    f = lambda a, b: uo.unet_forward(W, a, b, levels=32, ff=(6, 8), has_dropout_slot=True)  # noqa: E731
+    with torch.no_grad():
+        got = bsi._predict_x(mu.to(DEV), t.to(DEV)).cpu()
+        ref = bo.BSIOracle(f, data_shape=shape, k=128).predict_x(mu, t)
+    assert rel_linf(got, ref) < 3e-2, rel_linf(got, ref)

@@ -104,3 +104,23 @@ def test_nyquist_tables_match_reference():
         assert torch.equal(pe.scale, g[f"pe_{size}_{rate}_scale"])
         assert torch.equal(pe.bias, g[f"pe_{size}_{rate}_bias"])
         assert pe.state_dict() == {}
+
+
+def test_unet_state_dict_contract():
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+
+    W = weights("unet_ff")
+    m = DenoisingVDMUNet((3, 8, 8), NyquistPositionalEmbedding(32, 100), "silu", 64, 1, 4, n_attention_heads=1,
+                         dropout=0.1, downsampling_attention=False, fourier_features=FourierFeatures(n_min=6, n_max=8),
+                         name="unet")
+    sd = m.state_dict()
+    assert set(sd) == set(W), set(sd) ^ set(W)
+    assert all(sd[k].shape == W[k].shape for k in W)
+    m.load_state_dict(W)
+    # without a Dropout module the second conv moves from layers.6 to layers.5
+    m2 = DenoisingVDMUNet((3, 8, 8), NyquistPositionalEmbedding(32, 100), "silu", 64, 1, 4, dropout=None)
+    assert "u_net.downsampling_blocks.0.0.layers.5.weight" in m2.state_dict()
+    assert "u_net.upsampling_blocks.0.0.skip.weight" in m2.state_dict()
+    assert m2.encode.weight.shape == (64, 3, 3, 3)

@@ -187,7 +187,11 @@ def main():
 
     train = None
     if a.train_steps > 0:
-        train = train_bench(a, bsi, model, dev, world, rank, barrier)
+        try:
+            train = train_bench(a, bsi, model, dev, world, rank, barrier)
+        except Exception as e:  # the sampling line must survive a failure of the secondary measurement
+            train = {"error": f"{type(e).__name__}: {e}"}
+            model.eval()
 
     if a.breakdown and rank == 0:
         names = list(N.PROF_CLASSES)
@@ -225,7 +229,7 @@ def main():
         }
         if train is not None:
             line["train"] = train
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.k)
         print(json.dumps(line))
     if world > 1:

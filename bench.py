@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimizer steps of the train benchmark (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=512, help="GLOBAL batch of the train benchmark (split over ranks)")
+    ap.add_argument("--train-timeout", type=int, default=300, help="seconds before the train benchmark is abandoned")
     return ap.parse_args()
 
 
@@ -185,25 +186,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    train = None
-    if a.train_steps > 0:
-        try:
-            train = train_bench(a, bsi, model, dev, world, rank, barrier)
-        except Exception as e:  # the sampling line must survive a failure of the secondary measurement
-            train = {"error": f"{type(e).__name__}: {e}"}
-            model.eval()
-
-    if a.breakdown and rank == 0:
-        names = list(N.PROF_CLASSES)
-        N.prof_enable(names)
-        step()
-        torch.cuda.synchronize()
-        rows = [(n, *N.prof_read(n)) for n in names]
-        N.prof_enable([])
-        tot = sum(r[2] for r in rows)
-        for n, c, ms in rows:
-            print(f"  {n:12s} {c:6d} launches {ms:10.2f} ms  {100 * ms / max(tot, 1e-9):5.1f} %", file=sys.stderr)
-
+    line = None
     if rank == 0:
         n_gpus = world
         imgs = a.batch * a.steps * n_gpus
@@ -227,11 +210,46 @@ def main():
                          "kernel": "gemm_bf16_pring_kernel<BSI_EPI_BIAS_GELU_BF16=2, 0> (fc1)",
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }
+
+    if a.breakdown and rank == 0:
+        names = list(N.PROF_CLASSES)
+        N.prof_enable(names)
+        step()
+        torch.cuda.synchronize()
+        rows = [(n, *N.prof_read(n)) for n in names]
+        N.prof_enable([])
+        tot = sum(r[2] for r in rows)
+        for n, c, ms in rows:
+            print(f"  {n:12s} {c:6d} launches {ms:10.2f} ms  {100 * ms / max(tot, 1e-9):5.1f} %", file=sys.stderr)
+
+    train = None
+    if a.train_steps > 0:
+        # The train measurement is secondary: if it fails or hangs (e.g. a collective mismatch on an untested topology)
+        # the sampling line is still emitted by the watchdog and the process exits.
+        import threading
+
+        def give_up():
+            if line is not None:
+                line["train"] = {"error": "train benchmark did not finish within %d s" % a.train_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(a.train_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            train = train_bench(a, bsi, model, dev, world, rank, barrier)
+        except Exception as e:
+            train = {"error": f"{type(e).__name__}: {e}"}
+            model.eval()
+        dog.cancel()
+
+    if rank == 0:
         if train is not None:
             line["train"] = train
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.k)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -29,6 +29,18 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 FWD_GFLOP_PER_IMG = 161.46  # DiT-L/2 forward, 2*MAC
 
 
+def pmc_traffic(batch):
+    """Fabric-side bytes per fc1 launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py writes the file;
+    counters cannot be collected from inside the benchmark).  None when no measurement at this batch is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "fc1_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec["traffic_bytes_per_launch"] if rec.get("images_per_gpu") == batch else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +218,7 @@ def main():
                        "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}"},
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.batch),
                          "kernel": "gemm_bf16_pring_kernel<BSI_EPI_BIAS_GELU_BF16=2, 0> (fc1)",
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }

@@ -212,27 +212,39 @@ __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* _
 
 // Backward of dit.py:163-172,181 + bsi.py:382-386: given g_xhat [B,C,H,W] (gradient of x_hat = c_skip*mu + c_out*f):
 //   dY[token, o] = c_out[b] * g_xhat[b, ch, hh, ww]  (patchify order), y = LN_affine(x) (fp32)
-//   dWdec[o,:] += dY[o] * y,  dbdec[o] += dY[o],  dy = sum_o dY[o] * Wdec[o,:]
-//   dlnw += dy * n, dlnb += dy,  dX = LN_bwd(dy * lnw)     (dX is WRITTEN, it starts the residual gradient)
-// Parameter gradients are accumulated per workgroup in LDS ([P+2][d] fp32) and flushed with atomics.
-template <int VPL>
-__global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int d, int P, const float* __restrict__ ln_w,
-                                     const float* __restrict__ ln_b, const float* __restrict__ dec_w, int C, int H, int W,
-                                     int ps, const float* __restrict__ g_xhat, const float* __restrict__ c_out,
-                                     int coef_stride, float* __restrict__ dX, float* __restrict__ d_dec_w,
+//   dy = sum_o dY[o] * Wdec[o,:],  dlnw += dy * n, dlnb += dy,  dbdec[o] += dY[o],
+//   dX = LN_bwd(dy * lnw)     (dX is WRITTEN, it starts the residual gradient)
+// The decoder weight gradient dWdec = dY^T y is a token-contraction and goes to the TN GEMM: this kernel writes its
+// operands yb = bf16(y) [M, d] and dYb = bf16(dY) [M, Pp] (Pp = P rounded up to 8, zero padded).
+// dlnw / dlnb / dbdec: per-wave register accumulators over the wave's rows, one LDS reduction per workgroup, one
+// global atomic per element per workgroup.
+template <int VPL, bool WLDS>
+__global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int d, int P, int Pp,
+                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                     const float* __restrict__ dec_w, int C, int H, int W, int ps,
+                                     const float* __restrict__ g_xhat, const float* __restrict__ c_out, int coef_stride,
+                                     float* __restrict__ dX, __bf16* __restrict__ yb, __bf16* __restrict__ dYb,
                                      float* __restrict__ d_dec_b, float* __restrict__ d_ln_w, float* __restrict__ d_ln_b) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [P][d] weights, then [P+2][d] gradient accumulators
-    float* wsm = sm;
-    float* gsm = sm + (size_t)P * d;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][d] reduction, then (WLDS) [P][d] weights
+    float* gsm = sm;
+    float* wsm = sm + 2 * (size_t)d;
     const int d4 = d >> 2;
-    for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
-        reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
-    for (int i = threadIdx.x; i < (P + 2) * d4; i += blockDim.x)
-        reinterpret_cast<f32x4*>(gsm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < 2 * d4; i += blockDim.x) reinterpret_cast<f32x4*>(gsm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (WLDS)
+        for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
+            reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int nw = W / ps, tokens = (H / ps) * nw, HW = H * W;
     float db_acc = 0.f;  // lane o accumulates d_dec_b[o]
+    f32x4 glw[VPL], glb[VPL], lw[VPL], lb[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        glw[i] = glb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lw[i] = (c < d4) ? reinterpret_cast<const f32x4*>(ln_w)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        lb[i] = (c < d4) ? reinterpret_cast<const f32x4*>(ln_b)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Mtok; row += gridDim.x * wpb) {
         const int b_idx = row / tokens, tok = row % tokens;
         const int th = tok / nw, tw = tok % nw;
@@ -244,13 +256,13 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
             if (c_out) dy_o *= c_out[(size_t)b_idx * coef_stride];
             db_acc += dy_o;
         }
-        f32x4 v[VPL], lw[VPL];
+        if (lane < Pp) dYb[(size_t)row * Pp + lane] = (__bf16)dy_o;
+        f32x4 v[VPL];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = i * 64 + lane;
             v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-            lw[i] = (c < d4) ? reinterpret_cast<const f32x4*>(ln_w)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         const float mean = wave_sum(s) / (float)d;
@@ -270,9 +282,16 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
         f32x4 dy[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
             dy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[i][k] = (v[i][k] - mean) * rstd;  // n
+            if (c < d4) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(__fmaf_rn(v[i][0], lw[i][0], lb[i][0]), __fmaf_rn(v[i][1], lw[i][1], lb[i][1]));
+                pk[1] = pack_bf16x2(__fmaf_rn(v[i][2], lw[i][2], lb[i][2]), __fmaf_rn(v[i][3], lw[i][3], lb[i][3]));
+                reinterpret_cast<u32x2*>(yb + (size_t)row * d)[c] = pk;
+            }
         }
         for (int o = 0; o < P; ++o) {
             const float g = __shfl(dy_o, o, 64);
@@ -280,33 +299,24 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
             for (int i = 0; i < VPL; ++i) {
                 const int c = i * 64 + lane;
                 if (c < d4) {
-                    const f32x4 wv = reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c];
-                    const f32x4 lb = reinterpret_cast<const f32x4*>(ln_b)[c];
-                    float* ga = gsm + (size_t)o * d + c * 4;
+                    const f32x4 wv = WLDS ? reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c]
+                                          : reinterpret_cast<const f32x4*>(dec_w + (size_t)o * d)[c];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        dy[i][k] = __fmaf_rn(g, wv[k], dy[i][k]);
-                        atomicAdd(ga + k, g * __fmaf_rn(v[i][k], lw[i][k], lb[k]));  // LDS atomic: dWdec[o] += dY[o]*y
-                    }
+                    for (int k = 0; k < 4; ++k) dy[i][k] = __fmaf_rn(g, wv[k], dy[i][k]);
                 }
             }
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < d4) {
-                float* g_lw = gsm + (size_t)P * d + c * 4;
-                float* g_lb = gsm + (size_t)(P + 1) * d + c * 4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    atomicAdd(g_lw + k, dy[i][k] * v[i][k]);
-                    atomicAdd(g_lb + k, dy[i][k]);
-                    const float dn = dy[i][k] * lw[i][k];
-                    dy[i][k] = dn;
-                    s1 += dn;
-                    s2 = __fmaf_rn(dn, v[i][k], s2);
-                }
+            for (int k = 0; k < 4; ++k) {
+                glw[i][k] = __fmaf_rn(dy[i][k], v[i][k], glw[i][k]);
+                glb[i][k] += dy[i][k];
+                const float dn = dy[i][k] * lw[i][k];
+                dy[i][k] = dn;
+                s1 += dn;
+                s2 = __fmaf_rn(dn, v[i][k], s2);
             }
         }
         const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
@@ -321,11 +331,21 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
             }
         }
     }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(gsm + c * 4 + k, glw[i][k]);
+                atomicAdd(gsm + d + c * 4 + k, glb[i][k]);
+            }
+        }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < P * d; i += blockDim.x) atomicAdd(d_dec_w + i, gsm[i]);
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
-        atomicAdd(d_ln_w + i, gsm[(size_t)P * d + i]);
-        atomicAdd(d_ln_b + i, gsm[(size_t)(P + 1) * d + i]);
+        atomicAdd(d_ln_w + i, gsm[i]);
+        atomicAdd(d_ln_b + i, gsm[d + i]);
     }
     if (lane < P) atomicAdd(d_dec_b + lane, db_acc);
 }
@@ -401,22 +421,25 @@ extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scal
 
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
                              const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
-                             int coef_stride, float* dX, float* d_dec_w, float* d_dec_b, float* d_ln_w, float* d_ln_b,
-                             hipStream_t s) {
-    const size_t lds = ((size_t)P * d + (size_t)(P + 2) * d) * sizeof(float);
-    if (lds > 160 * 1024 || P > 64) {
-        bsi_set_error("bsi_dit_final_bwd: P=%d d=%d needs %zu B of LDS", P, d, lds);
+                             int coef_stride, float* dX, void* yb, void* dYb, float* d_dec_b, float* d_ln_w,
+                             float* d_ln_b, hipStream_t s) {
+    if (P > 64) {
+        bsi_set_error("bsi_dit_final_bwd: decoder P=%d unsupported (needs patch*patch*C <= 64)", P);
         return BSI_EINVAL;
     }
+    const int Pp = (P + 7) / 8 * 8;
+    const bool wlds = (size_t)(P + 2) * d * sizeof(float) <= 128 * 1024;
+    const size_t lds = (size_t)(wlds ? P + 2 : 2) * d * sizeof(float);
     int grid = (Mtok + 4 * 16 - 1) / (4 * 16);
     if (grid < 1) grid = 1;
-    if (grid > 512) grid = 512;
+    if (grid > 1024) grid = 1024;
 #define LAUNCH_FB(V)                                                                                                   \
     do {                                                                                                               \
-        auto kern = dit_final_bwd_kernel<V>;                                                                           \
+        auto kern = wlds ? dit_final_bwd_kernel<V, true> : dit_final_bwd_kernel<V, false>;                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, ln_w, ln_b, dec_w, C, H, W, ps, g_xhat,   \
-                           c_out, coef_stride, dX, d_dec_w, d_dec_b, d_ln_w, d_ln_b);                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, Pp, ln_w, ln_b, dec_w, C, H, W, ps, g_xhat, \
+                           c_out, coef_stride, dX, reinterpret_cast<__bf16*>(yb), reinterpret_cast<__bf16*>(dYb),       \
+                           d_dec_b, d_ln_w, d_ln_b);                                                                    \
     } while (0)
     if (d <= 256) LAUNCH_FB(1);
     else if (d <= 1024) LAUNCH_FB(4);

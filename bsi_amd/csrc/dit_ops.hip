@@ -187,8 +187,9 @@ __global__ void dit_prologue_kernel(const float* __restrict__ mu, const float* _
 
 // dit.py:163-172,181 (+ bsi.py:382-386): per token LayerNorm(affine) -> Linear(dim -> P=ps*ps*C) in fp32 ->
 // unpatchify -> x_hat = fma(c_out, f, c_skip*mu).  dec_w (P x dim fp32) is staged in LDS once per workgroup;
-// each wave walks tokens with a grid stride.
-template <int VPL>
+// each wave walks tokens with a grid stride.  WLDS = false (decoder larger than the LDS, e.g. DiT-L/4: 48 x 1024 fp32):
+// the weights are read through L1/L2 instead.
+template <int VPL, bool WLDS>
 __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, int P, const float* __restrict__ ln_w,
                                  const float* __restrict__ ln_b, const float* __restrict__ dec_w,
                                  const float* __restrict__ dec_b, int C, int H, int W, int ps,
@@ -198,9 +199,11 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
                                  float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // [P][d]
     const int d4 = d >> 2;
-    for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
-        reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
-    __syncthreads();
+    if constexpr (WLDS) {
+        for (int i = threadIdx.x; i < P * d4; i += blockDim.x)
+            reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(dec_w)[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nw = W / ps;
@@ -257,7 +260,8 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
             for (int i = 0; i < VPL; ++i) {
                 const int c = i * 64 + lane;
                 if (c < d4) {
-                    const f32x4 wv = reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c];
+                    const f32x4 wv = WLDS ? reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c]
+                                          : reinterpret_cast<const f32x4*>(dec_w + (size_t)o * d)[c];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc = __fmaf_rn(v[i][k], wv[k], acc);
                 }
@@ -403,18 +407,20 @@ int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln
                          const float* dec_w, const float* dec_b, int C, int H, int W, int ps, const float* mu,
                          const float* c_skip, const float* c_out, int coef_stride, const void* delta, const float* gate,
                          int gate_rows, int gate_stride, float* out, hipStream_t s) {
-    const size_t lds = (size_t)P * d * sizeof(float);
-    if (lds > 160 * 1024 || P > 64) {
-        bsi_set_error("bsi_dit_final: decoder P=%d d=%d unsupported (needs P <= 64 and P*d*4 <= 160 KiB)", P, d);
+    size_t lds = (size_t)P * d * sizeof(float);
+    if (P > 64) {
+        bsi_set_error("bsi_dit_final: decoder P=%d unsupported (needs patch*patch*C <= 64)", P);
         return BSI_EINVAL;
     }
+    const bool wlds = lds <= 128 * 1024;
+    if (!wlds) lds = 0;
     const int wpb = TPB / 64;
     int grid = (Mtok + wpb * 8 - 1) / (wpb * 8);  // ~8 tokens per wave amortise the LDS fill
     if (grid < 1) grid = 1;
     if (grid > 2048) grid = 2048;
 #define LAUNCH_FINAL(V)                                                                                              \
     do {                                                                                                             \
-        auto kern = dit_final_kernel<V>;                                                                             \
+        auto kern = wlds ? dit_final_kernel<V, true> : dit_final_kernel<V, false>;                                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, ln_w, ln_b, dec_w, dec_b, C, H, W, ps, \
                            mu, c_skip, c_out, coef_stride, reinterpret_cast<const __bf16*>(delta), gate,             \

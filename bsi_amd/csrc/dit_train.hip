@@ -11,8 +11,8 @@
 
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
                              const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
-                             int coef_stride, float* dX, float* d_dec_w, float* d_dec_b, float* d_ln_w, float* d_ln_b,
-                             hipStream_t s);
+                             int coef_stride, float* dX, void* yb, void* dYb, float* d_dec_b, float* d_ln_w,
+                             float* d_ln_b, hipStream_t s);
 
 namespace {
 
@@ -98,6 +98,7 @@ struct BwdWs {
     char* dpre_bf; // bf16 [B, dim]
     char* tn;      // TN GEMM slabs
     char* cs;      // colsum slabs
+    float* decw;   // fp32 [64, dim]   decoder weight gradient with its rows padded to a multiple of 8
     size_t total;
 };
 
@@ -116,6 +117,7 @@ inline BwdWs carve_bwd(const Dims& d, int B, void* base) {
     w.dpre_bf = p + off; off += au((size_t)B * dim * 2);
     w.tn = p + off; off += au(bsi_gemm_tn_workspace_bytes((int)M, 4 * (int)dim, (int)dim));
     w.cs = p + off; off += au(bsi_colsum_workspace_bytes(6 * (int)dim));
+    w.decw = reinterpret_cast<float*>(p + off); off += au((size_t)64 * dim * 4);
     w.total = off;
     return w;
 }
@@ -225,7 +227,6 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
     BwdWs ws = carve_bwd(d, B, workspace);
 
     if (hipMemsetAsync(ws.dmod, 0, (size_t)B * mod_stride * sizeof(float), s) != hipSuccess ||
-        hipMemsetAsync(g->dec_w, 0, (size_t)d.P * dim * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(g->dec_b, 0, (size_t)d.P * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(g->dec_ln_w, 0, (size_t)dim * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(g->dec_ln_b, 0, (size_t)dim * sizeof(float), s) != hipSuccess) {
@@ -233,8 +234,18 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         return BSI_ELAUNCH;
     }
     // decoder: dX = d/dx_final, parameter gradients of patch_decoder (dit.py:163-165)
-    TRY(bsi_dit_final_bwd_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, cfg->C, cfg->H, cfg->W, cfg->patch,
-                                 g_out, c_out, 1, ws.dX, g->dec_w, g->dec_b, g->dec_ln_w, g->dec_ln_b, s));
+    {
+        const int Pp = (d.P + 7) / 8 * 8;  // yb -> ws.dd, dYb -> ws.dsmall (Pp <= 64 <= dim columns)
+        BSI_CHECK_ARG(Pp <= dim, "bsi_dit_backward: decoder width %d exceeds dim %d", Pp, dim);
+        TRY(bsi_dit_final_bwd_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, cfg->C, cfg->H, cfg->W,
+                                     cfg->patch, g_out, c_out, 1, ws.dX, ws.dd, ws.dsmall, g->dec_b, g->dec_ln_w,
+                                     g->dec_ln_b, s));
+        TRY(bsi_gemm_tn_bf16(ws.dsmall, Pp, ws.dd, dim, M, Pp, dim, ws.decw, dim, 0, ws.tn, stream));
+        if (hipMemcpyAsync(g->dec_w, ws.decw, (size_t)d.P * dim * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            bsi_set_error("bsi_dit_backward: decoder gradient copy failed");
+            return BSI_ELAUNCH;
+        }
+    }
 
     for (int l = d.depth - 1; l >= 0; --l) {
         const bsi_dit_block_weights& bw = w->blocks[l];

@@ -224,6 +224,33 @@ def test_full_size_dit_l2_one_forward_vs_oracle():
     assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
+def test_dit_patch4_decoder_larger_than_lds_vs_oracle():
+    """DiT-L/4 geometry (config/experiment/imagenet64.yaml: patch 4 -> 48 decoder outputs x dim 1024 = 192 KB of fp32
+    decoder weights, more than the LDS holds) at depth 1 on a 32x32 image: forward and parameter gradients against
+    autograd through the fp32 CPU oracle."""
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    shape, ps, dim, depth, heads = (3, 32, 32), 4, 1024, 1, 16
+    W = do.dit_random_weights(shape, ps, dim, depth, ff=(6, 8), seed=3)
+    m = DenoisingDiT(shape, ps, dim, depth, heads, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    m.load_state_dict(W)
+    m = m.to(DEV).train()
+    gen = torch.Generator().manual_seed(1)
+    mu = torch.randn((4, *shape), generator=gen)
+    t = torch.rand(4, generator=gen)
+    r = torch.randn((4, *shape), generator=gen)
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    ref = do.dit_forward(Wr, mu, t, patch_size=ps, dim=dim, depth=depth, heads=heads, ff=(6, 8))
+    (ref * r).sum().backward()
+    got = m(mu.to(DEV), t.to(DEV))
+    assert rel_linf(got.detach().cpu(), ref.detach()) < 2e-2
+    (got * r.to(DEV)).sum().backward()
+    for name, p in m.named_parameters():
+        gref = Wr[name].grad
+        err = float((p.grad.cpu().double() - gref.double()).norm() / gref.double().norm().clamp_min(1e-30))
+        assert err < 3e-2, (name, err)
+
+
 def test_train_loss_gradients_vs_golden():
     """BSI.train_loss(...).mean().backward() through the HIP training engine vs the reference's gradients (G4)."""
     for case, tag, ff in [("g4_train_dit", "dit_ff", True), ("g4_train_dit_noff", "dit_noff", False)]:

@@ -144,6 +144,10 @@ _PROTOS = {
     "bsi_clip_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "bsi_conv_nhwc_bf16": (_i, [C.POINTER(ConvArgs), _vp]),
     "bsi_conv_weight_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_conv_weight_pack_t": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_conv_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "bsi_conv_wgrad_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "bsi_conv_wgrad_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "bsi_unet_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "bsi_unet_cin_pad": (_i, [C.POINTER(UNetConfig)]),

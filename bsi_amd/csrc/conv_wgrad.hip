@@ -1,0 +1,278 @@
+// Weight gradient of the 3x3 / 1x1 convolutions of the VDM-UNet path as an IMPLICIT transposed GEMM on bf16 MFMA:
+//   dW[co][tap][ci] = sum_m dY[m, co] * X[m + shift(tap), ci]        (taps that fall outside the image contribute 0)
+//   dWskip[co][c]   = sum_m dY[m, co] * X2[m, c]                      (the 1x1 skip conv folded into conv2's K range)
+// i.e. autograd's conv2d weight gradient (bsi/nn/residual_block.py:40-48, bsi/nn/attention.py:29-30,
+// bsi/models/vdm_unet.py:71 of the reference).  Both operands have the contraction index (pixel m) as the SLOW
+// dimension, exactly like the Linear weight gradient, so the machinery is gemm_tn.hip's: stages of 32 pixels are DMA'd
+// as they lie in memory (NHWC rows) and the MFMA fragments come from ds_read_b64_tr_b16.  The im2col matrix
+// X_col[m][tap*Cin + ci] exists only as source addresses of the DMA: each 16-B chunk of a stage row is fetched from the
+// pixel (y+dy, x+dx) of its tap, or from a zero page.
+//
+// Tile: 128 output channels x 512 im2col columns (four 128-column units); per stage 4 unit sub-tiles + 1 dY sub-tile of
+// [32 pixels][256 B] = 40 KB, 4-slot ring = all 160 KB of LDS.  8 waves = 8 slices of 64 im2col columns, every wave
+// against all 128 dY columns.  The pixel range is split over workgroups; partial tiles go to fp32 slabs summed by
+// reduce_slabs (deterministic).  Output layout = the forward's packed weight layout [Cout][taps*Cin + Cin2].
+#include "common.h"
+
+int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out,
+                            hipStream_t s);
+
+namespace {
+
+struct WgParams {
+    const __bf16* dY;     // [M, ldy]
+    const __bf16* X;      // [M, Cin]
+    const __bf16* X2;     // [M, Cin2] or null
+    const __bf16* zeros;  // >= 256 B of zeros
+    float* out;           // [splits][Cout][Ktot]
+    int M, H, Wd, HW, Cin, Cin2, taps, Cout, ldy, Ktot;
+    int tiles_u, tiles_n, splits, m_per_split;
+    size_t slab_stride;
+};
+
+constexpr int G_RB = 256;          // bytes per sub-tile row (128 bf16 columns)
+constexpr int G_SUB = 32 * G_RB;   // one sub-tile of a stage: 32 pixels
+constexpr int G_SLOT = 5 * G_SUB;  // 4 im2col units + dY = 40 KB
+constexpr int G_R = 4, G_D = G_R - 1;
+
+__device__ __forceinline__ int wg_swz(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
+
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // ping-pong group
+
+    const int tiles = p.tiles_n * p.tiles_u;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int n0 = (tile / p.tiles_u) * 128, u0 = (tile % p.tiles_u) * 4;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 31) / 32;
+    if (nk <= 0) return;  // uniform per workgroup
+
+    // staging: a wave-instruction covers 4 pixel rows x 256 B; wave w fills rows 4w..4w+3 of every sub-tile (5 per stage)
+    const int srow = 4 * wave + (lane >> 4), spos = lane & 15;
+    const int schunk = spos ^ wg_swz(srow);  // source chunk that lands at this lane's LDS position
+    const char* ubase[4];  // source tensor + channel byte offset of this lane's chunk, per unit; null = beyond Ktot
+    int upitch[4], ushift[4], udyx[4];
+    const int conv_k = p.taps * p.Cin;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int vc = (u0 + q) * 128 + schunk * 8;
+        ubase[q] = nullptr; upitch[q] = 0; ushift[q] = 0; udyx[q] = 0;
+        if (vc < conv_k) {
+            const int tap = vc / p.Cin, c = vc - tap * p.Cin;
+            int dy = 0, dx = 0;
+            if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; }
+            ubase[q] = reinterpret_cast<const char*>(p.X + c);
+            upitch[q] = p.Cin * 2;
+            ushift[q] = dy * p.Wd + dx;
+            udyx[q] = ((dy + 1) << 2) | (dx + 1);
+        } else if (vc < p.Ktot) {
+            ubase[q] = reinterpret_cast<const char*>(p.X2 + (vc - conv_k));
+            upitch[q] = p.Cin2 * 2;
+            udyx[q] = (1 << 2) | 1;
+        }
+    }
+    const int ycol = n0 + schunk * 8;
+    const char* ybase = ycol < p.Cout ? reinterpret_cast<const char*>(p.dY + ycol) : nullptr;
+    const char* zsrc = reinterpret_cast<const char*>(p.zeros) + spos * 16;
+
+    auto stage = [&](int v, int slot_i) {
+        char* base = lds + slot_i * G_SLOT + wave * 1024;
+        const int m = mbeg + v * 32 + srow;
+        const bool m_ok = m < mend;
+        const int rem = m % p.HW;
+        const int y = rem / p.Wd, x = rem - y * p.Wd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y + (udyx[q] >> 2) - 1, xx = x + (udyx[q] & 3) - 1;
+            const bool ok = m_ok && ubase[q] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+            const char* src = ok ? ubase[q] + (size_t)(m + ushift[q]) * upitch[q] : zsrc;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * G_SUB), 16, 0, 0);
+        }
+        const char* src = (m_ok && ybase) ? ybase + (size_t)m * p.ldy * 2 : zsrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + 4 * G_SUB), 16, 0, 0);
+    };
+
+    // fragments (gemm_tn.hip): lane = (q4, qp, pp): q4 = lane>>4 selects pixels 8q4..8q4+7 of the stage, qp the row inside
+    // a 4-row transpose block, pp the 4-column quad
+    const int q4 = lane >> 4, qp = (lane & 15) >> 2, pp = lane & 3;
+    const int mA = 8 * q4 + qp, mB = mA + 4;
+    const int swA = wg_swz(mA), swB = wg_swz(mB);
+    const int rowA = mA * G_RB, rowB = mB * G_RB;
+    const int half8 = 8 * (pp & 1), chp = pp >> 1;
+    const int xunit = (wave >> 1) * G_SUB, xch0 = (wave & 1) * 8;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4], bf[8];
+
+#define WG_BARRIER()                             \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#define TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
+
+    auto load_frags = [&](const char* b) {
+        union U { bf16x8 v; s16x4 h[2]; };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // im2col columns 64*(wave&1) + 16i + 4pp of unit wave>>1
+            const int ch = xch0 + 2 * i + chp;
+            U u;
+            u.h[0] = TR(b + xunit + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + xunit + rowB + ((ch ^ swB) << 4) + half8);
+            af[i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // dY columns 16j + 4pp
+            const int ch = 2 * j + chp;
+            U u;
+            u.h[0] = TR(b + 4 * G_SUB + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + 4 * G_SUB + rowB + ((ch ^ swB) << 4) + half8);
+            bf[j] = u.v;
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < G_D; ++d)
+        if (d < nk) stage(d, d);
+    if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_BARRIER();
+    if (grp == 1) WG_BARRIER();
+
+    int slot = 0, pslot = G_D;
+    for (int v = 0; v < nk; ++v) {
+        load_frags(lds + slot * G_SLOT);
+        if (v + G_D < nk) {
+            stage(v + G_D, pslot);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WG_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        WG_BARRIER();
+        slot = (slot == G_R - 1) ? 0 : slot + 1;
+        pslot = (pslot == G_R - 1) ? 0 : pslot + 1;
+    }
+    if (grp == 0) WG_BARRIER();
+#undef WG_BARRIER
+#undef TR
+
+    // D rows = im2col column (4*(lane>>4) + reg inside slice tile i), D cols = output channel (lane & 15 inside tile j)
+    float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 16 * j + (lane & 15);
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = u0 * 128 + 64 * wave + 16 * i + 4 * q4;
+            if (k < p.Ktot) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(out + (size_t)n * p.Ktot + k));
+        }
+    }
+}
+
+int g_wg_cus = 0;
+
+void plan(WgParams& p) {
+    if (g_wg_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_wg_cus = prop.multiProcessorCount;
+        if (g_wg_cus <= 0) g_wg_cus = 256;
+    }
+    p.tiles_u = (p.Ktot + 511) / 512;
+    p.tiles_n = (p.Cout + 127) / 128;
+    const int tiles = p.tiles_u * p.tiles_n;
+    int s = (g_wg_cus + tiles - 1) / tiles;
+    const int max_s = (p.M + 255) / 256;  // at least 8 stages per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    int mps = (p.M + s - 1) / s;
+    mps = (mps + 31) / 32 * 32;
+    p.m_per_split = mps;
+    p.splits = (p.M + mps - 1) / mps;
+    p.slab_stride = (size_t)p.Cout * p.Ktot;
+}
+
+// packed fp32 [Cout][ld] (K index (tap, channel), channels padded to cin_pad, columns from col0) -> torch Conv2d layout
+// [Cout][Cin][taps]; accumulate != 0 adds.
+__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ packed, int Cout, int Cin, int taps, int cin_pad, int ld,
+                                         int col0, int accumulate, float* __restrict__ out) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int c = (int)((i / taps) % Cin);
+        const int o = (int)(i / ((size_t)taps * Cin));
+        const float v = packed[(size_t)o * ld + col0 + tap * cin_pad + c];
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int Cout, int taps) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    WgParams p{};
+    p.M = M; p.Cin = Cin; p.Cin2 = Cin2; p.Cout = Cout; p.taps = taps; p.Ktot = taps * Cin + Cin2;
+    plan(p);
+    return (size_t)p.splits * p.slab_stride * sizeof(float);
+}
+
+extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B,
+                                        int H, int W, int Cin, int Cin2, int Cout, int taps, float* out_packed, int accumulate,
+                                        void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dy && x && zeros && out_packed && workspace, "bsi_conv_wgrad: null pointer");
+    BSI_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 9 || taps == 1), "bsi_conv_wgrad: bad sizes");
+    BSI_CHECK_ARG(Cin % 8 == 0 && Cin2 % 8 == 0 && Cout % 8 == 0 && ldy % 8 == 0 && ldy >= Cout,
+                  "bsi_conv_wgrad: Cin=%d Cin2=%d Cout=%d ldy=%d must be multiples of 8", Cin, Cin2, Cout, ldy);
+    BSI_CHECK_ARG(Cin2 == 0 || x2, "bsi_conv_wgrad: second source missing");
+    WgParams p{};
+    p.dY = reinterpret_cast<const __bf16*>(dy);
+    p.X = reinterpret_cast<const __bf16*>(x);
+    p.X2 = reinterpret_cast<const __bf16*>(x2);
+    p.zeros = reinterpret_cast<const __bf16*>(zeros);
+    p.out = reinterpret_cast<float*>(workspace);
+    p.M = B * H * W; p.H = H; p.Wd = W; p.HW = H * W; p.Cin = Cin; p.Cin2 = Cin2; p.taps = taps; p.Cout = Cout; p.ldy = ldy;
+    p.Ktot = taps * Cin + Cin2;
+    plan(p);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  G_R * G_SLOT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_u * p.splits), dim3(512), G_R * G_SLOT, s, p);
+    BSI_CHECK_LAUNCH("bsi_conv_wgrad");
+    return bsi_reduce_slabs_launch(p.out, p.slab_stride, p.splits, p.slab_stride, accumulate, out_packed, s);
+}
+
+extern "C" int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int cin_pad, int ld, int col0,
+                                     int accumulate, float* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(packed && out && Cout > 0 && Cin > 0 && taps > 0 && cin_pad >= Cin && ld >= col0 + taps * cin_pad,
+                  "bsi_conv_wgrad_unpack: bad args");
+    const size_t total = (size_t)Cout * Cin * taps;
+    size_t g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), packed, Cout,
+                       Cin, taps, cin_pad, ld, col0, accumulate, out);
+    BSI_CHECK_LAUNCH("bsi_conv_wgrad_unpack");
+    return BSI_OK;
+}

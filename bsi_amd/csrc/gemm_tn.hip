@@ -246,6 +246,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 
 }  // namespace
 
+// out[0..n) (+)= sum over `splits` slabs (n a multiple of 4); shared with conv_wgrad.hip
+int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out,
+                            hipStream_t s) {
+    const size_t n4 = n / 4;
+    size_t g = (n4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, s, slabs, slab_stride, splits, n4, accumulate, out);
+    BSI_CHECK_LAUNCH("bsi_reduce_slabs");
+    return BSI_OK;
+}
+
 extern "C" size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K) {
     // worst case number of splits is 16
     return (size_t)16 * (size_t)N * (size_t)K * sizeof(float);
@@ -294,14 +306,8 @@ extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, 
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");
-    if (!direct) {
-        const size_t n4 = (size_t)N * ldc / 4;
-        size_t g = (n4 + 255) / 256;
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace),
-                           p.slab_stride, p.splits, n4, accumulate, out);
-        BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16(reduce)");
-    }
+    if (!direct) return bsi_reduce_slabs_launch(reinterpret_cast<const float*>(workspace), p.slab_stride, p.splits, (size_t)N * ldc,
+                                                accumulate, out, s);
     return BSI_OK;
 }
 

@@ -119,9 +119,33 @@ __global__ void conv_weight_pack_kernel(const float* __restrict__ w, int Cout, i
     }
 }
 
+// fp32 Conv2d weight [Cout][Cin][taps] -> bf16 [Cin][ld] with out[ci][(taps-1-tap)*Cout + co] = w[co][ci][tap]: the weights
+// of the input-gradient convolution (180-degree rotated taps, channels swapped), in the forward kernel's packed layout.
+__global__ void conv_weight_pack_t_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int ld,
+                                          __bf16* __restrict__ out) {
+    const size_t total = (size_t)Cin * taps * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Cout);
+        const int tap = (int)((i / Cout) % taps);
+        const int c = (int)(i / ((size_t)Cout * taps));
+        out[(size_t)c * ld + (taps - 1 - tap) * Cout + o] = (__bf16)w[((size_t)o * Cin + c) * taps + tap];
+    }
+}
+
 }  // namespace
 
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int bsi_conv_weight_pack_t(const float* w, int Cout, int Cin, int taps, int ld, void* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && taps > 0 && ld >= taps * Cout, "bsi_conv_weight_pack_t: bad args");
+    const size_t total = (size_t)Cin * taps * Cout;
+    size_t g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(conv_weight_pack_t_kernel, dim3((int)g), dim3(256), 0, S(stream), w, Cout, Cin, taps, ld,
+                       reinterpret_cast<__bf16*>(out));
+    BSI_CHECK_LAUNCH("bsi_conv_weight_pack_t");
+    return BSI_OK;
+}
 
 extern "C" int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                                   const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16,

@@ -302,6 +302,22 @@ int bsi_conv_nhwc_bf16(const bsi_conv_args* a /*host*/, bsi_stream_t stream);
 /* fp32 Conv2d weight [Cout][Cin][kh][kw] -> bf16 [Cout][ld] at column col0 with K index (tap, channel), Cin padded. */
 int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, void* out,
                          bsi_stream_t stream);
+/* Weights of the INPUT-gradient convolution: fp32 [Cout][Cin][taps] -> bf16 [Cin][ld],
+ * out[ci][(taps-1-tap)*Cout + co] = w[co][ci][tap] (taps rotated by 180 degrees, channels swapped); feeding it to
+ * bsi_conv_nhwc_bf16 with dY as the input computes autograd's conv2d input gradient. */
+int bsi_conv_weight_pack_t(const float* w, int Cout, int Cin, int taps, int ld, void* out, bsi_stream_t stream);
+/* WEIGHT gradient of bsi_conv_nhwc_bf16 (autograd of nn.Conv2d w.r.t. weight, residual_block.py:40-48, attention.py:29-30):
+ *   out_packed[co][tap*Cin + ci] (+)= sum_m dy[m, co] * x[pixel m shifted by tap, ci]   (zero outside the image)
+ *   out_packed[co][taps*Cin + c] (+)= sum_m dy[m, co] * x2[m, c]                        (folded 1x1 skip conv)
+ * dy bf16 [B*H*W, ldy], x bf16 NHWC [B*H*W, Cin], x2 bf16 [B*H*W, Cin2] or NULL; channel counts multiples of 8;
+ * zeros: >= 256 bytes of zeros.  fp32 result in the packed layout of bsi_conv_weight_pack; bsi_conv_wgrad_unpack
+ * converts to the nn.Conv2d layout [Cout][Cin][kh][kw].  Deterministic (split-M slabs in `workspace`). */
+size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int Cout, int taps);
+int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
+                             int Cin, int Cin2, int Cout, int taps, float* out_packed, int accumulate, void* workspace,
+                             bsi_stream_t stream);
+int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, int accumulate,
+                          float* out, bsi_stream_t stream);
 /* GroupNorm(32 groups, affine, eps) over cat(x1, x2) channels (x2 nullable) per image, optional SiLU -> bf16 NHWC
  * (residual_block.py:42-43, vdm_unet.py:52,84); raw_bf16 (nullable) receives the un-normalised bf16 copy. */
 int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,

@@ -517,3 +517,54 @@ def test_groupnorm_nhwc(N, B, HW, C1, C2, silu):
                                        N.ptr(dev(be)), 1e-5, silu, N.ptr(out), N.ptr(raw), N.stream()))
     assert float((out.cpu().double() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8 + 1e-3
     assert torch.equal(raw.cpu(), xc.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cin2,Cout,taps", [(2, 8, 8, 128, 0, 128, 9), (3, 16, 16, 256, 256, 128, 9),
+                                                     (2, 16, 8, 32, 0, 128, 9), (2, 8, 8, 128, 0, 384, 9),
+                                                     (5, 16, 16, 384, 0, 128, 9), (2, 8, 8, 256, 0, 128, 1)])
+def test_conv_weight_and_input_gradients(N, B, H, W, Cin, Cin2, Cout, taps):
+    """bsi_conv_wgrad_nhwc_bf16 (+ unpack) and the input-gradient convolution (bsi_conv_weight_pack_t + the forward
+    kernel) against autograd of torch.nn.functional.conv2d in float64."""
+    gen = torch.Generator().manual_seed(B + H + Cin + Cout + taps)
+    ks = 3 if taps == 9 else 1
+    x = bf16r(torch.randn((B, Cin, H, W), generator=gen)).double().requires_grad_(True)
+    w = bf16r(torch.randn((Cout, Cin, ks, ks), generator=gen) / math.sqrt(Cin * taps)).double().requires_grad_(True)
+    dy = bf16r(torch.randn((B, Cout, H, W), generator=gen))
+    y = torch.nn.functional.conv2d(x, w, padding=ks // 2)
+    x2 = w2 = None
+    if Cin2:
+        x2 = bf16r(torch.randn((B, Cin2, H, W), generator=gen)).double()
+        w2 = bf16r(torch.randn((Cout, Cin2, 1, 1), generator=gen) / math.sqrt(Cin2)).double().requires_grad_(True)
+        y = y + torch.nn.functional.conv2d(x2, w2)
+    y.backward(dy.double())
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    M, K = B * H * W, taps * Cin + Cin2
+    dyd = dev(_nhwc(dy).reshape(M, Cout).to(torch.bfloat16))
+    xd = dev(_nhwc(x.detach().float()).reshape(M, Cin).to(torch.bfloat16))
+    x2d = dev(_nhwc(x2.float()).reshape(M, Cin2).to(torch.bfloat16)) if Cin2 else None
+    lib = N.lib()
+    ws = empty(lib.bsi_conv_wgrad_workspace_bytes(M, Cin, Cin2, Cout, taps), dtype=torch.uint8)
+    packed = empty(Cout, K)
+    N.check(lib.bsi_conv_wgrad_nhwc_bf16(N.ptr(dyd), Cout, N.ptr(xd), N.ptr(x2d) if Cin2 else None, N.ptr(zeros), B, H, W, Cin,
+                                         Cin2, Cout, taps, N.ptr(packed), 0, N.ptr(ws), N.stream()))
+    gw = empty(Cout, Cin, ks, ks)
+    N.check(lib.bsi_conv_wgrad_unpack(N.ptr(packed), Cout, Cin, taps, Cin, K, 0, 0, N.ptr(gw), N.stream()))
+    assert rel_linf(gw, w.grad) < 2e-5, rel_linf(gw, w.grad)
+    if Cin2:
+        gw2 = empty(Cout, Cin2, 1, 1)
+        N.check(lib.bsi_conv_wgrad_unpack(N.ptr(packed), Cout, Cin2, 1, Cin2, K, taps * Cin, 0, N.ptr(gw2), N.stream()))
+        assert rel_linf(gw2, w2.grad) < 2e-5
+    # accumulate flag
+    N.check(lib.bsi_conv_wgrad_nhwc_bf16(N.ptr(dyd), Cout, N.ptr(xd), N.ptr(x2d) if Cin2 else None, N.ptr(zeros), B, H, W, Cin,
+                                         Cin2, Cout, taps, N.ptr(packed), 1, N.ptr(ws), N.stream()))
+    N.check(lib.bsi_conv_wgrad_unpack(N.ptr(packed), Cout, Cin, taps, Cin, K, 0, 1, N.ptr(gw), N.stream()))
+    assert rel_linf(gw, 3 * w.grad) < 2e-5
+    # input gradient = convolution of dY with the rotated, channel-swapped weights
+    if Cout % 32 == 0 and Cin % 16 == 0:
+        wt = empty(Cin, taps * Cout, dtype=torch.bfloat16)
+        N.check(lib.bsi_conv_weight_pack_t(N.ptr(dev(w.detach().float())), Cout, Cin, taps, taps * Cout, N.ptr(wt), N.stream()))
+        dx = empty(M, Cin)
+        a = N.ConvArgs(x=dyd.data_ptr(), w=wt.data_ptr(), zeros=zeros.data_ptr(), out=dx.data_ptr(), B=B, H=H, W=W, Cin=Cout,
+                       Cin2=0, Cout=Cin, taps=taps, ldo=Cin, epilogue=N.CONV_BIAS_RESID_F32)
+        N.check(lib.bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+        assert rel_linf(dx, _nhwc(x.grad).reshape(M, Cin)) < 2e-5, rel_linf(dx, _nhwc(x.grad).reshape(M, Cin))

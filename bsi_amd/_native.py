@@ -149,6 +149,10 @@ _PROTOS = {
     "bsi_conv_wgrad_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "bsi_conv_wgrad_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "bsi_groupnorm_bwd_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_film_silu": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
+    "bsi_film_silu_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp, _i, _vp]),
+    "bsi_unet_decode_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "bsi_unet_decode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "bsi_unet_cin_pad": (_i, [C.POINTER(UNetConfig)]),
     "bsi_unet_workspace_bytes": (_sz, [C.POINTER(UNetConfig), _i]),

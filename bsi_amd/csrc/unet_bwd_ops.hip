@@ -1,0 +1,341 @@
+// Memory-bound kernels of the VDM-UNet TRAINING path (autograd of bsi/nn/residual_block.py:21-24,40-48,61-64 and
+// bsi/models/vdm_unet.py:72,100 of the reference): FiLM + SiLU + Dropout forward/backward, GroupNorm(+SiLU) backward,
+// backward of the fp32 1x1 decode convolution.
+#include <math.h>
+
+#include "common.h"
+#include "dit_ops.h"
+#include "unet_ops.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 w, float* v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(w[e] << 16);
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+
+// y = Dropout(SiLU(h1 * (scale + 1) + shift))  (FeatureModulation: addcmul(shift, scale + 1, y), residual_block.py:21-24,
+// then ActFn and nn.Dropout, :44-46).  h1, y bf16 [M, N]; film row of pixel m = (m / HW) % film_rows.
+__global__ void film_silu_drop_kernel(const __bf16* __restrict__ h1, size_t M, int N, int HW, const float* __restrict__ film,
+                                      int film_rows, int film_stride, DropCfg dc, __bf16* __restrict__ y) {
+    const int n8 = N / 8;
+    const size_t total = M * n8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / n8;
+        const int c = (int)(i % n8) * 8;
+        const float* fr = film + (size_t)((m / HW) % film_rows) * film_stride;
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(h1 + m * N + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u = silu_f(__fmaf_rn(fr[c + e] + 1.0f, v[e], fr[N + c + e]));
+            if (dc.thr) u = drop_keep(dc, (unsigned long long)m * N + c + e) ? u * dc.scale : 0.0f;
+            v[e] = u;
+        }
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(y + m * N + c) = w;
+    }
+}
+
+// Backward of the above: dU = dy * mask/(1-p) * silu'(u), u = h1*(scale+1)+shift;
+//   dh1 = dU * (scale + 1)  (bf16),  dscale[b, n] += sum_p dU * h1,  dshift[b, n] += sum_p dU.
+// One workgroup (256 threads) per slab of FB_ROWS pixels of one image; thread = (8-channel chunk, pixel sub-row).
+constexpr int FB_ROWS = 64;
+__global__ __launch_bounds__(256) void film_silu_bwd_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ h1, int N,
+                                                            int HW, const float* __restrict__ film, int film_rows,
+                                                            int film_stride, DropCfg dc, __bf16* __restrict__ dh1,
+                                                            float* __restrict__ dfilm, int dfilm_stride) {
+    __shared__ float red[2][256 * 8];
+    const int n8 = N / 8;            // chunks per pixel (8, 16)
+    const int rows_par = 256 / n8;   // pixel rows handled in parallel
+    const int ch = threadIdx.x % n8, sub = threadIdx.x / n8;
+    const int c = ch * 8;
+    const size_t m0 = (size_t)blockIdx.x * FB_ROWS;
+    const int b = (int)(m0 / HW);
+    const float* fr = film + (size_t)(b % film_rows) * film_stride;
+    float sc1[8], sh[8], gs[8], gh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc1[e] = fr[c + e] + 1.0f; sh[e] = fr[N + c + e]; gs[e] = 0.f; gh[e] = 0.f; }
+    for (int r = sub; r < FB_ROWS; r += rows_par) {
+        const size_t m = m0 + r;
+        float g[8], h[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + m * N + c), g);
+        unpack8(*reinterpret_cast<const u32x4*>(h1 + m * N + c), h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float du = g[e] * silu_grad_f(__fmaf_rn(sc1[e], h[e], sh[e]));
+            if (dc.thr) du = drop_keep(dc, (unsigned long long)m * N + c + e) ? du * dc.scale : 0.0f;
+            gs[e] = __fmaf_rn(du, h[e], gs[e]);
+            gh[e] += du;
+            g[e] = du * sc1[e];
+        }
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(g[2 * e], g[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(dh1 + m * N + c) = w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = gs[e]; red[1][threadIdx.x * 8 + e] = gh[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * N; i += 256) {
+        const int which = i / N, n = i % N;
+        float a = 0.f;
+        for (int s = 0; s < rows_par; ++s) a += red[which][(s * n8 + n / 8) * 8 + (n & 7)];
+        atomicAdd(dfilm + (size_t)b * dfilm_stride + which * N + n, a);
+    }
+}
+
+// Backward of GroupNorm(32, affine)(+ SiLU) over cat(x1, x2) of one image (see groupnorm_kernel):
+//   z = n*gamma + beta, n = (x - mean)*rstd;  dz = da * silu'(z) (or da);  dgamma += sum dz*n, dbeta += sum dz,
+//   dn = dz*gamma;  dx = rstd * (dn - mean_g(dn) - n * mean_g(dn * n));   out = dx (+ add) (+ add_b on the x1 part).
+// One workgroup of 1024 threads per image, three passes (statistics; group sums and affine gradients; write).
+__global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __restrict__ da, const float* __restrict__ x1, int C1,
+                                                             const float* __restrict__ x2, int C2, int HW,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int silu, const float* __restrict__ add,
+                                                             const float* __restrict__ add_b, float* __restrict__ out1,
+                                                             float* __restrict__ out2, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    __shared__ float red_s[2048], red_q[2048];
+    __shared__ float red_g[4096], red_b[4096];  // [pixel row][channel]
+    __shared__ float mean_s[32], rstd_s[32], m1_s[32], m2_s[32];
+    const int C = C1 + C2, CH4 = C / 4, cpg = C / 32;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ch = t % CH4, prow = t / CH4, PPI = 1024 / CH4;
+    const int c0 = ch * 4;
+    const bool second = c0 >= C1;
+    const float* src = second ? x2 + (size_t)b * HW * C2 + (c0 - C1) : x1 + (size_t)b * HW * C1 + c0;
+    const int sstride = second ? C2 : C1;
+    const int NS = CH4 * 2;
+    // ---- pass 0: statistics
+    {
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        for (int p = prow; p < HW; p += PPI) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+            s0 += v[0] + v[1];
+            q0 += v[0] * v[0] + v[1] * v[1];
+            s1 += v[2] + v[3];
+            q1 += v[2] * v[2] + v[3] * v[3];
+        }
+        red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+        red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < PPI; ++r)
+            for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+        const float n = (float)HW * cpg;
+        const float mean = ts / n;
+        mean_s[t] = mean;
+        rstd_s[t] = 1.0f / sqrtf(fmaxf(tq / n - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(c0 + k) / cpg]; rstd[k] = rstd_s[(c0 + k) / cpg]; }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    const __bf16* dap = da + (size_t)b * HW * C + c0;
+    auto dz_of = [&](const f32x4 v, const u32x2 gw, float* nrm, float* dz) {
+        const float g[4] = {__uint_as_float(gw[0] << 16), __uint_as_float(gw[0] & 0xffff0000u), __uint_as_float(gw[1] << 16),
+                            __uint_as_float(gw[1] & 0xffff0000u)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nrm[k] = (v[k] - mean[k]) * rstd[k];
+            dz[k] = silu ? g[k] * silu_grad_f(__fmaf_rn(nrm[k], ga[k], be[k])) : g[k];
+        }
+    };
+    // ---- pass 1: group sums of dn and dn*n, per-channel dgamma / dbeta
+    {
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f, gg[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = prow; p < HW; p += PPI) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+            const u32x2 gw = *reinterpret_cast<const u32x2*>(dap + (size_t)p * C);
+            float nrm[4], dz[4];
+            dz_of(v, gw, nrm, dz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gg[k] = __fmaf_rn(dz[k], nrm[k], gg[k]); gb[k] += dz[k]; }
+            const float d0 = dz[0] * ga[0], d1 = dz[1] * ga[1], d2 = dz[2] * ga[2], d3 = dz[3] * ga[3];
+            s0 += d0 + d1; q0 += d0 * nrm[0] + d1 * nrm[1];
+            s1 += d2 + d3; q1 += d2 * nrm[2] + d3 * nrm[3];
+        }
+        red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+        red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red_g[prow * C + c0 + k] = gg[k]; red_b[prow * C + c0 + k] = gb[k]; }
+    }
+    __syncthreads();
+    if (t < 32) {
+        const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < PPI; ++r)
+            for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+        const float n = (float)HW * cpg;
+        m1_s[t] = ts / n;
+        m2_s[t] = tq / n;
+    }
+    if (t >= 64 && t < 64 + C) {
+        const int c = t - 64;
+        float a = 0.f, bb = 0.f;
+        for (int r = 0; r < PPI; ++r) { a += red_g[r * C + c]; bb += red_b[r * C + c]; }
+        atomicAdd(dgamma + c, a);
+        atomicAdd(dbeta + c, bb);
+    }
+    __syncthreads();
+    float m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { m1[k] = m1_s[(c0 + k) / cpg]; m2[k] = m2_s[(c0 + k) / cpg]; }
+    // ---- pass 2: dx
+    float* dst = second ? out2 + (size_t)b * HW * C2 + (c0 - C1) : out1 + (size_t)b * HW * C1 + c0;
+    const float* ab = (!second && add_b) ? add_b + (size_t)b * HW * C1 + c0 : nullptr;
+    const float* aa = add ? add + (size_t)b * HW * C + c0 : nullptr;
+    for (int p = prow; p < HW; p += PPI) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+        const u32x2 gw = *reinterpret_cast<const u32x2*>(dap + (size_t)p * C);
+        float nrm[4], dz[4];
+        dz_of(v, gw, nrm, dz);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (dz[k] * ga[k] - m1[k] - nrm[k] * m2[k]);
+        if (aa) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(aa + (size_t)p * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += a4[k];
+        }
+        if (ab) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + (size_t)p * C1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += a4[k];
+        }
+        *reinterpret_cast<f32x4*>(dst + (size_t)p * sstride) = o;
+    }
+}
+
+// Backward of unet_decode_kernel: dY[m, o] = c_out[b] * g_xhat[b, o, pix];  dh[m, :] = sum_o dY[m, o] * w[o, :];
+// dw[o, :] += sum_m dY[m, o] * h[m, :];  db[o] += sum_m dY[m, o].  One workgroup per slab of 256 pixels.
+constexpr int DB_PIX = 256;
+__global__ __launch_bounds__(256) void unet_decode_bwd_kernel(const float* __restrict__ g_xhat, const float* __restrict__ c_out,
+                                                              int coef_stride, const float* __restrict__ h, int M, int C,
+                                                              int HW, const float* __restrict__ w, int Cout,
+                                                              float* __restrict__ dh, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+    __shared__ float dys[DB_PIX][4];
+    __shared__ float red[256][4];
+    const int m0 = blockIdx.x * DB_PIX;
+    {
+        const int m = m0 + threadIdx.x;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+            const int b = m / HW, pix = m % HW;
+            const float co = c_out ? c_out[(size_t)b * coef_stride] : 1.0f;
+            for (int o = 0; o < Cout; ++o) v[o] = co * g_xhat[((size_t)b * Cout + o) * HW + pix];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            dys[threadIdx.x][o] = v[o];
+            const float s = wave_sum(v[o]);
+            if ((threadIdx.x & 63) == 0 && o < Cout) atomicAdd(db + o, s);
+        }
+    }
+    __syncthreads();
+    const int c = threadIdx.x % C, sub = threadIdx.x / C, S = 256 / C;
+    float wv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) wv[o] = o < Cout ? w[(size_t)o * C + c] : 0.f;
+    for (int p = sub; p < DB_PIX && m0 + p < M; p += S) {
+        const float hv = h[(size_t)(m0 + p) * C + c];
+        float d = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o] = __fmaf_rn(dys[p][o], hv, acc[o]);
+            d = __fmaf_rn(dys[p][o], wv[o], d);
+        }
+        dh[(size_t)(m0 + p) * C + c] = d;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) red[threadIdx.x][o] = acc[o];
+    __syncthreads();
+    if (sub == 0) {
+        for (int o = 0; o < Cout; ++o) {
+            float a = 0.f;
+            for (int s = 0; s < S; ++s) a += red[s * C + c][o];
+            atomicAdd(dw + (size_t)o * C + c, a);
+        }
+    }
+}
+
+}  // namespace
+
+#define S_(stream) reinterpret_cast<hipStream_t>(stream)
+
+int bsi_film_silu_drop(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride, DropCfg dc,
+                       void* y, bsi_stream_t stream) {
+    BSI_CHECK_ARG(h1 && film && y && M > 0 && N > 0 && N % 8 == 0 && HW > 0 && film_rows > 0, "bsi_film_silu: bad args");
+    size_t g = ((size_t)M * (N / 8) + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(film_silu_drop_kernel, dim3((int)g), dim3(256), 0, S_(stream), reinterpret_cast<const __bf16*>(h1), (size_t)M,
+                       N, HW, film, film_rows, film_stride, dc, reinterpret_cast<__bf16*>(y));
+    BSI_CHECK_LAUNCH("bsi_film_silu");
+    return BSI_OK;
+}
+
+int bsi_film_silu_bwd_drop(const void* dy, const void* h1, int M, int N, int HW, const float* film, int film_rows,
+                           int film_stride, DropCfg dc, void* dh1, float* dfilm, int dfilm_stride, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dy && h1 && film && dh1 && dfilm && M > 0, "bsi_film_silu_bwd: bad args");
+    BSI_CHECK_ARG((N == 64 || N == 128) && HW % FB_ROWS == 0 && M % HW == 0 && film_rows > 0,
+                  "bsi_film_silu_bwd: N=%d (64 or 128), HW=%d (multiple of %d)", N, HW, FB_ROWS);
+    hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(M / FB_ROWS), dim3(256), 0, S_(stream), reinterpret_cast<const __bf16*>(dy),
+                       reinterpret_cast<const __bf16*>(h1), N, HW, film, film_rows, film_stride, dc,
+                       reinterpret_cast<__bf16*>(dh1), dfilm, dfilm_stride);
+    BSI_CHECK_LAUNCH("bsi_film_silu_bwd");
+    return BSI_OK;
+}
+
+extern "C" int bsi_film_silu(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride,
+                             float dropout_p, unsigned long long seed, unsigned site, void* y, bsi_stream_t stream) {
+    return bsi_film_silu_drop(h1, M, N, HW, film, film_rows, film_stride, make_drop(dropout_p, seed, site), y, stream);
+}
+
+extern "C" int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, int HW, const float* film, int film_rows,
+                                 int film_stride, float dropout_p, unsigned long long seed, unsigned site, void* dh1,
+                                 float* dfilm, int dfilm_stride, bsi_stream_t stream) {
+    return bsi_film_silu_bwd_drop(dy, h1, M, N, HW, film, film_rows, film_stride, make_drop(dropout_p, seed, site), dh1, dfilm,
+                                  dfilm_stride, stream);
+}
+
+extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
+                                      const float* gamma, const float* beta, float eps, int silu, const float* add,
+                                      const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
+                                      bsi_stream_t stream) {
+    BSI_CHECK_ARG(da && x1 && gamma && beta && out1 && dgamma && dbeta && B > 0 && HW > 0, "bsi_groupnorm_bwd_nhwc: bad args");
+    const int C = C1 + C2;
+    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 4 == 0 && C2 % 4 == 0 && (C2 == 0 || (x2 && out2)),
+                  "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
+    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B), dim3(1024), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
+                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta);
+    BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
+    return BSI_OK;
+}
+
+extern "C" int bsi_unet_decode_bwd(const float* g_xhat, const float* c_out, int coef_stride, const float* h, int B, int HW, int C,
+                                   const float* w, int Cout, float* dh, float* dw, float* db, bsi_stream_t stream) {
+    BSI_CHECK_ARG(g_xhat && h && w && dh && dw && db && B > 0 && HW > 0, "bsi_unet_decode_bwd: bad args");
+    BSI_CHECK_ARG(Cout >= 1 && Cout <= 4 && C >= 1 && C <= 256 && 256 % C == 0, "bsi_unet_decode_bwd: Cout=%d (<= 4), C=%d (divides 256)",
+                  Cout, C);
+    const int M = B * HW;
+    hipLaunchKernelGGL(unet_decode_bwd_kernel, dim3((M + DB_PIX - 1) / DB_PIX), dim3(256), 0, S_(stream), g_xhat, c_out, coef_stride,
+                       h, M, C, HW, w, Cout, dh, dw, db);
+    BSI_CHECK_LAUNCH("bsi_unet_decode_bwd");
+    return BSI_OK;
+}

@@ -322,6 +322,24 @@ int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int 
  * (residual_block.py:42-43, vdm_unet.py:52,84); raw_bf16 (nullable) receives the un-normalised bf16 copy. */
 int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                        const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16, bsi_stream_t stream);
+/* Backward of bsi_groupnorm_nhwc: da bf16 [B*HW, C1+C2] is the gradient of the (SiLU'd) output.
+ *   out1 [B*HW, C1] = dx1 (+ add[:, :C1]) (+ add_b),  out2 [B*HW, C2] = dx2 (+ add[:, C1:]);  add: fp32 [B*HW, C1+C2] or NULL,
+ *   add_b: fp32 [B*HW, C1] or NULL (out1 may alias add when C2 == 0);  dgamma, dbeta [C1+C2] are ACCUMULATED (atomics). */
+int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
+                           const float* gamma, const float* beta, float eps, int silu, const float* add, const float* add_b,
+                           float* out1, float* out2, float* dgamma, float* dbeta, bsi_stream_t stream);
+/* Training form of the FiLM stage (residual_block.py:21-24,44-46): y = Dropout_p(SiLU(h1*(scale+1)+shift)), h1 and y bf16
+ * [M, N], film fp32 rows (scale at [0,N), shift at [N,2N)) selected by (m / HW) % film_rows; the dropout mask is the
+ * counter hash of (seed, site, m*N+n) (bsi_dropout_mask exports the same mask).  _bwd: dh1 = bf16(dU*(scale+1)) with
+ * dU = dy*mask/(1-p)*silu'(u); dfilm[b, n] += sum dU*h1, dfilm[b, N+n] += sum dU (atomics; N 64 or 128, HW % 64 == 0). */
+int bsi_film_silu(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride, float dropout_p,
+                  unsigned long long seed, unsigned site, void* y, bsi_stream_t stream);
+int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride,
+                      float dropout_p, unsigned long long seed, unsigned site, void* dh1, float* dfilm, int dfilm_stride,
+                      bsi_stream_t stream);
+/* Backward of bsi_unet_decode: dh fp32 [B*HW, C] is written; dw [Cout, C] and db [Cout] are ACCUMULATED. */
+int bsi_unet_decode_bwd(const float* g_xhat, const float* c_out, int coef_stride, const float* h, int B, int HW, int C,
+                        const float* w, int Cout, float* dh, float* dw, float* db, bsi_stream_t stream);
 /* decode Conv2d(C -> Cout, 1x1) in fp32 on NHWC fp32 h, NCHW output, fused x_hat = c_skip*mu + c_out*f. */
 int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout, const float* mu,
                     const float* c_skip, const float* c_out, int coef_stride, float* out, bsi_stream_t stream);

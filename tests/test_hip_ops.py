@@ -568,3 +568,85 @@ def test_conv_weight_and_input_gradients(N, B, H, W, Cin, Cin2, Cout, taps):
                        Cin2=0, Cout=Cin, taps=taps, ldo=Cin, epilogue=N.CONV_BIAS_RESID_F32)
         N.check(lib.bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
         assert rel_linf(dx, _nhwc(x.grad).reshape(M, Cin)) < 2e-5, rel_linf(dx, _nhwc(x.grad).reshape(M, Cin))
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(3, 64, 64, 0, 1), (2, 1024, 128, 0, 1), (2, 256, 128, 128, 1), (2, 1024, 128, 0, 0)])
+def test_groupnorm_backward(N, B, HW, C1, C2, silu):
+    from oracle.unet_oracle import group_norm
+    gen = torch.Generator().manual_seed(B + HW + C1 + C2 + 7)
+    Cc = C1 + C2
+    side = int(math.isqrt(HW))
+    x1 = torch.randn((B, HW, C1), generator=gen) * 2 + 0.5
+    x2 = torch.randn((B, HW, C2), generator=gen) if C2 else None
+    ga, be = torch.randn(Cc, generator=gen), torch.randn(Cc, generator=gen)
+    da = bf16r(torch.randn((B, HW, Cc), generator=gen))
+    add = torch.randn((B, HW, Cc), generator=gen)
+    add_b = torch.randn((B, HW, C1), generator=gen)
+    xc = (torch.cat([x1, x2], 2) if C2 else x1).double().requires_grad_(True)
+    gad, bed = ga.double().requires_grad_(True), be.double().requires_grad_(True)
+    y = group_norm(xc.permute(0, 2, 1).reshape(B, Cc, side, side), 32, gad, bed)
+    if silu:
+        y = do.silu(y)
+    y.backward(da.double().permute(0, 2, 1).reshape(B, Cc, side, side))
+    want = xc.grad + add.double()
+    want[:, :, :C1] += add_b.double()
+    out1, out2 = empty(B, HW, C1), (empty(B, HW, C2) if C2 else None)
+    dg, db = torch.ones(Cc, device=DEV), torch.ones(Cc, device=DEV)  # accumulated on top of existing values
+    N.check(N.lib().bsi_groupnorm_bwd_nhwc(N.ptr(dev(da.to(torch.bfloat16))), N.ptr(dev(x1)), C1, N.ptr(dev(x2)) if C2 else None, C2,
+                                           B, HW, N.ptr(dev(ga)), N.ptr(dev(be)), 1e-5, silu, N.ptr(dev(add)), N.ptr(dev(add_b)),
+                                           N.ptr(out1), N.ptr(out2) if C2 else None, N.ptr(dg), N.ptr(db), N.stream()))
+    assert rel_linf(out1, want[:, :, :C1]) < 2e-5, rel_linf(out1, want[:, :, :C1])
+    if C2:
+        assert rel_linf(out2, want[:, :, C1:]) < 2e-5
+    assert rel_linf(dg - 1, gad.grad) < 2e-5 and rel_linf(db - 1, bed.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,HW,Nc,p", [(3, 64, 64, 0.0), (2, 1024, 128, 0.1)])
+def test_film_silu_dropout_forward_backward(N, B, HW, Nc, p):
+    gen = torch.Generator().manual_seed(B + HW + Nc)
+    M = B * HW
+    h1 = bf16r(torch.randn((M, Nc), generator=gen))
+    film = torch.randn((B, 2 * Nc), generator=gen) * 0.5
+    dy = bf16r(torch.randn((M, Nc), generator=gen))
+    seed, site = 1234, 5
+    lib = N.lib()
+    keep = torch.ones(M * Nc, dtype=torch.uint8, device=DEV)
+    if p > 0:
+        N.check(lib.bsi_dropout_mask(p, seed, site, 0, M * Nc, N.ptr(keep), N.stream()))
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p)) < 0.01, frac
+    mask = keep.cpu().double().reshape(M, Nc) / (1 - p)
+    hd = h1.double().requires_grad_(True)
+    fd = film.double().requires_grad_(True)
+    sc = fd[:, :Nc].repeat_interleave(HW, 0)
+    sh = fd[:, Nc:].repeat_interleave(HW, 0)
+    y = do.silu(hd * (sc + 1) + sh) * mask
+    y.backward(dy.double())
+    yb = empty(M, Nc, dtype=torch.bfloat16)
+    h1d, fdv = dev(h1.to(torch.bfloat16)), dev(film)
+    N.check(lib.bsi_film_silu(N.ptr(h1d), M, Nc, HW, N.ptr(fdv), B, 2 * Nc, p, seed, site, N.ptr(yb), N.stream()))
+    assert rel_linf(yb.float(), y.detach()) < 5e-3
+    dh1 = empty(M, Nc, dtype=torch.bfloat16)
+    dfilm = torch.zeros((B, 2 * Nc), device=DEV)
+    N.check(lib.bsi_film_silu_bwd(N.ptr(dev(dy.to(torch.bfloat16))), N.ptr(h1d), M, Nc, HW, N.ptr(fdv), B, 2 * Nc, p, seed, site,
+                                  N.ptr(dh1), N.ptr(dfilm), 2 * Nc, N.stream()))
+    assert rel_linf(dh1.float(), hd.grad) < 5e-3
+    assert rel_linf(dfilm, fd.grad) < 1e-4, rel_linf(dfilm, fd.grad)
+
+
+def test_unet_decode_backward(N):
+    gen = torch.Generator().manual_seed(11)
+    B, HW, Cc, Co = 3, 320, 128, 3
+    h = torch.randn((B * HW, Cc), generator=gen)
+    w = torch.randn((Co, Cc), generator=gen) / math.sqrt(Cc)
+    g = torch.randn((B, Co, HW), generator=gen)
+    c_out = torch.rand(B, generator=gen) + 0.5
+    hd, wd = h.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = torch.zeros(Co, dtype=torch.double, requires_grad=True)
+    f = (hd @ wd.t() + bd).reshape(B, HW, Co).permute(0, 2, 1)
+    (f * c_out.double()[:, None, None]).backward(g.double())
+    dh = empty(B * HW, Cc)
+    dw, db = torch.zeros((Co, Cc), device=DEV), torch.zeros(Co, device=DEV)
+    N.check(N.lib().bsi_unet_decode_bwd(N.ptr(dev(g)), N.ptr(dev(c_out)), 1, N.ptr(dev(h)), B, HW, Cc, N.ptr(dev(w)), Co, N.ptr(dh),
+                                        N.ptr(dw), N.ptr(db), N.stream()))
+    assert rel_linf(dh, hd.grad) < 1e-5 and rel_linf(dw, wd.grad) < 1e-5 and rel_linf(db, bd.grad) < 1e-5

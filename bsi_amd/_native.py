@@ -125,6 +125,7 @@ _PROTOS = {
     "bsi_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "bsi_attention_fwd_lse": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "bsi_attention_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "bsi_attention_bwd_long": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "bsi_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "bsi_ln_mod_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "bsi_silu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),

@@ -211,6 +211,10 @@ int bsi_attention_fwd_lse(const void* qkv, int ld_qkv, int B, int tokens, int he
  * `out`, its gradient `dout` (both bf16 [B,tokens,heads*dh], row stride ld_o) and lse.  dh = 64, tokens <= 256. */
 int bsi_attention_bwd(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
                       int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, bsi_stream_t stream);
+/* Same contract for long sequences / wide heads (UNet centre attention, attention.py:18,38: 1024 positions, dh 128):
+ * the other side of each pass is streamed through LDS; tokens % 64 == 0, dh 64 or 128, no dropout. */
+int bsi_attention_bwd_long(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
+                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, bsi_stream_t stream);
 
 /* Backward building blocks of the DiT block (autograd of dit.py:50-55,87-103):
  * bsi_gate_bwd: for x2 = x1 + gate*delta and dX = dL/dx2: ddelta = bf16(gate*dX), dgate[b] += sum_tokens dX*delta,

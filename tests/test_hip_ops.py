@@ -362,9 +362,10 @@ def test_gemm_tn_and_colsum(N, M, Nn, K):
 # ----------------------------------------------------------------------------------------------
 # backward kernels (checked against torch autograd of the oracle expressions in fp64)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,tokens,heads", [(2, 64, 2), (2, 256, 3), (1, 128, 1)])
-def test_attention_backward(N, B, tokens, heads):
-    dh, d = 64, heads * 64
+@pytest.mark.parametrize("B,tokens,heads,dh,long", [(2, 64, 2, 64, 0), (2, 256, 3, 64, 0), (1, 128, 1, 64, 0), (2, 1024, 1, 128, 1),
+                                                    (2, 192, 2, 128, 1), (1, 320, 2, 64, 1), (3, 64, 1, 64, 1)])
+def test_attention_backward(N, B, tokens, heads, dh, long):
+    d = heads * dh
     gen = torch.Generator().manual_seed(B * 5 + tokens + heads)
     qkv = bf16r(torch.randn((B, tokens, 3, heads, dh), generator=gen) * 1.2)
     dout = bf16r(torch.randn((B, tokens, d), generator=gen))
@@ -379,8 +380,9 @@ def test_attention_backward(N, B, tokens, heads):
     assert rel_linf(lse, torch.logsumexp(sc, -1).detach()) < 1e-5
     ref_o.backward(dout.double())
     dqkv = empty(B, tokens, 3 * d, dtype=torch.bfloat16)
-    N.check(N.lib().bsi_attention_bwd(N.ptr(dq_), 3 * d, N.ptr(out), N.ptr(dev(dout.to(torch.bfloat16))), d, N.ptr(lse),
-                                      B, tokens, heads, dh, N.ptr(dqkv), 3 * d, N.stream()))
+    fn = N.lib().bsi_attention_bwd_long if long else N.lib().bsi_attention_bwd
+    N.check(fn(N.ptr(dq_), 3 * d, N.ptr(out), N.ptr(dev(dout.to(torch.bfloat16))), d, N.ptr(lse), B, tokens, heads, dh, N.ptr(dqkv),
+               3 * d, N.stream()))
     got = dqkv.cpu().float().reshape(B, tokens, 3, heads, dh)
     # P and dS are rounded to bf16 before the second products, O and the outputs are bf16: 1e-2 relative to the max
     for i, nm in enumerate("qkv"):

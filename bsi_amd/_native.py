@@ -52,6 +52,25 @@ class UNetWeights(C.Structure):
                [(k, C.c_void_p) for k in ("agn_w", "agn_b", "aqkv_w", "aqkv_b", "aout_w", "aout_b")]
 
 
+class UNetResBlockWeightsT(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("conv1_wT", "conv2_wT", "skip_wT")]
+
+
+class UNetWeightsT(C.Structure):
+    _fields_ = [("blocks", C.POINTER(UNetResBlockWeightsT))] + [(k, C.c_void_p) for k in ("aqkv_wT", "aout_wT", "film_wT", "pm3_wT")]
+
+
+class UNetResBlockGrads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("gn_w", "gn_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b")]
+
+
+class UNetGrads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("enc_w", "enc_b", "dec_w", "dec_b", "pm1_w_padded", "pm1_b", "pm3_w", "pm3_b",
+                                          "film_w", "film_b")] + \
+               [("blocks", C.POINTER(UNetResBlockGrads))] + \
+               [(k, C.c_void_p) for k in ("agn_w", "agn_b", "aqkv_w", "aqkv_b", "aout_w", "aout_b")]
+
+
 class DitConfig(C.Structure):
     _fields_ = [("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("patch", C.c_int),
                 ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
@@ -159,6 +178,12 @@ _PROTOS = {
     "bsi_unet_workspace_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
     "bsi_unet_film_scratch_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
     "bsi_unet_film": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), _vp, _i, _vp, _vp, _vp]),
+    "bsi_unet_tape_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
+    "bsi_unet_backward_workspace_bytes": (_sz, [C.POINTER(UNetConfig), _i]),
+    "bsi_unet_train_forward": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f,
+                                    C.c_ulonglong, _vp]),
+    "bsi_unet_backward": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), C.POINTER(UNetWeightsT), C.POINTER(UNetGrads), _i,
+                               _vp, _vp, _vp, _vp, _f, C.c_ulonglong, _vp]),
     "bsi_unet_forward": (_i, [C.POINTER(UNetConfig), C.POINTER(UNetWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_kpad": (_i, [C.POINTER(DitConfig)]),
     "bsi_dit_tokens": (_i, [C.POINTER(DitConfig)]),

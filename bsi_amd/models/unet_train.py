@@ -1,0 +1,168 @@
+"""Training path of the native DenoisingVDMUNet: a `torch.autograd.Function` whose forward records a tape in device
+memory (`bsi_unet_train_forward`) and whose backward is the hand-written HIP backward (`bsi_unet_backward`).
+torch's autograd only carries the parameter gradients out; no torch op computes anything.
+
+Replaces autograd over bsi/models/vdm_unet.py:92-100, bsi/nn/simplified_unet.py:33-48, bsi/nn/residual_block.py:61-64 and
+bsi/nn/attention.py:32-41 of the reference inside `BSI.train_loss(...).mean().backward()` (bsi/tasks/bsi.py:187-194)."""
+import ctypes as C
+
+import torch
+from torch import Tensor, nn
+
+from .. import _native as N
+
+
+def _block_names(model):
+    L = model._cfg_args["levels"]
+    return ([f"u_net.downsampling_blocks.{i}.0." for i in range(L)] + ["u_net.center_block.0.", "u_net.center_block.2."] +
+            [f"u_net.upsampling_blocks.{i}.0." for i in range(L)])
+
+
+def transposed_pack(model):
+    """bf16 shadows for the input-gradient products (rotated conv weights, transposed Linear weights), cached per
+    parameter version like `native_pack`."""
+    key = model._weights_key()
+    if getattr(model, "_pack_t", None) is not None and model._pack_t_key == key:
+        return model._pack_t
+    lib = N.lib()
+    dev = model.encode.weight.device
+    keep = []
+
+    def conv_t(conv: nn.Conv2d):
+        cout, cin, kh, kw = conv.weight.shape
+        taps = kh * kw
+        w = conv.weight.detach().contiguous()
+        out = torch.empty((cin, taps * cout), dtype=torch.bfloat16, device=dev)
+        N.check(lib.bsi_conv_weight_pack_t(N.ptr(w), cout, cin, taps, taps * cout, N.ptr(out), N.stream()))
+        keep.extend([w, out])
+        return out.data_ptr()
+
+    def lin_t(w: Tensor):
+        w = w.detach().contiguous()
+        rows, cols = w.shape
+        out = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev)
+        N.check(lib.bsi_cast_transpose_bf16(N.ptr(w), rows, cols, N.ptr(out), rows, N.stream()))
+        keep.extend([w, out])
+        return out.data_ptr()
+
+    blocks = model._blocks()
+    arr = (N.UNetResBlockWeightsT * len(blocks))()
+    for i, rb in enumerate(blocks):
+        arr[i].conv1_wT = conv_t(rb.layers[2])
+        arr[i].conv2_wT = conv_t(rb.layers[-1])
+        arr[i].skip_wT = conv_t(rb.skip) if isinstance(rb.skip, nn.Conv2d) else None
+    wt = N.UNetWeightsT()
+    wt.blocks = C.cast(arr, C.POINTER(N.UNetResBlockWeightsT))
+    att = model.u_net.center_block[1].fn[1]
+    wt.aqkv_wT, wt.aout_wT = conv_t(att.to_qkv), conv_t(att.to_out)
+    wt.film_wT = lin_t(torch.cat([rb.project_onto_scale_shift.weight.detach() for rb in blocks], dim=0))
+    wt.pm3_wT = lin_t(model.pos_map[3].weight)
+    model._pack_t = (wt, arr, keep)
+    model._pack_t_key = key
+    return model._pack_t
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, drop_p, seed, mu, t, c_in, c_skip, c_out, *params):
+        lib = N.lib()
+        cfg, w, _, _ = model.native_pack()
+        mu = mu.contiguous()
+        t = t.detach().to(torch.float32).contiguous()
+        B = mu.shape[0]
+        out = torch.empty_like(mu)
+        tape = torch.empty(lib.bsi_unet_tape_bytes(C.byref(cfg), B), dtype=torch.uint8, device=mu.device)
+        N.check(lib.bsi_unet_train_forward(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(t), N.ptr(c_in), N.ptr(c_skip),
+                                           N.ptr(c_out), N.ptr(out), N.ptr(tape), drop_p, seed, N.stream()))
+        ctx.model, ctx.tape, ctx.c_out, ctx.B = model, tape, c_out, B
+        ctx.drop = (drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = N.lib()
+        model, B = ctx.model, ctx.B
+        cfg, w, _, _ = model.native_pack()
+        wt, _, _ = transposed_pack(model)
+        dev = g_out.device
+        g_out = g_out.contiguous()
+        dim, cd = cfg.dim, cfg.c_dim
+        cin_pad = lib.bsi_unet_cin_pad(C.byref(cfg))
+        named = dict(model.named_parameters())
+        order = [n for n, _ in model.named_parameters()]
+        sizes = {n: named[n].numel() for n in order}
+        flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for n in order:
+            views[n] = flat[off:off + sizes[n]].view_as(named[n])
+            off += sizes[n]
+        keep, unpack = [], []  # (packed tensor, conv param name, cin_pad, col0, skip?)
+
+        def packed(name, cin_p=None, extra=None):
+            cout, cin, kh, kw = named[name].shape
+            taps = kh * kw
+            cin_p = cin_p or cin
+            k = taps * cin_p + (named[extra].shape[1] if extra else 0)
+            buf = torch.empty((cout, k), dtype=torch.float32, device=dev)
+            keep.append(buf)
+            unpack.append((buf, name, cout, cin, taps, cin_p, k, 0))
+            if extra:
+                unpack.append((buf, extra, cout, named[extra].shape[1], 1, named[extra].shape[1], k, taps * cin_p))
+            return buf.data_ptr()
+
+        names = _block_names(model)
+        blocks_m = model._blocks()
+        arr = (N.UNetResBlockGrads * len(names))()
+        skip_bias = []
+        for i, (pfx, rb) in enumerate(zip(names, blocks_m)):
+            last = len(rb.layers) - 1
+            has_skip = isinstance(rb.skip, nn.Conv2d)
+            arr[i].gn_w, arr[i].gn_b = views[pfx + "layers.0.weight"].data_ptr(), views[pfx + "layers.0.bias"].data_ptr()
+            arr[i].conv1_w, arr[i].conv1_b = packed(pfx + "layers.2.weight"), views[pfx + "layers.2.bias"].data_ptr()
+            arr[i].conv2_w = packed(pfx + f"layers.{last}.weight", extra=pfx + "skip.weight" if has_skip else None)
+            arr[i].conv2_b = views[pfx + f"layers.{last}.bias"].data_ptr()
+            if has_skip:
+                skip_bias.append((pfx + "skip.bias", pfx + f"layers.{last}.bias"))
+        F = len(names) * 2 * dim
+        film_w = torch.empty((F, cd), dtype=torch.float32, device=dev)
+        film_b = torch.empty(F, dtype=torch.float32, device=dev)
+        pm1_pad = torch.empty((cd, 64), dtype=torch.float32, device=dev)
+        g = N.UNetGrads()
+        g.enc_w, g.enc_b = packed("encode.weight", cin_p=cin_pad), views["encode.bias"].data_ptr()
+        g.dec_w, g.dec_b = views["decode.weight"].data_ptr(), views["decode.bias"].data_ptr()
+        g.pm1_w_padded, g.pm1_b = pm1_pad.data_ptr(), views["pos_map.1.bias"].data_ptr()
+        g.pm3_w, g.pm3_b = views["pos_map.3.weight"].data_ptr(), views["pos_map.3.bias"].data_ptr()
+        g.film_w, g.film_b = film_w.data_ptr(), film_b.data_ptr()
+        g.blocks = C.cast(arr, C.POINTER(N.UNetResBlockGrads))
+        apfx = "u_net.center_block.1.fn."
+        g.agn_w, g.agn_b = views[apfx + "0.weight"].data_ptr(), views[apfx + "0.bias"].data_ptr()
+        g.aqkv_w, g.aqkv_b = packed(apfx + "1.to_qkv.weight"), views[apfx + "1.to_qkv.bias"].data_ptr()
+        g.aout_w, g.aout_b = packed(apfx + "1.to_out.weight"), views[apfx + "1.to_out.bias"].data_ptr()
+        ws = torch.empty(lib.bsi_unet_backward_workspace_bytes(C.byref(cfg), B), dtype=torch.uint8, device=dev)
+        N.check(lib.bsi_unet_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
+                                      N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
+        ctx.tape = None
+        # packed conv gradients -> nn.Conv2d layout inside the flat buffer
+        for buf, name, cout, cin, taps, cin_p, k, col0 in unpack:
+            N.check(lib.bsi_conv_wgrad_unpack(N.ptr(buf), cout, cin, taps, cin_p, k, col0, 0, N.ptr(views[name]), N.stream()))
+        for sb, cb in skip_bias:  # out = skip(x) + layers(x): both biases receive the same gradient
+            views[sb].copy_(views[cb])
+        for i, pfx in enumerate(names):
+            views[pfx + "project_onto_scale_shift.weight"].copy_(film_w[i * 2 * dim:(i + 1) * 2 * dim])
+            views[pfx + "project_onto_scale_shift.bias"].copy_(film_b[i * 2 * dim:(i + 1) * 2 * dim])
+        views["pos_map.1.weight"].copy_(pm1_pad[:, :named["pos_map.1.weight"].shape[1]])
+        model._last_flat_grad = flat
+        return (None, None, None, None, None, None, None, None, *[views[n] for n in order])
+
+
+def unet_forward_train(model, mu: Tensor, t: Tensor, c_in=None, c_skip=None, c_out=None) -> Tensor:
+    """x_hat = c_skip*mu + c_out*f(c_in*mu, t) (or f(mu, t)) with gradients w.r.t. the model parameters.  In `train()` mode
+    the residual blocks' nn.Dropout (residual_block.py:46) is applied with a counter-based mask seeded from
+    `torch.initial_seed()` and a per-model call counter."""
+    p = float(model._dropout or 0.0) if model.training else 0.0
+    seed = 0
+    if p > 0.0:
+        model._drop_calls = getattr(model, "_drop_calls", 0) + 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + model._drop_calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+    params = [q for _, q in model.named_parameters()]
+    return _UNetTrainFn.apply(model, p, seed, mu, t, c_in, c_skip, c_out, *params)

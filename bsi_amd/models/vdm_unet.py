@@ -105,8 +105,11 @@ class DenoisingVDMUNet(nn.Module):
                                residual_block(dim, dim, c_dim))
         self.u_net = SimplifiedUNet(down, up, center)
         self._cfg_args = dict(dim=dim, levels=levels, heads=n_attention_heads, c_dim=c_dim)
+        self._dropout = dropout
         self._pack = None
         self._pack_key = None
+        self._pack_t = None
+        self._pack_t_key = None
         self._ws = None
 
     # ------------------------------------------------------------------------------------------------
@@ -236,6 +239,10 @@ class DenoisingVDMUNet(nn.Module):
         if not mu.is_cuda:
             raise RuntimeError("bsi_amd.DenoisingVDMUNet: input is not on a HIP device; there is no CPU path")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("bsi_amd.DenoisingVDMUNet: the HIP backward of the UNet is not built yet; "
-                                      "run under torch.no_grad() (sampling / ELBO)")
+            return self.forward_train(mu, t)  # backward kernels live in the training engine
         return self.forward_native(mu, self.adaln_table(t))
+
+    def forward_train(self, mu: Tensor, t: Tensor, c_in=None, c_skip=None, c_out=None) -> Tensor:
+        """Differentiable evaluation (parameters only): tape-recording HIP forward + hand-written HIP backward."""
+        from .unet_train import unet_forward_train
+        return unet_forward_train(self, mu, t, c_in, c_skip, c_out)

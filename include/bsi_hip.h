@@ -385,6 +385,49 @@ int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weights* w /*hos
                      int film_rows, const float* c_in, const float* c_skip, const float* c_out, int coef_stride, float* out,
                      void* workspace, bsi_stream_t stream);
 
+/* DenoisingVDMUNet training engine — forward with a tape + hand-written backward (replaces torch autograd over
+ * vdm_unet.py:92-100, simplified_unet.py:33-48, residual_block.py:61-64, attention.py:32-41 inside
+ * `BSI.train_loss(...).mean().backward()`, bsi/tasks/bsi.py:187-194). */
+typedef struct bsi_unet_resblock_weights_t { /* bf16 shadows for the input-gradient products */
+    const void* conv1_wT; /* [Cin][9*dim]  bsi_conv_weight_pack_t(layers.2.weight) */
+    const void* conv2_wT; /* [dim][9*dim]  bsi_conv_weight_pack_t(layers.5|6.weight) */
+    const void* skip_wT;  /* up blocks: [2*dim][dim] = bsi_conv_weight_pack_t(skip.weight, taps 1); else NULL */
+} bsi_unet_resblock_weights_t;
+typedef struct bsi_unet_weights_t {
+    const bsi_unet_resblock_weights_t* blocks; /* host array [2*levels+2], order of bsi_unet_weights.blocks */
+    const void* aqkv_wT;  /* [dim][9*3*dim] */
+    const void* aout_wT;  /* [dim][9*dim] */
+    const void* film_wT;  /* [c_dim][nblocks*2*dim]  transpose of the stacked project_onto_scale_shift weights */
+    const void* pm3_wT;   /* [c_dim][c_dim] */
+} bsi_unet_weights_t;
+typedef struct bsi_unet_resblock_grads { /* fp32; conv weights in the PACKED layout of bsi_conv_weight_pack */
+    float *gn_w, *gn_b;
+    float* conv1_w; float* conv1_b; /* [dim][9*Cin] */
+    float* conv2_w; float* conv2_b; /* [dim][9*dim (+ 2*dim skip columns)]; conv2_b is also the skip conv's bias gradient */
+} bsi_unet_resblock_grads;
+typedef struct bsi_unet_grads {
+    float* enc_w; float* enc_b;         /* [dim][9*cin_pad] packed */
+    float *dec_w, *dec_b;
+    float* pm1_w_padded; float* pm1_b;  /* [c_dim][64] */
+    float* pm3_w; float* pm3_b;
+    float* film_w; float* film_b;       /* stacked [nblocks*2*dim][c_dim], [nblocks*2*dim] */
+    const bsi_unet_resblock_grads* blocks;
+    float *agn_w, *agn_b;
+    float* aqkv_w; float* aqkv_b;       /* [3*dim][9*dim] packed */
+    float* aout_w; float* aout_b;       /* [dim][9*dim] packed */
+} bsi_unet_grads;
+size_t bsi_unet_tape_bytes(const bsi_unet_config* cfg, int B);
+size_t bsi_unet_backward_workspace_bytes(const bsi_unet_config* cfg, int B);
+/* out = c_skip*mu + c_out*f(c_in*mu, t) with per-sample t [B]; records the tape.  dropout_p > 0 applies nn.Dropout after the
+ * FiLM stage of every residual block (residual_block.py:46) with the counter mask (seed, site = block index). */
+int bsi_unet_train_forward(const bsi_unet_config* cfg, const bsi_unet_weights* w /*host*/, int B, const float* mu, const float* t,
+                           const float* c_in, const float* c_skip, const float* c_out, float* out, void* tape,
+                           float dropout_p, unsigned long long seed, bsi_stream_t stream);
+/* Parameter gradients of sum(g_out * out) into `g` (every field is WRITTEN). */
+int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weights* w /*host*/, const bsi_unet_weights_t* wT /*host*/,
+                      const bsi_unet_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
+                      void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DenoisingDiT training engine — forward with a tape + hand-written backward (replaces torch autograd over
  * dit.py:87-103,174-181 inside `BSI.train_loss(...).mean().backward()`, bsi/tasks/bsi.py:187-194).

@@ -26,16 +26,20 @@ def conv(x, w, b, md=None):
     return F.conv2d(_rt(x, md), _rt(w, md), b, padding=w.shape[-1] // 2)
 
 
-def residual_block(x, c, W, pre, *, has_dropout_slot, md=None):
+def residual_block(x, c, W, pre, *, has_dropout_slot, md=None, drop=None):
     """residual_block.py:61-64 with layers of :41-49.  The second conv sits at index 6 when a
-    Dropout module occupies index 5 (dropout is not None), else at index 5."""
+    Dropout module occupies index 5 (dropout is not None), else at index 5.  ``drop``: optional dict
+    {block prefix: keep-mask / (1 - p), [B, C, H, W]} applied where nn.Dropout sits (:46)."""
     i2 = 6 if has_dropout_slot else 5
     ss = linear(c, W[pre + "project_onto_scale_shift.weight"], W[pre + "project_onto_scale_shift.bias"], md)
     scale, shift = ss.chunk(2, dim=1)
     h = silu(group_norm(x, 32, W[pre + "layers.0.weight"], W[pre + "layers.0.bias"]))
     h = conv(h, W[pre + "layers.2.weight"], W[pre + "layers.2.bias"], md)
     h = torch.addcmul(shift[..., None, None], scale[..., None, None] + 1, h)  # FeatureModulation :21-24
-    h = conv(silu(h), W[pre + f"layers.{i2}.weight"], W[pre + f"layers.{i2}.bias"], md)
+    h = silu(h)
+    if drop is not None:
+        h = h * drop[pre]
+    h = conv(h, W[pre + f"layers.{i2}.weight"], W[pre + f"layers.{i2}.bias"], md)
     skip = x
     if (pre + "skip.weight") in W:
         skip = conv(x, W[pre + "skip.weight"], W[pre + "skip.bias"], md)
@@ -57,7 +61,7 @@ def attention2d(x, W, pre, heads, md=None):
 
 
 def unet_forward(W, mu, t, *, levels, pos_emb_size=32, pos_emb_rate=100, heads=1, ff=None,
-                 has_dropout_slot=True, md=None):
+                 has_dropout_slot=True, md=None, drop=None):
     """DenoisingVDMUNet.forward (vdm_unet.py:92-100) + SimplifiedUNet.forward (simplified_unet.py:33-48)."""
     parts = [mu]
     if ff is not None:
@@ -66,7 +70,7 @@ def unet_forward(W, mu, t, *, levels, pos_emb_size=32, pos_emb_rate=100, heads=1
     e = nyquist_embedding(t, pos_emb_size, pos_emb_rate)
     c = silu(linear(e, W["pos_map.1.weight"], W["pos_map.1.bias"], md))
     c = silu(linear(c, W["pos_map.3.weight"], W["pos_map.3.bias"], md))
-    kw = dict(has_dropout_slot=has_dropout_slot, md=md)
+    kw = dict(has_dropout_slot=has_dropout_slot, md=md, drop=drop)
     x = conv(x, W["encode.weight"], W["encode.bias"], md)
     skips = []
     for i in range(levels):

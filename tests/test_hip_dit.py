@@ -447,3 +447,67 @@ def test_full_size_unet_one_forward_vs_oracle():
         got = bsi._predict_x(mu.to(DEV), t.to(DEV)).cpu()
         ref = bo.BSIOracle(f, data_shape=shape, k=128).predict_x(mu, t)
     assert rel_linf(got, ref) < 3e-2, rel_linf(got, ref)
+
+
+def test_unet_train_loss_gradients_vs_golden():
+    """BSI.train_loss(...).mean().backward() through the HIP UNet training engine vs the reference's gradients (G4)."""
+    g = golden("g4_train_unet")
+    model = make_unet()
+    bsi = make_bsi(model, (3, 8, 8))
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = bsi.train_loss(g["x"].to(DEV))
+    assert max_rel(loss.detach(), g["loss"]) < 1e-2
+    loss.mean().backward()
+    sq, worst = 0.0, (0.0, None)
+    for name, p in model.named_parameters():
+        ref = g["G." + name]
+        assert p.grad is not None and p.grad.shape == ref.shape, name
+        sq += float((p.grad.double() ** 2).sum())
+        err = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+        worst = max(worst, (err, name))
+        assert err < 3e-2, (name, err)
+    assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)
+
+
+def test_unet_training_dropout_and_two_levels_vs_oracle():
+    """dim 128, two levels (both skip paths), 16x16, dropout 0.1 in train() mode: the masks the kernels use are exported
+    with bsi_dropout_mask and applied in the CPU oracle; loss and gradients against autograd through the oracle."""
+    import bsi_amd._native as N
+    from oracle import unet_oracle as uo
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+    shape, dim, levels, p, B = (3, 16, 16), 128, 2, 0.1, 3
+    W = uo.unet_random_weights(shape, dim, levels, seed=4, ff=(6, 8))
+    m = DenoisingVDMUNet(shape, NyquistPositionalEmbedding(32, 100), "silu", dim, levels, 4, n_attention_heads=1, dropout=p,
+                         fourier_features=FourierFeatures(n_min=6, n_max=8))
+    m.load_state_dict(W)
+    m = m.to(DEV).train()
+    bsi = make_bsi(m, shape)
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randint(0, 256, (B, *shape), generator=gen).float() / 255) * 2 - 1
+    off, perm, eps = torch.rand((), generator=gen), torch.randperm(B, generator=gen), torch.randn((B, *shape), generator=gen)
+    torch.manual_seed(77)
+    m._drop_calls = 0
+    with replay_noise(rand=[off], randperm=[perm], randn=[eps]):
+        loss = bsi.train_loss(x.to(DEV))
+    loss.mean().backward()
+    seed = (torch.initial_seed() * 0x9E3779B1 + 1 * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+    names = ([f"u_net.downsampling_blocks.{i}.0." for i in range(levels)] + ["u_net.center_block.0.", "u_net.center_block.2."] +
+             [f"u_net.upsampling_blocks.{i}.0." for i in range(levels)])
+    drop = {}
+    HW = shape[1] * shape[2]
+    for blk, pre in enumerate(names):
+        mk = torch.empty(B * HW * dim, dtype=torch.uint8, device=DEV)
+        N.check(N.lib().bsi_dropout_mask(p, seed, blk, 0, mk.numel(), N.ptr(mk), N.stream()))
+        drop[pre] = mk.cpu().float().reshape(B, shape[1], shape[2], dim).permute(0, 3, 1, 2) / (1 - p)
+        assert abs(float(mk.float().mean()) - (1 - p)) < 0.01
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    f = lambda a, b: uo.unet_forward(Wr, a, b, levels=levels, ff=(6, 8), has_dropout_slot=True, drop=drop)  # noqa: E731
+    ref = bo.BSIOracle(f, data_shape=shape, k=16).train_loss(x, off, perm, eps)
+    assert max_rel(loss.detach(), ref.detach()) < 2e-2, max_rel(loss.detach(), ref.detach())
+    ref.mean().backward()
+    for name, q in m.named_parameters():
+        r = Wr[name].grad
+        err = float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
+        assert err < 4e-2, (name, err)

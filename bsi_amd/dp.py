@@ -83,7 +83,9 @@ class FlatParams:
 
 
 class DPTrainer:
-    """Native data-parallel train step around a `bsi_amd.BSI` whose model is a `bsi_amd.models.dit.DenoisingDiT`."""
+    """Native data-parallel train step around a `bsi_amd.BSI` whose model is a `bsi_amd.models.dit.DenoisingDiT` (per-block
+    gradient buckets overlapped with the backward) or a `bsi_amd.models.vdm_unet.DenoisingVDMUNet` (28 M parameters: one
+    bucket after the backward)."""
 
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
@@ -107,13 +109,15 @@ class DPTrainer:
         self.v = torch.zeros_like(self.fp.flat)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sq_ws = torch.empty(N.lib().bsi_sqnorm_workspace_bytes(), dtype=torch.uint8, device=dev)
-        depth = len(self.model.dit.blocks)
+        self.bucketed = hasattr(self.model, "dit")
+        depth = len(self.model.dit.blocks) if self.bucketed else 0
         self.block_spans = [self.fp.span(f"dit.blocks.{i}.") for i in range(depth)]
-        self.head_span = (0, self.block_spans[0][0])                     # patch encoder
-        self.tail_span = (self.block_spans[-1][1], self.fp.flat.numel())  # decoder
+        if self.bucketed:
+            self.head_span = (0, self.block_spans[0][0])                     # patch encoder
+            self.tail_span = (self.block_spans[-1][1], self.fp.flat.numel())  # decoder
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self.events = None
-        if self.world > 1:
+        if self.world > 1 and self.bucketed:
             self.events = [torch.cuda.Event() for _ in range(depth)]
             for e in self.events:
                 e.record()  # instantiate the underlying hipEvent_t
@@ -131,13 +135,19 @@ class DPTrainer:
         for p in self.model.parameters():
             p.grad = None
         self.model._last_flat_grad = None
-        if self.world > 1:
+        if self.world > 1 and self.bucketed:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
         loss = self.bsi.train_loss(x, generator).mean()
         loss.backward()
         flat_g = self.model._last_flat_grad
-        assert flat_g is not None, "the HIP training engine did not run (model is not a native DenoisingDiT?)"
-        if self.world > 1:
+        assert flat_g is not None, "the HIP training engine did not run (model is not a native denoiser?)"
+        if self.world > 1 and not self.bucketed:
+            cur = torch.cuda.current_stream()
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            cur.wait_stream(self.comm_stream)
+        elif self.world > 1:
             N.check(lib.bsi_dit_backward_set_events(None, 0))
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self.comm_stream):

@@ -511,3 +511,22 @@ def test_unet_training_dropout_and_two_levels_vs_oracle():
         r = Wr[name].grad
         err = float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
         assert err < 4e-2, (name, err)
+
+
+def test_dp_trainer_unet_single_gpu_step():
+    """DPTrainer with the UNet (one gradient bucket): loss and gradient norm of the first step match the golden, the EMA
+    copies the weights during warm-up, and a second step on the same batch lowers the loss."""
+    from bsi_amd.dp import DPTrainer
+    g = golden("g4_train_unet")
+    model = make_unet()  # eval(): dropout off, as in the golden
+    bsi = make_bsi(model, (3, 8, 8))
+    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = tr.train_step(g["x"].to(DEV))
+    assert abs(float(loss) / float(g["loss_mean"]) - 1) < 5e-3
+    assert abs(float(tr.last_grad_norm.sqrt()) / float(g["grad_norm"]) - 1) < 1e-2
+    for (n, p), (_, e) in zip(model.named_parameters(), tr.ema_model.named_parameters()):
+        assert torch.equal(p.detach(), e.detach()), n
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss2 = tr.train_step(g["x"].to(DEV))
+    assert float(loss2) < float(loss) and torch.isfinite(loss2)

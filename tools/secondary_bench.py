@@ -3,7 +3,8 @@
   * DiT-L/2 32x32 k=128 sampling at 64 / 256 / 512 images per call (the headline bench.py line uses 128),
   * DiT-L/4 64x64 k=256 sampling (config/experiment/imagenet64.yaml:33-39),
   * ELBO / bpd evaluation throughput (elbo with 1 reconstruction + 1 measurement sample = 2 forwards per image),
-  * VDM-UNet k=128 sampling (config/experiment/cifar10-vdm.yaml:32-39).
+  * VDM-UNet k=128 sampling (config/experiment/cifar10-vdm.yaml:32-39),
+  * VDM-UNet train steps/s at global batch 128 (fwd + bwd + clip + AdamW + EMA, dropout 0.1) on one GPU.
 FLOP figures are SURVEY §8's probe values (2*MAC)."""
 import json
 import os
@@ -20,7 +21,7 @@ from bsi_amd.models.vdm_unet import DenoisingVDMUNet  # noqa: E402
 from bsi_amd.nn import FourierFeatures  # noqa: E402
 
 dev = torch.device("cuda", 0)
-WHICH = set(os.environ.get("WHICH", "dit32,dit64,elbo,unet").split(","))
+WHICH = set(os.environ.get("WHICH", "dit32,dit64,elbo,unet,unet_train").split(","))
 
 
 def make_bsi(model, shape, k):
@@ -92,3 +93,19 @@ with torch.no_grad():
         assert torch.isfinite(out).all()
         emit(what="VDM-UNet(dim128, levels32) 32x32 BSI.sample k=128", images_per_call=b, images_per_s=b / dt,
              model_tflops=b / dt * 129 * 53.47 / 1e3)
+
+if "unet_train" in WHICH:
+    from bsi_amd.dp import DPTrainer
+    shape = (3, 32, 32)
+    torch.manual_seed(0)
+    m = DenoisingVDMUNet(shape, NyquistPositionalEmbedding(32, 100), "silu", 128, 32, 4, n_attention_heads=1, dropout=0.1,
+                         fourier_features=FourierFeatures(n_min=6, n_max=8)).to(dev).train()
+    bsi = make_bsi(m, shape, 128)
+    tr = DPTrainer(bsi, lr=2e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+    g = torch.Generator(dev).manual_seed(0)
+    b = int(os.environ.get("UNET_TRAIN_BATCH", "128"))
+    x = (torch.randint(0, 256, (b, *shape), device=dev).float() / 255) * 2 - 1
+    dt, loss = timed(lambda: tr.train_step(x, g), reps=3)
+    assert torch.isfinite(loss)
+    emit(what="VDM-UNet train step (fwd+bwd+clip+AdamW+EMA, dropout 0.1)", global_batch=b, steps_per_s=1 / dt,
+         ms_per_step=1e3 * dt, images_per_s=b / dt, model_tflops=b / dt * 3 * 53.47 / 1e3, loss=float(loss))

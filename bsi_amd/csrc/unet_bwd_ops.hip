@@ -24,26 +24,30 @@ __device__ __forceinline__ void unpack8(const u32x4 w, float* v) {
 
 // y = Dropout(SiLU(h1 * (scale + 1) + shift))  (FeatureModulation: addcmul(shift, scale + 1, y), residual_block.py:21-24,
 // then ActFn and nn.Dropout, :44-46).  h1, y bf16 [M, N]; film row of pixel m = (m / HW) % film_rows.
-__global__ void film_silu_drop_kernel(const __bf16* __restrict__ h1, size_t M, int N, int HW, const float* __restrict__ film,
+__global__ void film_silu_drop_kernel(const __bf16* __restrict__ h1, unsigned M, int N, int HW, const float* __restrict__ film,
                                       int film_rows, int film_stride, DropCfg dc, __bf16* __restrict__ y) {
-    const int n8 = N / 8;
-    const size_t total = M * n8;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t m = i / n8;
-        const int c = (int)(i % n8) * 8;
-        const float* fr = film + (size_t)((m / HW) % film_rows) * film_stride;
-        float v[8];
-        unpack8(*reinterpret_cast<const u32x4*>(h1 + m * N + c), v);
+    const unsigned n8 = N / 8;
+    const unsigned total = M * n8;  // launcher guarantees M * N < 2^32
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned m = i / n8;
+        const unsigned c = (i - m * n8) * 8;
+        const float* fr = film + (size_t)((m / (unsigned)HW) % (unsigned)film_rows) * film_stride;
+        float v[8], sc[8], sh[8];
+        unpack8(*reinterpret_cast<const u32x4*>(h1 + (size_t)i * 8), v);
+        *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(fr + c);
+        *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(fr + c + 4);
+        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(fr + N + c);
+        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(fr + N + c + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float u = silu_f(__fmaf_rn(fr[c + e] + 1.0f, v[e], fr[N + c + e]));
-            if (dc.thr) u = drop_keep(dc, (unsigned long long)m * N + c + e) ? u * dc.scale : 0.0f;
+            float u = silu_f(__fmaf_rn(sc[e] + 1.0f, v[e], sh[e]));
+            if (dc.thr) u = drop_keep(dc, (unsigned long long)(i * 8u + e)) ? u * dc.scale : 0.0f;
             v[e] = u;
         }
         u32x4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(y + m * N + c) = w;
+        *reinterpret_cast<u32x4*>(y + (size_t)i * 8) = w;
     }
 }
 
@@ -98,21 +102,23 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(const __bf16* __rest
 // Backward of GroupNorm(32, affine)(+ SiLU) over cat(x1, x2) of one image (see groupnorm_kernel):
 //   z = n*gamma + beta, n = (x - mean)*rstd;  dz = da * silu'(z) (or da);  dgamma += sum dz*n, dbeta += sum dz,
 //   dn = dz*gamma;  dx = rstd * (dn - mean_g(dn) - n * mean_g(dn * n));   out = dx (+ add) (+ add_b on the x1 part).
-// One workgroup of 1024 threads per image, three passes (statistics; group sums and affine gradients; write).
-__global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __restrict__ da, const float* __restrict__ x1, int C1,
+// Grid (image, 32-channel slice) like the forward kernel; three passes (statistics; group sums and affine gradients; write).
+constexpr int GN_CS = 32, GN_TPB = 256;
+__global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __restrict__ da, const float* __restrict__ x1, int C1,
                                                              const float* __restrict__ x2, int C2, int HW,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int silu, const float* __restrict__ add,
                                                              const float* __restrict__ add_b, float* __restrict__ out1,
                                                              float* __restrict__ out2, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
-    __shared__ float red_s[2048], red_q[2048];
-    __shared__ float red_g[4096], red_b[4096];  // [pixel row][channel]
-    __shared__ float mean_s[32], rstd_s[32], m1_s[32], m2_s[32];
-    const int C = C1 + C2, CH4 = C / 4, cpg = C / 32;
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int ch = t % CH4, prow = t / CH4, PPI = 1024 / CH4;
-    const int c0 = ch * 4;
+    __shared__ float red_s[512], red_q[512];
+    __shared__ float red_g[1024], red_b[1024];  // [pixel row][channel of the slice]
+    __shared__ float mean_s[16], rstd_s[16], m1_s[16], m2_s[16];
+    const int C = C1 + C2, cpg = C / 32;
+    constexpr int CH4 = GN_CS / 4;
+    const int b = blockIdx.x, t = threadIdx.x, cs0 = blockIdx.y * GN_CS;
+    const int ch = t % CH4, prow = t / CH4, PPI = GN_TPB / CH4;
+    const int c0 = cs0 + ch * 4, cl = ch * 4;
     const bool second = c0 >= C1;
     const float* src = second ? x2 + (size_t)b * HW * C2 + (c0 - C1) : x1 + (size_t)b * HW * C1 + c0;
     const int sstride = second ? C2 : C1;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __res
         red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
     }
     __syncthreads();
-    if (t < 32) {
+    if (t < GN_CS / cpg) {
         const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
         float ts = 0.f, tq = 0.f;
         for (int r = 0; r < PPI; ++r)
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __res
     __syncthreads();
     float mean[4], rstd[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(c0 + k) / cpg]; rstd[k] = rstd_s[(c0 + k) / cpg]; }
+    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(cl + k) / cpg]; rstd[k] = rstd_s[(cl + k) / cpg]; }
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
     const __bf16* dap = da + (size_t)b * HW * C + c0;
     auto dz_of = [&](const f32x4 v, const u32x2 gw, float* nrm, float* dz) {
@@ -173,10 +179,10 @@ __global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __res
         red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
         red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { red_g[prow * C + c0 + k] = gg[k]; red_b[prow * C + c0 + k] = gb[k]; }
+        for (int k = 0; k < 4; ++k) { red_g[prow * GN_CS + cl + k] = gg[k]; red_b[prow * GN_CS + cl + k] = gb[k]; }
     }
     __syncthreads();
-    if (t < 32) {
+    if (t < GN_CS / cpg) {
         const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
         float ts = 0.f, tq = 0.f;
         for (int r = 0; r < PPI; ++r)
@@ -185,17 +191,17 @@ __global__ __launch_bounds__(1024) void groupnorm_bwd_kernel(const __bf16* __res
         m1_s[t] = ts / n;
         m2_s[t] = tq / n;
     }
-    if (t >= 64 && t < 64 + C) {
+    if (t >= 64 && t < 64 + GN_CS) {
         const int c = t - 64;
         float a = 0.f, bb = 0.f;
-        for (int r = 0; r < PPI; ++r) { a += red_g[r * C + c]; bb += red_b[r * C + c]; }
-        atomicAdd(dgamma + c, a);
-        atomicAdd(dbeta + c, bb);
+        for (int r = 0; r < PPI; ++r) { a += red_g[r * GN_CS + c]; bb += red_b[r * GN_CS + c]; }
+        atomicAdd(dgamma + cs0 + c, a);
+        atomicAdd(dbeta + cs0 + c, bb);
     }
     __syncthreads();
     float m1[4], m2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { m1[k] = m1_s[(c0 + k) / cpg]; m2[k] = m2_s[(c0 + k) / cpg]; }
+    for (int k = 0; k < 4; ++k) { m1[k] = m1_s[(cl + k) / cpg]; m2[k] = m2_s[(cl + k) / cpg]; }
     // ---- pass 2: dx
     float* dst = second ? out2 + (size_t)b * HW * C2 + (c0 - C1) : out1 + (size_t)b * HW * C1 + c0;
     const float* ab = (!second && add_b) ? add_b + (size_t)b * HW * C1 + c0 : nullptr;
@@ -281,10 +287,12 @@ __global__ __launch_bounds__(256) void unet_decode_bwd_kernel(const float* __res
 
 int bsi_film_silu_drop(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride, DropCfg dc,
                        void* y, bsi_stream_t stream) {
-    BSI_CHECK_ARG(h1 && film && y && M > 0 && N > 0 && N % 8 == 0 && HW > 0 && film_rows > 0, "bsi_film_silu: bad args");
+    BSI_CHECK_ARG(h1 && film && y && M > 0 && N > 0 && N % 8 == 0 && HW > 0 && film_rows > 0 && film_stride % 4 == 0 &&
+                      (size_t)M * N < (1ull << 32),
+                  "bsi_film_silu: bad args");
     size_t g = ((size_t)M * (N / 8) + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(film_silu_drop_kernel, dim3((int)g), dim3(256), 0, S_(stream), reinterpret_cast<const __bf16*>(h1), (size_t)M,
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(film_silu_drop_kernel, dim3((int)g), dim3(256), 0, S_(stream), reinterpret_cast<const __bf16*>(h1), (unsigned)M,
                        N, HW, film, film_rows, film_stride, dc, reinterpret_cast<__bf16*>(y));
     BSI_CHECK_LAUNCH("bsi_film_silu");
     return BSI_OK;
@@ -320,9 +328,9 @@ extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, c
                                       bsi_stream_t stream) {
     BSI_CHECK_ARG(da && x1 && gamma && beta && out1 && dgamma && dbeta && B > 0 && HW > 0, "bsi_groupnorm_bwd_nhwc: bad args");
     const int C = C1 + C2;
-    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 4 == 0 && C2 % 4 == 0 && (C2 == 0 || (x2 && out2)),
+    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
-    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B), dim3(1024), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
+    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
                        HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta);
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
     return BSI_OK;

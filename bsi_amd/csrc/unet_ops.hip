@@ -10,21 +10,24 @@ namespace {
 
 // GroupNorm over one image (H*W pixels x C channels, NHWC fp32; optionally the channel-concatenation of two tensors,
 // simplified_unet.py:45-46 `cat((x, x_skip), dim=-3)`), 32 groups, affine, optional SiLU  ->  bf16 NHWC.
-// One workgroup of 1024 threads per image.  Thread t owns the float4 channel chunk (t % CH4) of pixels t / CH4 + k*PPI:
-// every load instruction of a wave covers whole pixels (coalesced), and a thread's chunk always belongs to one group.
+// Groups are independent, so the grid is (image, 32-channel slice): one workgroup of 256 threads normalises the 32/cpg
+// groups of its slice (B*C/32 workgroups fill the chip also at small batch).  Thread t owns the float4 channel chunk
+// (t % 8) of pixels t / 8 + k*32: a wave-instruction covers 8 pixels x 128 B (whole cache lines).
 // Two passes over the image (statistics, then normalise); `raw` optionally receives the un-normalised bf16 copy
 // (A operand of the 1x1 skip convolution, residual_block.py:40).
-__global__ __launch_bounds__(1024) void groupnorm_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
+constexpr int GN_CS = 32, GN_TPB = 256;  // channels per slice, threads per workgroup
+__global__ __launch_bounds__(GN_TPB) void groupnorm_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
                                                          int C2, int HW, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int silu,
                                                          __bf16* __restrict__ out, __bf16* __restrict__ raw) {
-    __shared__ float red_s[2048], red_q[2048];  // [pixel row][2-channel sub-chunk]: PPI * CH4 * 2 = 2048
-    __shared__ float mean_s[32], rstd_s[32];
-    const int C = C1 + C2, CH4 = C / 4;           // float4 chunks per pixel (16, 32 or 64)
+    __shared__ float red_s[512], red_q[512];  // [pixel row][2-channel sub-chunk]: PPI * CH4 * 2 = 512
+    __shared__ float mean_s[16], rstd_s[16];
+    const int C = C1 + C2;
+    constexpr int CH4 = GN_CS / 4;                // float4 chunks per pixel in this slice
     const int cpg = C / 32;                       // channels per group (2, 4 or 8)
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int ch = t % CH4, prow = t / CH4, PPI = 1024 / CH4;  // pixel rows handled in parallel
-    const int c0 = ch * 4;
+    const int b = blockIdx.x, t = threadIdx.x, cs0 = blockIdx.y * GN_CS;
+    const int ch = t % CH4, prow = t / CH4, PPI = GN_TPB / CH4;  // pixel rows handled in parallel
+    const int c0 = cs0 + ch * 4;
     const bool second = c0 >= C1;
     const float* src = second ? x2 + (size_t)b * HW * C2 + (c0 - C1) : x1 + (size_t)b * HW * C1 + c0;
     const int sstride = second ? C2 : C1;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(1024) void groupnorm_kernel(const float* __restrict
     red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
     red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
     __syncthreads();
-    if (t < 32) {  // group t: sub-chunks [t*cpg/2, (t+1)*cpg/2)
+    if (t < GN_CS / cpg) {  // local group t: sub-chunks [t*cpg/2, (t+1)*cpg/2)
         const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
         float ts = 0.f, tq = 0.f;
         for (int r = 0; r < PPI; ++r)
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(1024) void groupnorm_kernel(const float* __restrict
     __syncthreads();
     float mean[4], rstd[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(c0 + k) / cpg]; rstd[k] = rstd_s[(c0 + k) / cpg]; }
+    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(ch * 4 + k) / cpg]; rstd[k] = rstd_s[(ch * 4 + k) / cpg]; }
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
     for (int p = prow; p < HW; p += PPI) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
@@ -152,9 +155,9 @@ extern "C" int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int 
                                   bsi_stream_t stream) {
     BSI_CHECK_ARG(x1 && gamma && beta && out_bf16 && B > 0 && HW > 0, "bsi_groupnorm_nhwc: bad args");
     const int C = C1 + C2;
-    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 4 == 0 && C2 % 4 == 0 && (C2 == 0 || x2),
+    BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || x2),
                   "bsi_groupnorm_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
-    hipLaunchKernelGGL(groupnorm_kernel, dim3(B), dim3(1024), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps, silu,
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps, silu,
                        reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<__bf16*>(raw_bf16));
     BSI_CHECK_LAUNCH("bsi_groupnorm_nhwc");
     return BSI_OK;

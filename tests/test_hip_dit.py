@@ -8,6 +8,7 @@ fp32 residual stream, the BSI wrapper in fp32:
   * against an oracle that rounds the same operands to bf16 (isolates kernel bugs from bf16 rounding): 2e-3.
 """
 import contextlib
+import math
 from unittest import mock
 
 import pytest
@@ -530,3 +531,30 @@ def test_dp_trainer_unet_single_gpu_step():
     with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
         loss2 = tr.train_step(g["x"].to(DEV))
     assert float(loss2) < float(loss) and torch.isfinite(loss2)
+
+
+def test_drivers_on_the_native_path():
+    """ELBO evaluation loop, schedules and sample export (bsi_amd/drivers.py) driving the HIP path: the loop reproduces
+    direct `elbo` / `finite_elbo` calls made with the same generator state; non-linear schedules sample finite images."""
+    from bsi_amd import Discretization, drivers as D
+    model = make_model("dit_ff", True)
+    bsi = make_bsi(model, k=8)
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randint(0, 256, (6, 3, 16, 16), generator=gen).float() / 255) * 2 - 1
+    batches = [x[:4], x[4:]]
+    acc = D.evaluate_elbo(bsi, batches, 2, 2, ["inf", 4], torch.Generator(DEV).manual_seed(11))
+    g2 = torch.Generator(DEV).manual_seed(11)
+    with torch.no_grad():
+        want = [bsi.elbo(b.to(DEV), 2, 2, g2, estimate_var=True) for b in batches]
+        want_f = [bsi.finite_elbo(b.to(DEV), 2, 2, g2, estimate_var=True, t=torch.linspace(0, 1, 5, device=DEV)) for b in batches]
+    for a, w in ((acc["inf"], want), (acc[4], want_f)):
+        bpd = torch.cat([r[1] for r in w]).cpu().double().numpy()
+        var = torch.cat([r[2]["bpd_var"] for r in w]).cpu().double().numpy()
+        assert abs(a.mean() - bpd.mean()) < 1e-9 and abs(a.mean_var() - (bpd.var(ddof=1) + var.mean()) / 6) < 1e-12
+        assert math.isfinite(a.mc_std())
+    for name in D.SCHEDULES:
+        t = D.sampling_schedule(bsi, name, 8)
+        assert t.device.type == "cuda" and abs(float(t[0])) < 1e-6 and abs(float(t[-1]) - 1) < 1e-6
+        out = D.generate_samples(bsi, Discretization.image_8bit(), 5, 2, torch.Generator(DEV).manual_seed(1), t=t)
+        assert out["samples"].shape == (5, 3, 16, 16) and out["images"].dtype == torch.uint8
+        assert torch.isfinite(out["samples"]).all()

@@ -192,6 +192,7 @@ _PROTOS = {
     "bsi_dit_adaln": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                              _vp, _vp, _vp, _vp]),
+    "bsi_clock_probe": (_i, [_vp, _i, _vp]),
     "bsi_prof_enable": (_i, [C.c_uint]),
     "bsi_prof_read": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

@@ -933,6 +933,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + wl;
     if (tile >= hi) return;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (ABL & 64) {  // laboratory builds: shader clock over the kernel = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        clk0 = __builtin_readcyclecounter();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int srow = lane >> 2, spos = lane & 3;
     const char* gsrc[4];
@@ -1075,6 +1080,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                         // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
                         // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
                         if constexpr (ABL & 32) *dst = d[t4];
+                        else if constexpr (ABL & 128) {  // laboratory: everything but the global stores
+                            if (d[t4][0] == 0x12345678u && d[t4][3] == 0x9abcdef0u) *dst = d[t4];
+                        } else if (p.stagger & 64) *dst = d[t4];  // experiment: ordinary (write-back) stores
                         else __builtin_nontemporal_store(d[t4], dst);
                     }
                 }
@@ -1148,12 +1156,235 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             pslot = (pslot == R - 1) ? 0 : pslot + 1;
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        after_e = 2;
+        after_e = (p.stagger & 63) > 0 ? (p.stagger & 63) : 2;  // experiment: phases during which the epilogue's 16 stores may stay in flight
         if (!has_next) break;
         tile = next;
     }
     if (wm == 0) PHASE_BARRIER();
+    if constexpr (ABL & 64) {
+        if (blockIdx.x == 0 && tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out2);
+            o[0] = __builtin_readcyclecounter() - clk0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+    }
 #undef PHASE_BARRIER
+}
+
+extern int g_gm;
+int num_cus();
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 8: ONE WAVE PER SIMD.  4 waves, each owns a 128 x 128 quadrant of the 256 x 256 tile (64 accumulator tiles =
+// 256 registers per lane), K step 64, two 64 KB LDS stages.  Per stage a wave issues 128 MFMAs (2048 matrix-pipe
+// cycles) and, between them, 32 ds_read_b128 (fragments), 16 global_load_dwordx4 (stage s+2 -> registers) and
+// 16 ds_write_b128 (stage s+1 registers -> LDS): every other instruction is shorter than an MFMA's 16-cycle issue
+// interval, so the matrix pipe can stay busy without a partner wave.  Against the 8-wave schedule: 1/3 fewer LDS bytes
+// per FLOP (128 x 128 instead of 128 x 64 per wave), one barrier per 128 MFMAs, no LDS-DMA issue stalls.
+// LDS rows are 128 B; 16-B chunks are XOR-swizzled (activation rows by (row >> 1) & 7, weight rows by
+// ((row >> 1) & 1) | (((row >> 4) & 3) << 1)), which makes the staging writes and every fragment read conflict free.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_bf16_w1_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, RBY = 128, KS = 64;
+    constexpr int A_BYTES = BM * RBY, STAGE = (BM + BN) * RBY;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+
+    // staging: thread -> (row tid >> 3 of a 32-row slab, 16-B chunk tid & 7); slab q = rows 32q .. 32q+31
+    const int srow = tid >> 3, sch = tid & 7;
+    const int a_dst = srow * RBY + ((sch ^ ((srow >> 1) & 7)) << 4);  // + q * 4096
+    // weight rows r = 32q + srow: key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1), (r >> 4) & 3 = (2q + (srow >> 4)) & 3: two values
+    const int w_dst0 = A_BYTES + srow * RBY + ((sch ^ (((srow >> 1) & 1) | (((srow >> 4) & 3) << 1))) << 4);        // even q
+    const int w_dst1 = A_BYTES + srow * RBY + ((sch ^ (((srow >> 1) & 1) | ((((srow >> 4) + 2) & 3) << 1))) << 4);  // odd q
+    // fragments
+    const int rho = lane & 15, qd = lane >> 4;
+    const int xkey = (rho >> 1) & 7, wkey = ((rho >> 1) & 1) | ((rho >> 2) << 1);
+    const int xbase = (wm * 128 + rho) * RBY;                                          // + 16 j rows
+    const int wbase = A_BYTES + (wn * 128 + 16 * (rho >> 2) + (rho & 3)) * RBY;         // + 64 c + 4 i rows
+
+    // two staging register sets (stage parity): global loads run 2.5 stages ahead of their LDS stores
+    u32x4 ra0[8], rw0[8], ra1[8], rw1[8];
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    const unsigned a_slab = 32u * (unsigned)(p.lda * 2), w_slab = 32u * (unsigned)(p.ldw * 2);
+    unsigned a_off, w_off, a_offn, w_offn;  // this tile's and the next tile's row offsets (full tiles only)
+    auto offsets = [&](int t, unsigned& ao, unsigned& wo) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+        ao = (unsigned)(tm_ * BM + srow) * (unsigned)(p.lda * 2) + sch * 16;
+        wo = (unsigned)(tn_ * BN + srow) * (unsigned)(p.ldw * 2) + sch * 16;
+    };
+
+    f32x4 acc[2][4][8];
+    bf16x8 wfa[8], wfb[8], xf[8];  // W fragments of the two 32-wide k halves (double buffer), rolling X fragments
+    const int nk = p.K / KS;      // launcher: even, >= 4
+    const int cx0 = ((qd) ^ xkey) << 4, cx1 = ((4 + qd) ^ xkey) << 4;
+    const int cw0 = ((qd) ^ wkey) << 4, cw1 = ((4 + qd) ^ wkey) << 4;
+    auto rd_w = [&](const char* b, int cw, int idx) {  // idx = 4c + i
+        return *reinterpret_cast<const bf16x8*>(b + wbase + (64 * (idx >> 2) + 4 * (idx & 3)) * RBY + cw);
+    };
+    auto rd_x = [&](const char* b, int cx, int j) { return *reinterpret_cast<const bf16x8*>(b + xbase + 16 * j * RBY + cx); };
+    // accumulators are pinned to AGPRs and updated in place (the builtin lets the register allocator shuttle the 256
+    // accumulator registers between the two halves of the file inside the loop)
+#define W1_GROUP(J, WF)                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[c][i][J]) : "v"(WF[4 * c + i]), "v"(xf[J]))
+    // One stage (K = 64) whose data sits in LDS buffer B:
+    //   k half 0: 8 groups of (2 fragment reads for half 1, 8 MFMAs, [first 4 groups] 4 staging stores of stage s+1 from
+    //             register set RA/RW into the other buffer, whose last readers passed the previous barrier);
+    //   barrier;
+    //   k half 1: 8 groups of (2 fragment reads of stage s+1, 8 MFMAs, 2 global loads of stage s+3 into RA/RW).
+    // X fragment slot j is re-loaded one group after its last use; the reload of slot 7 opens the next half.
+#define W1_STAGE(B, BNX, RA, RW, AK, WK, AO, WO)                                                                     \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
+            if (!(ABL & 2) && j > 0) xf[j - 1] = rd_x(B, cx1, j - 1);                                                \
+            if (!(ABL & 2)) wfb[j] = rd_w(B, cw1, j);                                                                \
+            W1_GROUP(j, wfa);                                                                                        \
+            if (!(ABL & 1) && j < 4) {                                                                               \
+                *reinterpret_cast<u32x4*>(BNX + (2 * j) * 4096 + a_dst) = RA[2 * j];                                 \
+                *reinterpret_cast<u32x4*>(BNX + (2 * j) * 4096 + w_dst0) = RW[2 * j];                                \
+                *reinterpret_cast<u32x4*>(BNX + (2 * j + 1) * 4096 + a_dst) = RA[2 * j + 1];                         \
+                *reinterpret_cast<u32x4*>(BNX + (2 * j + 1) * 4096 + w_dst1) = RW[2 * j + 1];                        \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
+            if (!(ABL & 2)) {                                                                                        \
+                if (j == 0) xf[7] = rd_x(B, cx1, 7);                                                                 \
+                else xf[j - 1] = rd_x(BNX, cx0, j - 1);                                                              \
+                wfa[j] = rd_w(BNX, cw0, j);                                                                          \
+            }                                                                                                        \
+            W1_GROUP(j, wfb);                                                                                        \
+            if (!(ABL & 1)) {                                                                                        \
+                RA[j] = *reinterpret_cast<const u32x4*>(AK + (size_t)j * a_slab + AO);                               \
+                RW[j] = *reinterpret_cast<const u32x4*>(WK + (size_t)j * w_slab + WO);                               \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        if (!(ABL & 2)) xf[7] = rd_x(BNX, cx0, 7);                                                                   \
+    } while (0)
+
+    char* const buf0 = lds;
+    char* const buf1 = lds + STAGE;
+    int tile = lo + wl;
+    if (tile >= hi) return;
+    // pipeline fill: stage 0 -> LDS buffer 0, stage 1 -> set 1, stage 2 -> set 0
+    offsets(tile, a_off, w_off);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        ra0[q] = *reinterpret_cast<const u32x4*>(Ab + (size_t)q * a_slab + a_off);
+        rw0[q] = *reinterpret_cast<const u32x4*>(Wb + (size_t)q * w_slab + w_off);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        *reinterpret_cast<u32x4*>(buf0 + q * 4096 + a_dst) = ra0[q];
+        *reinterpret_cast<u32x4*>(buf0 + q * 4096 + ((q & 1) ? w_dst1 : w_dst0)) = rw0[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        ra1[q] = *reinterpret_cast<const u32x4*>(Ab + (KS * 2) + (size_t)q * a_slab + a_off);
+        rw1[q] = *reinterpret_cast<const u32x4*>(Wb + (KS * 2) + (size_t)q * w_slab + w_off);
+        ra0[q] = *reinterpret_cast<const u32x4*>(Ab + 2 * (KS * 2) + (size_t)q * a_slab + a_off);
+        rw0[q] = *reinterpret_cast<const u32x4*>(Wb + 2 * (KS * 2) + (size_t)q * w_slab + w_off);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wfa[j] = rd_w(buf0, cw0, j); xf[j] = rd_x(buf0, cx0, j); }
+
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+        a_offn = a_off; w_offn = w_off;
+        if (has_next) offsets(next, a_offn, w_offn);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nk; s += 2) {
+            // stage s (buffer 0): stores stage s+1 from set 1, loads stage s+3 into set 1
+            {
+                const bool in_tile = s + 3 < nk;
+                const int k3 = in_tile ? s + 3 : s + 3 - nk;
+                const char* ak = Ab + (size_t)k3 * (KS * 2);
+                const char* wk = Wb + (size_t)k3 * (KS * 2);
+                const unsigned ao = in_tile ? a_off : a_offn, wo = in_tile ? w_off : w_offn;
+                W1_STAGE(buf0, buf1, ra1, rw1, ak, wk, ao, wo);
+            }
+            // stage s+1 (buffer 1): stores stage s+2 from set 0, loads stage s+4 into set 0
+            {
+                const bool in_tile = s + 4 < nk;
+                const int k4 = in_tile ? s + 4 : s + 4 - nk;
+                const char* ak = Ab + (size_t)k4 * (KS * 2);
+                const char* wk = Wb + (size_t)k4 * (KS * 2);
+                const unsigned ao = in_tile ? a_off : a_offn, wo = in_tile ? w_off : w_offn;
+                W1_STAGE(buf1, buf0, ra0, rw0, ak, wk, ao, wo);
+            }
+        }
+        // buffer 0 now holds stage 0 of the next tile (its fragments are already on their way); buffer 1 is free once every
+        // wave has left the last stage: it becomes the epilogue scratch (16 KB per wave).
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        int tm_, tn_;
+        tile_coords(p, tile, tm_, tn_);
+        if constexpr (ABL & 4) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sacc += acc[c][i][j][0] + acc[c][i][j][1] + acc[c][i][j][2] + acc[c][i][j][3];
+            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                gemm_epilogue<8, EPI>(p, acc[c], tm_ * BM + wm * 128, tn_ * BN + wn * 128 + 64 * c, lane, buf1 + wave * 16384);
+        }
+        if (!has_next) break;
+        __builtin_amdgcn_s_barrier();  // scratch reads done before the next tile's stage 1 is stored into buffer 1
+        tile = next;
+        a_off = a_offn; w_off = w_offn;
+    }
+#undef W1_STAGE
+#undef W1_GROUP
+}
+
+template <int EPI>
+int launch_w1(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const size_t lds = 2 * (size_t)512 * 128;
+    auto kern = gemm_bf16_w1_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
 }
 
 template <int TM, int WM, int WN, int EPI>
@@ -1217,6 +1448,7 @@ int launch_pring(const GemmParams& p0, hipStream_t s) {
     p.tiles_n = (p.N + 255) / 256;
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
+    p.stagger = g_stagger;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
@@ -1294,7 +1526,8 @@ int launch_pp(const GemmParams& p0, hipStream_t s) {
 
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t s) {
-    if (g_variant == 6 && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
+    if (g_variant == 8 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 256 && p.K % 128 == 0) return launch_w1<EPI>(p, s);
+    if ((g_variant == 6 || g_variant == 8) && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
     if (g_variant == 4 && p.M > 128) return launch_ring<EPI, 5>(p, s);
     if (g_variant == 5 && p.M > 128) return launch_ring<EPI, 4>(p, s);
     if (g_variant == 3 && p.M > 128) return launch_ppp<EPI>(p, s);
@@ -1310,7 +1543,7 @@ int launch_epi(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int bsi_gemm_set_variant(int v) {
-    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 6, "bsi_gemm_set_variant: unknown variant %d", v);
+    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 8, "bsi_gemm_set_variant: unknown variant %d", v);
     g_variant = v & 0xff;
     g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger of variant 3, in units of 64 clocks per step
     g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of variant 6

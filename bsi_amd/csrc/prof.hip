@@ -67,3 +67,28 @@ extern "C" int bsi_prof_read(int cls, int* count, double* total_ms) {
     *total_ms = tot;
     return BSI_OK;
 }
+
+// Shader-clock probe: one wave spins for ~`us` microseconds of the constant 100 MHz counter and reports
+// {shader cycles, 100 MHz ticks}; launched right after a kernel it shows the DVFS state that kernel left the chip in
+// (power management reacts over milliseconds).  Diagnostic only.
+namespace {
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned ticks) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r = r0;
+    while (r - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_readcyclecounter() - c0;
+        out[1] = r - r0;
+    }
+}
+}  // namespace
+
+extern "C" int bsi_clock_probe(unsigned long long* out /*device, 2 words*/, int us, bsi_stream_t stream) {
+    BSI_CHECK_ARG(out && us > 0 && us <= 100000, "bsi_clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out, (unsigned)us * 100u);
+    BSI_CHECK_LAUNCH("bsi_clock_probe");
+    return BSI_OK;
+}

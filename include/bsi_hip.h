@@ -498,6 +498,8 @@ enum {
 /* bit i of mask enables class i; 0 disables.  Events are recorded around every launch of an enabled class
  * made through bsi_dit_forward / bsi_dit_adaln. */
 int bsi_prof_enable(unsigned mask);
+/* Diagnostic: shader clock seen by a one-wave kernel spinning `us` microseconds: out = {shader cycles, 100 MHz ticks}. */
+int bsi_clock_probe(unsigned long long* out /*device*/, int us, bsi_stream_t stream);
 /* Waits for the recorded launches of `cls`, returns their count and summed duration, and clears them. */
 int bsi_prof_read(int cls, int* count, double* total_ms);
 

@@ -2,7 +2,9 @@
 // ablated / alternative schedules with HIP events.  Build + run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I bsi_amd/csrc tools/experiments/gemm_lab.hip -o /tmp/gemm_lab && /tmp/gemm_lab
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../bsi_amd/csrc/gemm_bf16.hip"
@@ -31,6 +33,7 @@ template <int EPI, int ABL>
 float time_pring(GemmParams p, int iters) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
+    p.gm = 4;
     const size_t lds = 4 * 512 * 64 + 32768;
     auto kern = gemm_bf16_pring_kernel<EPI, ABL>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -40,6 +43,27 @@ float time_pring(GemmParams p, int iters) {
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
     hipEventRecord(a, 0);
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
+template <int EPI, int ABL>
+float time_w1(GemmParams p, int iters) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = 4;
+    const size_t lds = 2 * 512 * 128;
+    auto kern = gemm_bf16_w1_kernel<EPI, ABL>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int grid = 256;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, p);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, p);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms = 0;
@@ -68,6 +92,44 @@ int main() {
         const double fl = 2.0 * M * sh.N * sh.K;
         auto rep = [&](const char* what, float ms) { printf("%s %-28s %8.3f ms %8.0f TF\n", sh.name, what, ms, fl / ms / 1e9); };
         constexpr int E = BSI_EPI_BIAS_BF16;
+        if (getenv("LAB_CLK")) {
+            // shader clock under load for two operand distributions: the narrow-exponent lab data above, and N(0,1)
+            // activations x U(-1/sqrt(K), 1/sqrt(K)) weights (what the model feeds the kernel)
+            unsigned long long* dC; hipMalloc(&dC, 64);
+            GemmParams q = p; q.out2 = dC;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {
+                    auto f2b = [](float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
+                    for (auto& v : ha) {
+                        float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX;
+                        v = f2b(sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2));
+                    }
+                    for (auto& v : hw) v = f2b((2.f * rand() / (float)RAND_MAX - 1.f) / sqrtf((float)sh.K));
+                    hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+                    hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
+                }
+                for (int rep_i = 0; rep_i < 2; ++rep_i) {
+                    float ms = time_pring<E, 64>(q, 50);
+                    unsigned long long hc[2];
+                    hipMemcpy(hc, dC, 16, hipMemcpyDeviceToHost);
+                    printf("%s %-14s %8.3f ms %8.0f TF   shader clock %.0f MHz\n", sh.name, pass ? "randn data" : "lab data", ms,
+                           fl / ms / 1e9, 100.0 * hc[0] / hc[1]);
+                }
+            }
+            continue;
+        }
+        if (getenv("LAB_W1")) {
+            rep("v6 full", time_pring<E, 0>(p, 20));
+            rep("v6 epilogue w/o global stores", time_pring<E, 128>(p, 20));
+            rep("v6 no epilogue", time_pring<E, 4>(p, 20));
+            rep("w1 full", time_w1<E, 0>(p, 20));
+            rep("w1 no epilogue", time_w1<E, 4>(p, 20));
+            rep("w1 no gload/lstore, no epi", time_w1<E, 5>(p, 20));
+            rep("w1 no frag reads, no epi", time_w1<E, 6>(p, 20));
+            rep("w1 mfma + barrier only", time_w1<E, 7>(p, 20));
+            rep("w1 mfma only", time_w1<E, 15>(p, 20));
+            continue;
+        }
         if (getenv("LAB_V6")) {
             constexpr int G = BSI_EPI_BIAS_GELU_BF16;
             rep("v6 full", time_pring<E, 0>(p, 20));

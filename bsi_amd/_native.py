@@ -228,6 +228,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("BSI_GEMM_VARIANT"):  # kernel experiments (tools/gemm_bench.py documents the encoding)
+            _lib.bsi_gemm_set_variant(int(os.environ["BSI_GEMM_VARIANT"]))
     return _lib
 
 

@@ -1076,14 +1076,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                 for (int t4 = 0; t4 < 4; ++t4) {
                     const int m = mw0 + 32 * rnd + 8 * t4 + rr;
                     if (m < p.M && cols_ok) {
-                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nw0 + 8 * ch);
+                        const int m_dst = (ABL & 256) ? (m & 255) : m;  // laboratory: all tiles write the same 256 rows
+                        if ((ABL & 512) && rnd != 0) continue;           // laboratory: a quarter of the stores
+                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m_dst * p.ldo + nw0 + 8 * ch);
                         // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
                         // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
                         if constexpr (ABL & 32) *dst = d[t4];
                         else if constexpr (ABL & 128) {  // laboratory: everything but the global stores
                             if (d[t4][0] == 0x12345678u && d[t4][3] == 0x9abcdef0u) *dst = d[t4];
-                        } else if (p.stagger & 64) *dst = d[t4];  // experiment: ordinary (write-back) stores
-                        else __builtin_nontemporal_store(d[t4], dst);
+                        } else __builtin_nontemporal_store(d[t4], dst);
                     }
                 }
             }
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             pslot = (pslot == R - 1) ? 0 : pslot + 1;
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        after_e = (p.stagger & 63) > 0 ? (p.stagger & 63) : 2;  // experiment: phases during which the epilogue's 16 stores may stay in flight
+        after_e = 2;
         if (!has_next) break;
         tile = next;
     }

@@ -121,6 +121,10 @@ int main() {
         if (getenv("LAB_W1")) {
             rep("v6 full", time_pring<E, 0>(p, 20));
             rep("v6 epilogue w/o global stores", time_pring<E, 128>(p, 20));
+            rep("v6 stores into 256 rows (nt)", time_pring<E, 256>(p, 20));
+            rep("v6 stores into 256 rows (wb)", time_pring<E, 256 | 32>(p, 20));
+            rep("v6 quarter of the stores (nt)", time_pring<E, 512>(p, 20));
+            rep("v6 normal stores", time_pring<E, 32>(p, 20));
             rep("v6 no epilogue", time_pring<E, 4>(p, 20));
             rep("w1 full", time_w1<E, 0>(p, 20));
             rep("w1 no epilogue", time_w1<E, 4>(p, 20));

@@ -89,7 +89,7 @@ class DPTrainer:
 
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
-                 ema_update_after_step: int = 1000, lr_schedule=None, process_group=None):
+                 ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False):
         self.bsi = bsi
         self.model = bsi.model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -97,6 +97,9 @@ class DPTrainer:
         self.lr_schedule = lr_schedule  # callable step -> lr, or None for constant lr
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_exchange runs the gradient exchange (events, side stream, RCCL calls) even in a group of one rank, so that
+        # the multi-GPU code path can be exercised on a single device
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
         self.step_count = 0
         self.ema_beta, self.ema_after = ema_beta, ema_update_after_step
         self._invalidate(self.model)
@@ -115,9 +118,9 @@ class DPTrainer:
         if self.bucketed:
             self.head_span = (0, self.block_spans[0][0])                     # patch encoder
             self.tail_span = (self.block_spans[-1][1], self.fp.flat.numel())  # decoder
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
         self.events = None
-        if self.world > 1 and self.bucketed:
+        if self.exchange and self.bucketed:
             self.events = [torch.cuda.Event() for _ in range(depth)]
             for e in self.events:
                 e.record()  # instantiate the underlying hipEvent_t
@@ -135,19 +138,19 @@ class DPTrainer:
         for p in self.model.parameters():
             p.grad = None
         self.model._last_flat_grad = None
-        if self.world > 1 and self.bucketed:
+        if self.exchange and self.bucketed:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
         loss = self.bsi.train_loss(x, generator).mean()
         loss.backward()
         flat_g = self.model._last_flat_grad
         assert flat_g is not None, "the HIP training engine did not run (model is not a native denoiser?)"
-        if self.world > 1 and not self.bucketed:
+        if self.exchange and not self.bucketed:
             cur = torch.cuda.current_stream()
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=self.group)
             cur.wait_stream(self.comm_stream)
-        elif self.world > 1:
+        elif self.exchange:
             N.check(lib.bsi_dit_backward_set_events(None, 0))
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self.comm_stream):

@@ -558,3 +558,41 @@ def test_drivers_on_the_native_path():
         out = D.generate_samples(bsi, Discretization.image_8bit(), 5, 2, torch.Generator(DEV).manual_seed(1), t=t)
         assert out["samples"].shape == (5, 3, 16, 16) and out["images"].dtype == torch.uint8
         assert torch.isfinite(out["samples"]).all()
+
+
+def test_dp_trainer_exchange_path_on_one_rank():
+    """The multi-GPU gradient exchange (HIP events recorded by the backward, side stream, RCCL all-reduce per block bucket)
+    forced on in a process group of ONE rank: the step must equal the exchange-free step bit for bit (sum over one rank,
+    1/world = 1), for the DiT (bucketed) and the UNet (single bucket)."""
+    import os
+    import tempfile
+    import torch.distributed as dist
+    from bsi_amd.dp import DPTrainer
+    store = tempfile.NamedTemporaryFile(delete=False)
+    store.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"file://{store.name}", rank=0, world_size=1)
+    try:
+        for make, gname, shape in ((lambda: make_model("dit_ff", True).train(), "g4_train_dit", (3, 16, 16)),
+                                   (lambda: make_unet(), "g4_train_unet", (3, 8, 8))):
+            g = golden(gname)
+            outs = []
+            for force in (False, True):
+                torch.manual_seed(5)
+                model = make()
+                model._drop_calls = 0
+                tr = DPTrainer(make_bsi(model, shape), lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0,
+                               force_exchange=force)
+                assert tr.exchange == force
+                for _ in range(2):
+                    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+                        loss = tr.train_step(g["x"].to(DEV))
+                torch.cuda.synchronize()
+                outs.append((float(loss), tr.fp.flat.clone(), tr.ema_fp.flat.clone()))
+            assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]), (gname, outs[0][0], outs[1][0])
+            # atomics in the backward make the low bits run-dependent; the two paths must agree to fp32 noise
+            assert rel_linf(outs[1][1], outs[0][1]) < 1e-5 and rel_linf(outs[1][2], outs[0][2]) < 1e-5, gname
+    finally:
+        dist.destroy_process_group()
+        if os.path.exists(store.name):
+            os.unlink(store.name)

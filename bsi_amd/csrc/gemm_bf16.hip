@@ -907,9 +907,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p)
 //     per tile instead of prologue + two epilogues + store drain;
 //   * bf16 outputs leave through the LDS scratch in 4 rounds of 32 rows so that every store instruction writes
 //     whole 128-B lines.
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool ROLL = false, int RING = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p) {
-    constexpr int TM = 8, NW = 8, R = 4, D = R - 1;
+    // ROLL: the activation fragments of step v+1 are fetched DURING the MFMA phase of step v (fragment register j is
+    // re-loaded right after the four MFMAs that consume it), so the load phase shrinks to the weight fragments + the DMA
+    // issue and stops being longer than the partner group's MFMA phase.
+    constexpr int TM = 8, NW = 8, R = RING, D = R - 1;
     constexpr int BM = 256, BN = 256;
     constexpr int RB = 64;
     constexpr int SLOT_BYTES = (BM + BN) * RB;
@@ -1101,6 +1104,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
     PHASE_BARRIER();
     if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+    if constexpr (ROLL) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(lds + xoff + j * 16 * RB);
+    }
 
     int slot = 0, pslot = D;
     int after_e = 0;  // L phases since the last epilogue whose stores may still be in flight
@@ -1115,10 +1122,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             // ---- L(v)
             {
                 const char* b = lds + slot * SLOT_BYTES;
+                if constexpr (!(ABL & 2)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
+                    if constexpr (!ROLL) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
+                        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
+                    }
+                } else if (v == 0) {  // laboratory: fragments read once per tile only
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
+                }
             }
             bool issued = false;
             if constexpr (!(ABL & 1)) {
@@ -1145,11 +1161,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             PHASE_BARRIER();
             // ---- C(v)
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (ROLL) {
+                const char* bnx = lds + ((slot == R - 1) ? 0 : slot + 1) * SLOT_BYTES;  // stage v+1 (landed before this phase)
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
+                for (int j = 0; j < TM; ++j) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    xf[j] = *reinterpret_cast<const bf16x8*>(bnx + xoff + j * 16 * RB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
             PHASE_BARRIER();
@@ -1442,7 +1470,7 @@ int launch_ring(const GemmParams& p0, hipStream_t s) {
 
 int num_cus();
 
-template <int EPI>
+template <int EPI, bool ROLL = false>
 int launch_pring(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + 255) / 256;
@@ -1453,7 +1481,7 @@ int launch_pring(const GemmParams& p0, hipStream_t s) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
-    auto kern = gemm_bf16_pring_kernel<EPI>;
+    auto kern = gemm_bf16_pring_kernel<EPI, 0, ROLL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1528,6 +1556,7 @@ int launch_pp(const GemmParams& p0, hipStream_t s) {
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t s) {
     if (g_variant == 8 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 256 && p.K % 128 == 0) return launch_w1<EPI>(p, s);
+    if (g_variant == 9 && p.M > 128 && p.K >= 96) return launch_pring<EPI, true>(p, s);
     if ((g_variant == 6 || g_variant == 8) && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
     if (g_variant == 4 && p.M > 128) return launch_ring<EPI, 5>(p, s);
     if (g_variant == 5 && p.M > 128) return launch_ring<EPI, 4>(p, s);
@@ -1544,7 +1573,7 @@ int launch_epi(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int bsi_gemm_set_variant(int v) {
-    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 8, "bsi_gemm_set_variant: unknown variant %d", v);
+    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 9, "bsi_gemm_set_variant: unknown variant %d", v);
     g_variant = v & 0xff;
     g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger of variant 3, in units of 64 clocks per step
     g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of variant 6

@@ -29,13 +29,13 @@ float time_pp(GemmParams p, int iters) {
     return ms / iters;
 }
 
-template <int EPI, int ABL>
+template <int EPI, int ABL, int RING = 4>
 float time_pring(GemmParams p, int iters) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = 4;
-    const size_t lds = 4 * 512 * 64 + 32768;
-    auto kern = gemm_bf16_pring_kernel<EPI, ABL>;
+    const size_t lds = RING == 4 ? 4 * 512 * 64 + 32768 : RING * 512 * 64;  // RING 5: no epilogue scratch (ABL & 4 only)
+    auto kern = gemm_bf16_pring_kernel<EPI, ABL, false, RING>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -126,6 +126,11 @@ int main() {
             rep("v6 quarter of the stores (nt)", time_pring<E, 512>(p, 20));
             rep("v6 normal stores", time_pring<E, 32>(p, 20));
             rep("v6 no epilogue", time_pring<E, 4>(p, 20));
+            rep("v6 no epi, ring 5", time_pring<E, 4, 5>(p, 20));
+            rep("v6 no epi, ring 3", time_pring<E, 4, 3>(p, 20));
+            rep("v6 no epi, no glds", time_pring<E, 5>(p, 20));
+            rep("v6 no epi, no frag reads", time_pring<E, 6>(p, 20));
+            rep("v6 no epi, no glds, no frag reads", time_pring<E, 7>(p, 20));
             rep("w1 full", time_w1<E, 0>(p, 20));
             rep("w1 no epilogue", time_w1<E, 4>(p, 20));
             rep("w1 no gload/lstore, no epi", time_w1<E, 5>(p, 20));

@@ -259,43 +259,36 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(bsi_gate_bwd(ws.dX, bt.d2, tp.x, ml + 5 * dim, mod_stride, dml + 5 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
         // dh = dd2 . W2, times gelu'(hp)  -> dhp
         TRY(gemm(ws.dd, dim, bT.fc2_wT, dim, nullptr, ws.dbig, 4 * dim, M, 4 * dim, dim, BSI_EPI_MUL_GELUGRAD_BF16, bt.hp, nullptr, nullptr, 0, stream));
-        TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, bg.fc2_b, 0, ws.cs, stream));
+        TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, bg.fc2_b, 0, ws.tn, stream));
         // dxn2 = dhp . W1
         TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_gemm_tn_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dbig, 4 * dim, M, 4 * dim, bg.fc1_b, 0, ws.cs, stream));
+        TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, bg.fc1_b, 0, ws.tn, stream));
         TRY(bsi_ln_mod_bwd_drop(ws.dsmall, tp.x, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX, M,
                                 dim, d.tokens, 1e-5f, make_drop(dropout_p, seed, 2 * l + 1), stream));
         // ---- attention branch: x1 = x0 + g_a * d1
         TRY(bsi_gate_bwd(ws.dX, bt.d1, tp.x, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
-        TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, bg.out_b, 0, ws.cs, stream));
+        TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
                                    make_drop(dropout_p, seed, 2 * l), stream));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
-        TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
-        TRY(bsi_colsum_bf16(ws.dbig, 3 * dim, M, 3 * dim, bg.qkv_b, 0, ws.cs, stream));
+        TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
         TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, M, dim, d.tokens, 1e-5f, stream));
         {   // adaLN MLP of this block (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2, rows = samples
             const float* pre = tp.ada_pre + (size_t)l * B * dim;
             const char* sl = tp.ada_s + (size_t)l * B * dim * 2;
             // contiguous bf16 copy of dmod[:, l, :]
             TRY(bsi_cast_rows_bf16(ws.dmod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
-            TRY(bsi_gemm_tn_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, 0, ws.tn, stream));
-            TRY(bsi_colsum_bf16(ws.dmod_bf, 6 * dim, B, 6 * dim, bg.ada2_b, 0, ws.cs, stream));
+            TRY(bsi_gemm_tn_bias_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, bg.ada2_b, 0, ws.tn, stream));
             TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
             TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));
-            TRY(bsi_gemm_tn_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, 0, ws.tn, stream));
-            TRY(bsi_colsum_bf16(ws.dpre_bf, dim, B, dim, bg.ada0_b, 0, ws.cs, stream));
+            TRY(bsi_gemm_tn_bias_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, bg.ada0_b, 0, ws.tn, stream));
         }
         if (g_block_events && l < g_block_events_n && g_block_events[l]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(g_block_events[l]), s);
     }
     // patch encoder (dit.py:154,178): x0 = A0 . Wenc^T + b + pos
     TRY(bsi_silu_bwd_bf16(ws.dX, nullptr, (size_t)M * dim, ws.dd, stream));  // bf16 copy of dX
-    TRY(bsi_gemm_tn_bf16(ws.dd, dim, tp.a0, d.kpad, M, dim, d.kpad, g->enc_w_padded, d.kpad, 0, ws.tn, stream));
-    TRY(bsi_colsum_bf16(ws.dd, dim, M, dim, g->enc_b, 0, ws.cs, stream));
+    TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, tp.a0, d.kpad, M, dim, d.kpad, g->enc_w_padded, d.kpad, g->enc_b, 0, ws.tn, stream));
 
     return BSI_OK;
 }

@@ -23,6 +23,8 @@ struct TnParams {
     int ldp, ldq, ldc;
     int tiles_n, tiles_k, splits, m_per_split;
     size_t slab_stride;  // floats between slabs
+    float* colsum;       // optional: [splits][colsum_stride] column sums of P (bias gradient), written by the k-tile-0 workgroups
+    size_t colsum_stride;
 };
 
 constexpr int T_RB = 512;                 // bytes per LDS row (256 bf16 columns)
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4], bf[8];
+    // fused bias gradient: column sums of the P tile = one extra MFMA with an all-ones A operand; wave wk takes the
+    // column tiles 2wk and 2wk+1 of its P half, workgroups of k-tile 0 only
+    const bool do_colsum = p.colsum != nullptr && (tile % p.tiles_k) == 0;
+    f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
 #define TN_BARRIER()                             \
     do {                                         \
@@ -153,6 +159,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
                 }
             }
         }
+        bf16x8 onesf;
+        {
+            const int valid = mend - (mbeg + v * 32);  // >= 32 except in the ragged tail stage
+#pragma unroll
+            for (int e = 0; e < 8; ++e) onesf[e] = (8 * q + e < valid) ? (__bf16)1.0f : (__bf16)0.0f;
+        }
         TN_BARRIER();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -160,6 +172,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (do_colsum) {
+            const bf16x8 b0 = wk == 0 ? bf[0] : wk == 1 ? bf[2] : wk == 2 ? bf[4] : bf[6];
+            const bf16x8 b1 = wk == 0 ? bf[1] : wk == 1 ? bf[3] : wk == 2 ? bf[5] : bf[7];
+            accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, b0, accb[0], 0, 0, 0);
+            accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, b1, accb[1], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         TN_BARRIER();
         slot = (slot == T_R - 1) ? 0 : slot + 1;
@@ -169,6 +187,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 #undef TN_BARRIER
 #undef TR
 
+    if (do_colsum && lane < 16) {  // D row 0 (lanes 0..15, register 0) holds the column sums
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int n = n0 + 128 * wg + 16 * (2 * wk + jj) + lane;
+            if (n < p.N) p.colsum[(size_t)split * p.colsum_stride + n] = accb[jj][0];
+        }
+    }
     // D rows = k (4*(lane>>4) + reg inside A tile i), D cols = n (lane & 15 inside B tile j)
     float* out = p.out + (size_t)split * p.slab_stride;
 #pragma unroll
@@ -259,8 +284,8 @@ int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, 
 }
 
 extern "C" size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K) {
-    // worst case number of splits is 16
-    return (size_t)16 * (size_t)N * (size_t)K * sizeof(float);
+    // worst case number of splits is 16; the fused bias gradient needs 16 x N more floats behind the tile slabs
+    return (size_t)16 * (size_t)N * (size_t)K * sizeof(float) + (size_t)16 * (size_t)((N + 3) / 4 * 4) * sizeof(float);
 }
 
 static int tn_splits(int M, int N, int K, int num_cus) {
@@ -272,8 +297,8 @@ static int tn_splits(int M, int N, int K, int num_cus) {
     return s < 1 ? 1 : s;
 }
 
-extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
-                                int accumulate, void* workspace, bsi_stream_t stream) {
+static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc, float* colsum_out,
+                       int accumulate, void* workspace, bsi_stream_t stream) {
     BSI_CHECK_ARG(P && Q && out && M > 0 && N > 0 && K > 0, "bsi_gemm_tn_bf16: bad args");
     BSI_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldp % 8 == 0 && ldq % 8 == 0 && ldp >= N && ldq >= K,
                   "bsi_gemm_tn_bf16: N=%d K=%d ldp=%d ldq=%d must be multiples of 8", N, K, ldp, ldq);
@@ -298,6 +323,12 @@ extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, 
     BSI_CHECK_ARG(direct || workspace, "bsi_gemm_tn_bf16: workspace required");
     p.out = direct ? out : reinterpret_cast<float*>(workspace);
     p.slab_stride = (size_t)N * ldc;
+    const size_t n4 = (size_t)(N + 3) / 4 * 4;
+    float* cs_slabs = reinterpret_cast<float*>(workspace) + (size_t)16 * N * K;
+    if (colsum_out) {
+        p.colsum = direct ? colsum_out : cs_slabs;
+        p.colsum_stride = n4;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -306,9 +337,26 @@ extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, 
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");
-    if (!direct) return bsi_reduce_slabs_launch(reinterpret_cast<const float*>(workspace), p.slab_stride, p.splits, (size_t)N * ldc,
-                                                accumulate, out, s);
+    if (!direct) {
+        if (colsum_out) {
+            int rc = bsi_reduce_slabs_launch(cs_slabs, n4, p.splits, n4 <= (size_t)N ? n4 : (size_t)N / 4 * 4, accumulate, colsum_out, s);
+            if (rc) return rc;
+        }
+        return bsi_reduce_slabs_launch(reinterpret_cast<const float*>(workspace), p.slab_stride, p.splits, (size_t)N * ldc,
+                                       accumulate, out, s);
+    }
     return BSI_OK;
+}
+
+extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
+                                int accumulate, void* workspace, bsi_stream_t stream) {
+    return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, out, ldc, nullptr, accumulate, workspace, stream);
+}
+
+extern "C" int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
+                                     float* colsum_out, int accumulate, void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(colsum_out && workspace && N % 4 == 0, "bsi_gemm_tn_bias_bf16: bad args");
+    return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, out, ldc, colsum_out, accumulate, workspace, stream);
 }
 
 extern "C" size_t bsi_colsum_workspace_bytes(int N) { return (size_t)64 * (size_t)((N + 3) / 4 * 4) * sizeof(float); }

@@ -363,12 +363,10 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
 
     // FiLM projections and pos_map (rows = samples)
     TRY(bsi_cast_rows_bf16(ws.dfilm, d.F, B, d.F, ws.dfilm_bf, d.F, stream));
-    TRY(bsi_gemm_tn_bf16(ws.dfilm_bf, d.F, tp.c2, cd, B, d.F, cd, g->film_w, cd, 0, ws.tn, stream));
-    TRY(bsi_colsum_bf16(ws.dfilm_bf, d.F, B, d.F, g->film_b, 0, ws.cs, stream));
+    TRY(bsi_gemm_tn_bias_bf16(ws.dfilm_bf, d.F, tp.c2, cd, B, d.F, cd, g->film_w, cd, g->film_b, 0, ws.tn, stream));
     TRY(gemm(ws.dfilm_bf, d.F, wT->film_wT, d.F, nullptr, ws.dc, cd, B, cd, d.F, BSI_EPI_BIAS_F32, stream));
     TRY(bsi_silu_bwd_bf16(ws.dc, tp.pre2, (size_t)B * cd, ws.dpre_bf, stream));
-    TRY(bsi_gemm_tn_bf16(ws.dpre_bf, cd, tp.c1, cd, B, cd, cd, g->pm3_w, cd, 0, ws.tn, stream));
-    TRY(bsi_colsum_bf16(ws.dpre_bf, cd, B, cd, g->pm3_b, 0, ws.cs, stream));
+    TRY(bsi_gemm_tn_bias_bf16(ws.dpre_bf, cd, tp.c1, cd, B, cd, cd, g->pm3_w, cd, g->pm3_b, 0, ws.tn, stream));
     TRY(gemm(ws.dpre_bf, cd, wT->pm3_wT, cd, nullptr, ws.dc, cd, B, cd, cd, BSI_EPI_BIAS_F32, stream));
     TRY(bsi_silu_bwd_bf16(ws.dc, tp.pre1, (size_t)B * cd, ws.dpre_bf, stream));
     TRY(bsi_gemm_tn_bf16(ws.dpre_bf, cd, tp.emb, 64, B, cd, 64, g->pm1_w_padded, 64, 0, ws.tn, stream));

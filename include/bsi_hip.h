@@ -173,6 +173,10 @@ int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
 size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K);
 int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
                      int accumulate, void* workspace, bsi_stream_t stream);
+/* Same, plus colsum_out[N] (+)= sum_m P[m, :] from the same launch (the bias gradient of the Linear: one extra MFMA with an
+ * all-ones operand per stage in the workgroups of the first k tile, instead of a second pass over dY). */
+int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
+                          float* colsum_out, int accumulate, void* workspace, bsi_stream_t stream);
 /* Bias gradient: out[n] (+)= sum_m Y[m,n] for bf16 Y [M, ld]. */
 size_t bsi_colsum_workspace_bytes(int N);
 int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,

@@ -338,7 +338,7 @@ def test_resid_ln_modulate(N, M, d, tokens, mod_rows):
 
 
 @pytest.mark.parametrize("M,Nn,K", [(512, 256, 256), (4096, 1024, 1024), (16384, 3072, 1024), (8192, 1024, 4096),
-                                     (1000 * 32, 128, 384), (544, 512, 128)])
+                                     (1000 * 32, 128, 384), (544, 512, 128), (4, 768, 128), (300, 64, 64)])
 def test_gemm_tn_and_colsum(N, M, Nn, K):
     """dW = dY^T X and db = colsum(dY) (backward of nn.Linear) vs fp64 on the same bf16 operands."""
     gen = torch.Generator().manual_seed(M + Nn + K)
@@ -357,6 +357,13 @@ def test_gemm_tn_and_colsum(N, M, Nn, K):
     ws2 = torch.empty(N.lib().bsi_colsum_workspace_bytes(Nn), dtype=torch.uint8, device=DEV)
     N.check(N.lib().bsi_colsum_bf16(N.ptr(dP), Nn, M, Nn, N.ptr(cs), 0, N.ptr(ws2), N.stream()))
     assert rel_linf(cs, dY.double().sum(0)) < 1e-5
+    # fused: weight and bias gradient from one launch (+ accumulate)
+    out2, cs2 = empty(Nn, K), empty(Nn)
+    for acc_flag, mult in ((0, 1), (1, 2)):
+        N.check(N.lib().bsi_gemm_tn_bias_bf16(N.ptr(dP), Nn, N.ptr(dQ), K, M, Nn, K, N.ptr(out2), K, N.ptr(cs2), acc_flag, N.ptr(ws),
+                                              N.stream()))
+        assert rel_linf(out2, mult * ref) < 3e-5
+        assert rel_linf(cs2, mult * dY.double().sum(0)) < 1e-5, rel_linf(cs2, mult * dY.double().sum(0))
 
 
 # ----------------------------------------------------------------------------------------------

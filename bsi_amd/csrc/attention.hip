@@ -67,6 +67,11 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
         for (int jq = 0; jq < 2; ++jq) o[dt][jq] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY};
     float l_run[2] = {0.f, 0.f};
+    unsigned rowh[2] = {0u, 0u};
+    if constexpr (DROP) {
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) rowh[jq] = drop_row(dc, (unsigned)bh * tokens + q0 + 16 * jq + c16);
+    }
 
     for (int kc0 = 0; kc0 < tokens; kc0 += KC) {
         __syncthreads();  // previous chunk fully consumed
@@ -118,10 +123,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
                 for (int r = 0; r < 4; ++r) {
                     float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
                     ps += pv;  // the normaliser uses the undropped probabilities
-                    if constexpr (DROP) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only
-                        const unsigned long long e = ((unsigned long long)bh * tokens + (q0 + 16 * jq + c16)) * tokens +
-                                                     (kc0 + 16 * kt + 4 * g + r);
-                        pv = drop_keep(dc, e) ? pv * dc.scale : 0.0f;
+                    if constexpr (DROP) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only:
+                        // element (row = (b, h, query), column = key)
+                        pv = drop_keep_rc(dc, rowh[jq], kc0 + 16 * kt + 4 * g + r) ? pv * dc.scale : 0.0f;
                     }
                     s[kt][jq][r] = pv;
                 }

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
     char* Dl = Vl + T * RB;                              // dO
     float* lse_s = reinterpret_cast<float*>(Dl + T * RB);  // [T] lse * log2(e)
     float* dlt_s = lse_s + T;                            // [T] delta = rowsum(dO * O)
+    unsigned* rowh_s = reinterpret_cast<unsigned*>(dlt_s + T);  // [T] per-query dropout row hash
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
         if (hlf == 0) {
             dlt_s[r] = a;
             lse_s[r] = lse[(size_t)bh * T + r] * L2E;
+            rowh_s[r] = drop_row(dc, (unsigned)bh * T + r);
         }
     }
     __syncthreads();
@@ -123,11 +125,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], sl2, -lq[jq]));
                         float dpv = dp[kt][jq][r];
-                        if (dc.thr) {
-                            const unsigned long long e = ((unsigned long long)bh * T + (r0 + 16 * jq + c16)) * T +
-                                                         (kc + 16 * kt + 4 * g + r);
-                            dpv = drop_keep(dc, e) ? dpv * dc.scale : 0.0f;
-                        }
+                        if (dc.thr) dpv = drop_keep_rc(dc, rowh_s[r0 + 16 * jq + c16], kc + 16 * kt + 4 * g + r) ? dpv * dc.scale : 0.0f;
                         s[kt][jq][r] = scale * pv * (dpv - dq_delta[jq]);
                     }
             // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
@@ -209,9 +207,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const __bf16* __rest
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[qt][jk][r], sl2, -lr[r]));
                         float dpv = dp[qt][jk][r], pd = pv;
                         if (dc.thr) {
-                            const unsigned long long e = ((unsigned long long)bh * T + (qc + 16 * qt + 4 * g + r)) * T +
-                                                         (r0 + 16 * jk + c16);
-                            const bool keep = drop_keep(dc, e);
+                            const bool keep = drop_keep_rc(dc, rowh_s[qc + 16 * qt + 4 * g + r], r0 + 16 * jk + c16);
                             dpv = keep ? dpv * dc.scale : 0.0f;
                             pd = keep ? pv * dc.scale : 0.0f;
                         }
@@ -273,11 +269,11 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
     BSI_CHECK_ARG(dh == 64, "bsi_attention_bwd: head dim %d unsupported (64)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
     BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 4 == 0, "bsi_attention_bwd: bad leading dimensions");
-    const size_t lds = (size_t)4 * tokens * RB + 2 * tokens * sizeof(float);
+    const size_t lds = (size_t)4 * tokens * RB + 3 * tokens * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * 256 * RB + 2 * 256 * 4);
+                                  4 * 256 * RB + 3 * 256 * 4);
         attr_set = true;
     }
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(512), lds, reinterpret_cast<hipStream_t>(stream),

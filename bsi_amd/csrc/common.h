@@ -104,6 +104,12 @@ __host__ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned lo
     const unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
     return bsi_mix32(lo ^ bsi_mix32(hi + c.s0) ^ c.s1) >= c.thr;
 }
+// Elements are addressed as (row, column) = the (high, low) words of the index: the inner hash depends on the row only, so
+// kernels hoist it per row (drop_row) and pay one 32-bit mix per element (drop_keep_rc) with no 64-bit arithmetic.
+__host__ __device__ __forceinline__ unsigned drop_row(const DropCfg& c, unsigned row) { return bsi_mix32(row + c.s0) ^ c.s1; }
+__host__ __device__ __forceinline__ bool drop_keep_rc(const DropCfg& c, unsigned rowh, unsigned col) {
+    return bsi_mix32(col ^ rowh) >= c.thr;  // == drop_keep(c, ((unsigned long long)row << 32) | col)
+}
 inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
     DropCfg c{};
     if (p <= 0.f) return c;

@@ -127,9 +127,9 @@ __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* _
             dv[i] = (c < d4) ? bf16x4_to_f32(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d)[c])
                              : f32x4{0.f, 0.f, 0.f, 0.f};
             if (dc.thr && c < d4) {  // gradient through the forward's dropout mask
-                const unsigned long long e0 = (unsigned long long)row * d + (unsigned long long)c * 4;
+                const unsigned rh = drop_row(dc, (unsigned)row);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dv[i][k] = drop_keep(dc, e0 + k) ? dv[i][k] * dc.scale : 0.0f;
+                for (int k = 0; k < 4; ++k) dv[i][k] = drop_keep_rc(dc, rh, (unsigned)c * 4 + k) ? dv[i][k] * dc.scale : 0.0f;
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }

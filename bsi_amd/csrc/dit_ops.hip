@@ -119,9 +119,9 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
                 for (int k = 0; k < 4; ++k) y[k] = __fmaf_rn(y[k], a[k], b[k]);
             }
             if (dc.thr) {  // nn.Dropout in front of the MLP (dit.py:70,101), training only
-                const unsigned long long e0 = (unsigned long long)row * d + (unsigned long long)c * 4;
+                const unsigned rh = drop_row(dc, (unsigned)row);  // element (row = token, column = feature)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = drop_keep(dc, e0 + k) ? y[k] * dc.scale : 0.0f;
+                for (int k = 0; k < 4; ++k) y[k] = drop_keep_rc(dc, rh, (unsigned)c * 4 + k) ? y[k] * dc.scale : 0.0f;
             }
             u32x2 w;
             w[0] = pack_bf16x2(y[0], y[1]);
@@ -369,17 +369,20 @@ extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const vo
                                       out_bf16, DropCfg{}, stream);
 }
 
-__global__ void dropout_mask_kernel(DropCfg dc, unsigned long long idx0, size_t n, uint8_t* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = drop_keep(dc, idx0 + i) ? 1 : 0;
+__global__ void dropout_mask_kernel(DropCfg dc, unsigned rows, unsigned cols, uint8_t* __restrict__ out) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned r = (unsigned)(i / cols), c = (unsigned)(i % cols);
+        out[i] = drop_keep_rc(dc, drop_row(dc, r), c) ? 1 : 0;
+    }
 }
 
-extern "C" int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned long long idx0, size_t n,
-                                uint8_t* out, bsi_stream_t stream) {
-    BSI_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f, "bsi_dropout_mask: bad args");
-    size_t g = (n + TPB - 1) / TPB;
+extern "C" int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned rows, unsigned cols, uint8_t* out,
+                                bsi_stream_t stream) {
+    BSI_CHECK_ARG(out && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "bsi_dropout_mask: bad args");
+    size_t g = ((size_t)rows * cols + TPB - 1) / TPB;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)g), dim3(TPB), 0, S(stream), make_drop(p, seed, site), idx0, n, out);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)g), dim3(TPB), 0, S(stream), make_drop(p, seed, site), rows, cols, out);
     BSI_CHECK_LAUNCH("bsi_dropout_mask");
     return BSI_OK;
 }

@@ -33,6 +33,7 @@ __global__ void film_silu_drop_kernel(const __bf16* __restrict__ h1, unsigned M,
         const unsigned c = (i - m * n8) * 8;
         const float* fr = film + (size_t)((m / (unsigned)HW) % (unsigned)film_rows) * film_stride;
         float v[8], sc[8], sh[8];
+        const unsigned rh = drop_row(dc, m);
         unpack8(*reinterpret_cast<const u32x4*>(h1 + (size_t)i * 8), v);
         *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(fr + c);
         *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(fr + c + 4);
@@ -41,7 +42,7 @@ __global__ void film_silu_drop_kernel(const __bf16* __restrict__ h1, unsigned M,
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float u = silu_f(__fmaf_rn(sc[e] + 1.0f, v[e], sh[e]));
-            if (dc.thr) u = drop_keep(dc, (unsigned long long)(i * 8u + e)) ? u * dc.scale : 0.0f;
+            if (dc.thr) u = drop_keep_rc(dc, rh, c + e) ? u * dc.scale : 0.0f;  // element (row = pixel, column = channel)
             v[e] = u;
         }
         u32x4 w;
@@ -73,12 +74,13 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(const __bf16* __rest
     for (int r = sub; r < FB_ROWS; r += rows_par) {
         const size_t m = m0 + r;
         float g[8], h[8];
+        const unsigned rh = drop_row(dc, (unsigned)m);
         unpack8(*reinterpret_cast<const u32x4*>(dy + m * N + c), g);
         unpack8(*reinterpret_cast<const u32x4*>(h1 + m * N + c), h);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float du = g[e] * silu_grad_f(__fmaf_rn(sc1[e], h[e], sh[e]));
-            if (dc.thr) du = drop_keep(dc, (unsigned long long)m * N + c + e) ? du * dc.scale : 0.0f;
+            if (dc.thr) du = drop_keep_rc(dc, rh, c + e) ? du * dc.scale : 0.0f;
             gs[e] = __fmaf_rn(du, h[e], gs[e]);
             gh[e] += du;
             g[e] = du * sc1[e];

@@ -338,7 +338,7 @@ int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float*
                            float* out1, float* out2, float* dgamma, float* dbeta, bsi_stream_t stream);
 /* Training form of the FiLM stage (residual_block.py:21-24,44-46): y = Dropout_p(SiLU(h1*(scale+1)+shift)), h1 and y bf16
  * [M, N], film fp32 rows (scale at [0,N), shift at [N,2N)) selected by (m / HW) % film_rows; the dropout mask is the
- * counter hash of (seed, site, m*N+n) (bsi_dropout_mask exports the same mask).  _bwd: dh1 = bf16(dU*(scale+1)) with
+ * counter hash of (seed, site, row m, column n) (bsi_dropout_mask exports the same mask).  _bwd: dh1 = bf16(dU*(scale+1)) with
  * dU = dy*mask/(1-p)*silu'(u); dfilm[b, n] += sum dU*h1, dfilm[b, N+n] += sum dU (atomics; N 64 or 128, HW % 64 == 0). */
 int bsi_film_silu(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride, float dropout_p,
                   unsigned long long seed, unsigned site, void* y, bsi_stream_t stream);
@@ -466,10 +466,11 @@ int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*
                      const bsi_dit_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
                      void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream);
 /* Dropout of the DiT blocks in training (dit.py:43-44 attention-weight dropout, dit.py:70,101 nn.Dropout before the
- * MLP) is a counter-based mask: element idx of site s is kept iff hash(seed, s, idx) >= p*2^32, re-evaluated in the
- * backward kernels (nothing stored).  Sites: 2*block (attention, idx = ((b*heads+h)*T + q)*T + key) and 2*block+1
- * (MLP input, idx = row*dim + col).  bsi_dropout_mask exposes the mask (uint8 keep flags) for tests. */
-int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned long long idx0, size_t n, uint8_t* out,
+ * MLP) is a counter-based mask: element (row, col) of site s is kept iff hash(seed, s, row, col) >= p*2^32, re-evaluated
+ * in the backward kernels (nothing stored).  Sites: 2*block (attention weights: row = (b*heads+h)*T + query, col = key) and
+ * 2*block+1 (MLP input: row = token, col = feature); UNet: site = residual block, row = pixel, col = channel.
+ * bsi_dropout_mask exposes the mask of a [rows, cols] site (uint8 keep flags) for tests. */
+int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned rows, unsigned cols, uint8_t* out /*[rows*cols]*/,
                      bsi_stream_t stream);
 /* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
  * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that

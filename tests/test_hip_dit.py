@@ -359,8 +359,8 @@ def test_training_dropout_matches_oracle_with_same_masks():
     for l in range(depth):
         ma = torch.empty(B * heads * T * T, dtype=torch.uint8, device=DEV)
         mm = torch.empty(B * T * d, dtype=torch.uint8, device=DEV)
-        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l, 0, ma.numel(), N.ptr(ma), N.stream()))
-        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l + 1, 0, mm.numel(), N.ptr(mm), N.stream()))
+        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l, B * heads * T, T, N.ptr(ma), N.stream()))
+        N.check(N.lib().bsi_dropout_mask(p, seed, 2 * l + 1, B * T, d, N.ptr(mm), N.stream()))
         drop[("attn", l)] = ma.cpu().float().reshape(B, heads, T, T) / (1 - p)
         drop[("mlp", l)] = mm.cpu().float().reshape(B, T, d) / (1 - p)
         assert abs(float(ma.float().mean()) - (1 - p)) < 0.01 and abs(float(mm.float().mean()) - (1 - p)) < 0.01
@@ -500,7 +500,7 @@ def test_unet_training_dropout_and_two_levels_vs_oracle():
     HW = shape[1] * shape[2]
     for blk, pre in enumerate(names):
         mk = torch.empty(B * HW * dim, dtype=torch.uint8, device=DEV)
-        N.check(N.lib().bsi_dropout_mask(p, seed, blk, 0, mk.numel(), N.ptr(mk), N.stream()))
+        N.check(N.lib().bsi_dropout_mask(p, seed, blk, B * HW, dim, N.ptr(mk), N.stream()))
         drop[pre] = mk.cpu().float().reshape(B, shape[1], shape[2], dim).permute(0, 3, 1, 2) / (1 - p)
         assert abs(float(mk.float().mean()) - (1 - p)) < 0.01
     Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}

@@ -621,7 +621,7 @@ def test_film_silu_dropout_forward_backward(N, B, HW, Nc, p):
     lib = N.lib()
     keep = torch.ones(M * Nc, dtype=torch.uint8, device=DEV)
     if p > 0:
-        N.check(lib.bsi_dropout_mask(p, seed, site, 0, M * Nc, N.ptr(keep), N.stream()))
+        N.check(lib.bsi_dropout_mask(p, seed, site, M, Nc, N.ptr(keep), N.stream()))
         frac = float(keep.float().mean())
         assert abs(frac - (1 - p)) < 0.01, frac
     mask = keep.cpu().double().reshape(M, Nc) / (1 - p)

@@ -130,6 +130,17 @@ _PROTOS = {
     "bsi_sqerr_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "bsi_sqerr_rows_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "bsi_recon_nll": (_i, [_vp, _vp, _f, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_tgrid": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "bsi_affine_noise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "bsi_axpbypcz": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp, _vp]),
+    "bsi_clip": (_i, [_vp, _f, _f, _sz, _vp, _vp]),
+    "bsi_clip_bwd": (_i, [_vp, _vp, _f, _f, _sz, _vp, _vp]),
+    "bsi_vdm_coeffs": (_i, [_vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_vdm_step_coeffs": (_i, [_vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_vdm_recon_nll": (_i, [_vp, _vp, _f, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_vdm_prior": (_i, [_vp, _f, _i, _i, _vp, _vp]),
+    "bsi_bfn_coeffs": (_i, [_vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_bfn_schedule": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp]),
     "bsi_to_uint8": (_i, [_vp, _f, _f, _sz, _vp, _vp]),
     "bsi_cast_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "bsi_nyquist_embed": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

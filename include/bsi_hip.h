@@ -117,6 +117,43 @@ int bsi_recon_nll(const float* x, const float* x_hat, float alpha_R, const float
 int bsi_to_uint8(const float* x, float lo, float hi, size_t n, uint8_t* out, bsi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The other two algorithm wrappers that share the denoisers with BSI — bsi/vdm.py (Variational Diffusion Models) and
+ * bsi/bfn.py (Bayesian Flow Networks); SURVEY §8(f) rank 4.  Row r of an [n_samples, batch] quantity is r = s*B + b.
+ * ---------------------------------------------------------------------------------------- */
+/* vdm.py:385-397 / bfn.py:313-325: t = (perm/(1+total) + offset) mod 1 (low-discrepancy time grid). */
+int bsi_tgrid(const int64_t* perm, const float* offset, int total, float* t, bsi_stream_t stream);
+/* vdm.py:343-347, bfn.py:302-309: out[r] = addcmul(a[r]*x[r % B], b[r], eps[r]). */
+int bsi_affine_noise(const float* x, const float* a, const float* b, const float* eps, int rows, int B, int D, float* out,
+                     bsi_stream_t stream);
+/* vdm.py:365-379: out = a[idx]*z + b[idx]*xh + c[idx]*eps over n floats (one ancestral sampling step). */
+int bsi_axpbypcz(const float* z, const float* xh, const float* eps, const float* a, const float* b, const float* c, int idx, size_t n,
+                 float* out, bsi_stream_t stream);
+/* bfn.py:291 (.clip) and its backward (gradient passes where lo <= raw <= hi). */
+int bsi_clip(const float* x, float lo, float hi, size_t n, float* out, bsi_stream_t stream);
+int bsi_clip_bwd(const float* g, const float* raw, float lo, float hi, size_t n, float* out, bsi_stream_t stream);
+/* vdm.py:138-150,324-329: gamma = lerp(gamma_0, gamma_1, t); alpha = sqrt(sigmoid(-gamma)), sigma = sqrt(sigmoid(gamma)),
+ * snr = exp(-gamma), c_skip = 1/alpha, c_out = -sigma/alpha (x_hat = (z - sigma f)/alpha).  Outputs nullable. */
+int bsi_vdm_coeffs(const float* t, int n, float gamma_0, float gamma_1, float* alpha, float* sigma, float* snr, float* c_skip,
+                   float* c_out, bsi_stream_t stream);
+/* vdm.py:350-379 over a schedule t[0..k]: z_s = c_z[i] z_t + c_x[i] x_hat + std[i] eps for the step t[i] -> t[i+1];
+ * dsnr[i] = snr(t[i+1]) - snr(t[i]) (vdm.py:231, nullable). */
+int bsi_vdm_step_coeffs(const float* t, int k, float gamma_0, float gamma_1, float* c_z, float* c_x, float* std_, float* dsnr,
+                        bsi_stream_t stream);
+/* vdm.py:167-195: Normal(x_hat, std) evaluated at the k bin centres, normalised over bins; out[r] = -sum_D log p[bin(x)]. */
+int bsi_vdm_recon_nll(const float* x, const float* x_hat, float std_, const float* bounds, float lo_edge, float dx, int k, int rows,
+                      int B, int D, float* out, bsi_stream_t stream);
+/* vdm.py:127-136: out[r] = 0.5 * sum_D (var_1 + (1 - var_1) x^2 - log var_1 - 1). */
+int bsi_vdm_prior(const float* x, float var_1, int rows, int D, float* out, bsi_stream_t stream);
+/* bfn.py:282-309,197-198 per time t[i] (gamma = 1 - sigma_1^(2t)): fa = gamma, fb = sqrt(gamma(1-gamma)) (flow distribution);
+ * c_skip = 1/g, c_out = -sqrt((1-g)/g) with g at max(t, t_min), both 0 where t < t_min (x_hat before the clip);
+ * w = sigma_1^(-2t).  Outputs nullable. */
+int bsi_bfn_coeffs(const float* t, int n, float sigma_1, float t_min, float* fa, float* fb, float* c_skip, float* c_out, float* w,
+                   bsi_stream_t stream);
+/* bfn.py:215-226: alpha[i] = sigma_1^(-2 t[i+1]) (1 - sigma_1^(2 (t[i+1]-t[i]))), rho[0] = 1, rho[i+1] = rho[i] + alpha[i]
+ * (rho, alpha feed bsi_refine_step as lam, alpha); wdisc[i] = sigma_1^((-2/k)(i+1)) (bfn.py:176-181, nullable). */
+int bsi_bfn_schedule(const float* t, int k, float sigma_1, float* alpha, float* rho, float* wdisc, bsi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Building blocks of the denoisers — bsi/models/dit.py, bsi/models/pos_emb.py, bsi/nn
  * ---------------------------------------------------------------------------------------- */
 

@@ -72,7 +72,7 @@ float time_w1(GemmParams p, int iters) {
 }
 
 int main() {
-    const int M = 65536;
+    const int M = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 65536;
     struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 3072, 1024}, {"fc2", 1024, 4096}};
     for (auto sh : shapes) {
         size_t na = (size_t)M * sh.K, nw = (size_t)sh.N * sh.K, no = (size_t)M * sh.N;

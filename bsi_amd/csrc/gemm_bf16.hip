@@ -893,6 +893,143 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p)
 }
 
 
+// Epilogue of one wave's 128 x 64 accumulator block (shared by the K = 32 ring kernel and the K = 64 kernel): bias /
+// activation, bf16 outputs transposed through the wave's 4 KB LDS scratch so that every store instruction writes whole
+// 128-B lines, non-temporal stores.
+// SCRATCH = false: no LDS at all.  Lanes rho and rho^1 (rows m and m+1 of the same 16-column group) swap one half of their
+// 16 columns with a DPP quad permute, after which every lane holds 8 columns of ONE row per store and the 8 lanes of a row
+// pair write a complete 128-B line per store instruction (even rows, then odd rows).
+template <int EPI, int ABL, bool SCRATCH = true>
+__device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane, char* scratch) {
+    constexpr int TM = 8;
+    constexpr bool BF16_OUT = EpiTraits<EPI>::out_bf16;
+    const int rho = lane & 15, qd = lane >> 4;
+
+
+        if constexpr (ABL & 4) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+        } else if constexpr (BF16_OUT) {
+            const int nb = nw0 + 16 * qd;
+            const bool nb_ok = nb < p.N;
+            float bias[16];
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+            }
+            const int rr = lane >> 3, ch = lane & 7;
+            const bool cols_ok = nw0 + 8 * ch < p.N;
+#pragma unroll
+            for (int rnd = 0; rnd < TM / 2; ++rnd) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * rnd + jj;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+                    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+                        const int m = mw0 + 16 * j + rho;
+                        if (m < p.M && nb_ok) {
+                            const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
+                            const u32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax));
+                            const u32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + 8));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
+                                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
+                                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
+                                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
+                            }
+                        }
+                    }
+                    if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // pre-activation: direct 32-B stores (training only)
+                        const int m = mw0 + 16 * j + rho;
+                        if (m < p.M && nb_ok) {
+                            u32x4 a0, a1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                                a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                            }
+                            __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
+                            __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
+                            __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
+                        }
+                    }
+                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
+                    }
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                        w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                    }
+                    if constexpr (!SCRATCH) {
+                        const bool odd = lane & 1;
+                        u32x4 st_even, st_odd;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned send = odd ? w0[e] : w1[e];
+                            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+                            st_even[e] = odd ? recv : w0[e];
+                            st_odd[e] = odd ? w1[e] : recv;
+                        }
+                        const int m_even = mw0 + 16 * j + (rho & ~1);
+                        const int col = nb + (odd ? 8 : 0);
+                        if (nb_ok) {
+                            __bf16* ob = reinterpret_cast<__bf16*>(p.out) + col;
+                            if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
+                            if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
+                        }
+                        continue;
+                    }
+                    const int r = 16 * jj + rho;  // row within this round's 32-row image
+                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
+                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
+                }
+                if constexpr (!SCRATCH) continue;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u32x4 d[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int r = 8 * t4 + rr;
+                    d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int m = mw0 + 32 * rnd + 8 * t4 + rr;
+                    if (m < p.M && cols_ok) {
+                        const int m_dst = (ABL & 256) ? (m & 255) : m;  // laboratory: all tiles write the same 256 rows
+                        if ((ABL & 512) && rnd != 0) continue;           // laboratory: a quarter of the stores
+                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m_dst * p.ldo + nw0 + 8 * ch);
+                        // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
+                        // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
+                        if constexpr (ABL & 32) *dst = d[t4];
+                        else if constexpr (ABL & 128) {  // laboratory: everything but the global stores
+                            if (d[t4][0] == 0x12345678u && d[t4][3] == 0x9abcdef0u) *dst = d[t4];
+                        } else __builtin_nontemporal_store(d[t4], dst);
+                    }
+                }
+            }
+        } else {
+            gemm_epilogue<TM, EPI>(p, acc, mw0, nw0, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fp32 read-modify-write paths: simple drain
+        }
+    }
+
 // ---------------------------------------------------------------------------------------------------------
 // Variant 6: PERSISTENT deep-ring ping-pong (the production schedule).
 //   * one workgroup per CU walks its tiles; tile 256 x 256, K step 32, ring of R = 4 slots of 32 KB + 32 KB
@@ -907,8 +1044,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p)
 //     per tile instead of prologue + two epilogues + store drain;
 //   * bf16 outputs leave through the LDS scratch in 4 rounds of 32 rows so that every store instruction writes
 //     whole 128-B lines.
-template <int EPI, int ABL = 0, bool ROLL = false, int RING = 4>
+template <int EPI, int ABL = 0, bool ROLL = false, int RING = 4, bool CDMA = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p) {
+    // CDMA: the four DMA instructions of a stage are issued INSIDE the MFMA phase, one behind every second group of four
+    // MFMAs (the matrix pipe keeps executing queued MFMAs while the wave's DMA issue stalls), instead of in the load phase,
+    // whose length then is just the twelve fragment reads.
     // ROLL: the activation fragments of step v+1 are fetched DURING the MFMA phase of step v (fragment register j is
     // re-loaded right after the four MFMAs that consume it), so the load phase shrinks to the weight fragments + the DMA
     // issue and stops being longer than the partner group's MFMA phase.
@@ -992,109 +1132,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     auto epilogue = [&](int t) {
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
-        const int mw0 = tm_ * BM + wm * TM * 16, nw0 = tn_ * BN + wn * 64;
-        if constexpr (ABL & 4) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-        } else if constexpr (BF16_OUT) {
-            const int nb = nw0 + 16 * qd;
-            const bool nb_ok = nb < p.N;
-            float bias[16];
-#pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-                bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
-            }
-            const int rr = lane >> 3, ch = lane & 7;
-            const bool cols_ok = nw0 + 8 * ch < p.N;
-#pragma unroll
-            for (int rnd = 0; rnd < TM / 2; ++rnd) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = 2 * rnd + jj;
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
-                    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
-                        const int m = mw0 + 16 * j + rho;
-                        if (m < p.M && nb_ok) {
-                            const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
-                            const u32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax));
-                            const u32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + 8));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
-                                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
-                                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
-                                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
-                            }
-                        }
-                    }
-                    if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // pre-activation: direct 32-B stores (training only)
-                        const int m = mw0 + 16 * j + rho;
-                        if (m < p.M && nb_ok) {
-                            u32x4 a0, a1;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                                a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-                            }
-                            __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
-                            __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
-                            __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
-                        }
-                    }
-                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
-                    } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
-                    }
-                    u32x4 w0, w1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                        w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-                    }
-                    const int r = 16 * jj + rho;  // row within this round's 32-row image
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4 d[4];
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int r = 8 * t4 + rr;
-                    d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int m = mw0 + 32 * rnd + 8 * t4 + rr;
-                    if (m < p.M && cols_ok) {
-                        const int m_dst = (ABL & 256) ? (m & 255) : m;  // laboratory: all tiles write the same 256 rows
-                        if ((ABL & 512) && rnd != 0) continue;           // laboratory: a quarter of the stores
-                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m_dst * p.ldo + nw0 + 8 * ch);
-                        // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
-                        // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
-                        if constexpr (ABL & 32) *dst = d[t4];
-                        else if constexpr (ABL & 128) {  // laboratory: everything but the global stores
-                            if (d[t4][0] == 0x12345678u && d[t4][3] == 0x9abcdef0u) *dst = d[t4];
-                        } else __builtin_nontemporal_store(d[t4], dst);
-                    }
-                }
-            }
-        } else {
-            gemm_epilogue<TM, EPI>(p, acc, mw0, nw0, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fp32 read-modify-write paths: simple drain
-        }
+        wave_tile_epilogue<EPI, ABL>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
     };
 
     const int nk = p.K / 32;  // launcher guarantees nk >= D
@@ -1110,6 +1148,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     }
 
     int slot = 0, pslot = D;
+    bool issued_prev = true;  // CDMA: the prologue issued stages 0 .. D-1
     int after_e = 0;  // L phases since the last epilogue whose stores may still be in flight
     while (true) {
         const int next = tile + wpx;
@@ -1137,19 +1176,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                 }
             }
             bool issued = false;
+            int kissue = -1;  // CDMA: K step (of this or the next tile) whose stage is issued during C(v)
             if constexpr (!(ABL & 1)) {
                 if (v + D < nk) {
-                    stage(v + D, pslot);
+                    if constexpr (CDMA) kissue = v + D;
+                    else stage(v + D, pslot);
                     issued = true;
                 } else if (has_next) {
                     if (v + D == nk) set_sources(next);
-                    stage(v + D - nk, pslot);
+                    if constexpr (CDMA) kissue = v + D - nk;
+                    else stage(v + D - nk, pslot);
                     issued = true;
                 }
             }
             // the stage of step v+1 must have landed; younger stages (and, right after an epilogue, its 16
             // stores) may stay in flight
-            if (issued) {
+            if constexpr (CDMA) {
+                // outstanding here: stages v+1 .. v+D-1 (stage v+D follows in C(v)); `issued_prev` = stage v+D-1 exists
+                if (issued_prev) {
+                    if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2) + 16) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                issued_prev = issued;
+            } else if (issued) {
                 if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1) + 16) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
@@ -1169,6 +1221,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                     for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                     xf[j] = *reinterpret_cast<const bf16x8*>(bnx + xoff + j * 16 * RB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (CDMA) {
+                char* pbase = lds + pslot * SLOT_BYTES + wave * 1024;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    if ((j & 1) && kissue >= 0) {
+                        const int q = j >> 1;
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kissue * KSB), LDS_PTR(pbase + q * NW * 1024), 16, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -1202,6 +1267,327 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
 
 extern int g_gm;
 int num_cus();
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 10: the persistent ping-pong schedule of variant 6 on K = 64 STAGES (128-B tile rows).
+// Why: the L2 -> LDS DMA moves whole 128-B cache lines; with 64-B rows (K step 32) every line is fetched in two halves by
+// two different stages and the fill rate is 37 B/clk/CU instead of 60 (tools/experiments/gemm_lab.hip, LAB_DMA), which at
+// 32 B/clk/CU of demand made the fill stream the bottleneck of variant 6.
+//   * two 64 KB stage buffers (A rows 0..255, W rows 256..511, 128 B each) + 32 KB epilogue scratch = 160 KB;
+//   * a stage is consumed in two k halves, each with its own load (L) and MFMA (C) phase as in variant 6;
+//   * the whole stage v+1 (8 DMA instructions per wave) is issued in L(v, 0), right after the other buffer's last readers
+//     passed; it must have landed at the barrier that ends C(v, 1): two k halves (~2200 clocks) of latency cover, the same as
+//     a 3-slot K = 32 ring, which costs nothing (a 2-slot ring loses 35 %);
+//   * the DMA stream continues across tile boundaries (the stage issued in the last L(., 0) belongs to the next tile).
+// LDS chunk swizzles for 128-B rows: activation rows by (row >> 1) & 7, weight rows by ((row >> 1) & 1) | (((row >> 4) & 3) << 1).
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_k64_kernel(const GemmParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr int BM = 256, BN = 256, RB = 128;
+    constexpr int STAGE = (BM + BN) * RB, A_BYTES = BM * RB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    char* scratch = lds + 2 * STAGE + wave * 4096;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;
+
+    // staging: a wave-instruction covers 8 rows x 128 B; wave w issues slots q*8 + w, q < 8 (slots 0..31 A rows, 32..63 W rows)
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned goff[8];  // byte offsets of this lane's source chunk from p.A (q < 4) / p.W (q >= 4)
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    auto set_sources = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int slot = q * NW + wave;
+            if (q < 4) {
+                const int r = slot * 8 + srow;
+                const int c = spos ^ ((r >> 1) & 7);
+                int m = tm_ * BM + r;
+                m = m < p.M ? m : p.M - 1;
+                goff[q] = (unsigned)m * (unsigned)(p.lda * 2) + c * 16;
+            } else {
+                const int r = (slot - 32) * 8 + srow;
+                const int c = spos ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1));
+                int n = tn_ * BN + r;
+                n = n < p.N ? n : p.N - 1;
+                goff[q] = (unsigned)n * (unsigned)(p.ldw * 2) + c * 16;
+            }
+        }
+    };
+    auto stage = [&](int kstage, int buf) {
+        char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const char* src = (q < 4 ? Ab : Wb) + (size_t)kstage * 128 + goff[q];
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (q * NW + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int xkey = (rho >> 1) & 7, wkey = ((rho >> 1) & 1) | ((rho >> 2) << 1);
+    const int xrow = (wm * TM * 16 + rho) * RB;
+    const int wrow = A_BYTES + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB;
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    auto epilogue = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+        wave_tile_epilogue<EPI, ABL>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
+    };
+
+    const int nk = p.K / 64;  // launcher: K % 64 == 0, nk >= 1
+    set_sources(tile);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int buf = 0;
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < nk; ++v) {
+            const char* b = lds + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // ---- L(v, ks)
+                {
+                    const int cx = ((ks * 4 + qd) ^ xkey) << 4, cw = ((ks * 4 + qd) ^ wkey) << 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + wrow + i * 4 * RB + cw);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xrow + j * 16 * RB + cx);
+                }
+                if (ks == 0) {
+                    if constexpr (!(ABL & 1)) {
+                        if (v + 1 < nk) {
+                            stage(v + 1, buf ^ 1);
+                        } else if (has_next) {
+                            set_sources(next);
+                            stage(0, buf ^ 1);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                // ---- C(v, ks)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (ks == 1) {
+                    // stage v+1 (issued two k halves ago) must have landed before the barrier that lets anyone read it
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
+                }
+                PHASE_BARRIER();
+            }
+            buf ^= 1;
+        }
+        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
+        if (!has_next) break;
+        tile = next;
+    }
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 12: 128-B tile rows (whole cache lines per DMA row, see variant 10) on a RING OF FIVE HALF-STAGES.
+// A half-stage is the A half (256 rows) or the W half (256 rows) of a K = 64 stage: 32 KB; five slots = all 160 KB of LDS
+// (the epilogue needs no scratch: wave_tile_epilogue<.., false>).  One half-stage (4 DMA instructions per wave) is issued
+// per load phase, exactly the DMA instruction count of variant 6 but with twice the bytes per LDS-DMA cycle.  With H(A of
+// global stage G) = 2G, H(W of G) = 2G+1 and slot = H % 5, load phase P = 2G + ks issues H = P + 3: W(G+1) at ks = 0,
+// A(G+2) at ks = 1; everything needed at P+1 has then been in flight for at least two phases (the cover that a 3-slot
+// K = 32 ring has and that costs nothing).  The issue stream runs ahead of the compute across tile boundaries with its
+// own tile pointer.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr int BM = 256, BN = 256, RB = 128;
+    constexpr int HALF = 256 * RB;  // 32 KB
+    constexpr bool BF16_OUT = EpiTraits<EPI>::out_bf16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;
+    const int nk = p.K / 64;
+
+    // ---- issue stream: half-stages in the order A(0) W(0) A(1) W(1) ... over this workgroup's tiles
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned gA[4], gW[4];  // source byte offsets of this lane's chunk for the 4 instructions of a half-stage
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    int itile = tile, iv = 0, ihalf = 0, islot = 0;  // next half-stage to issue and its slot
+    auto set_sources = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (q * NW + wave) * 8 + srow;
+            int m = tm_ * BM + r;
+            m = m < p.M ? m : p.M - 1;
+            int n = tn_ * BN + r;
+            n = n < p.N ? n : p.N - 1;
+            gA[q] = (unsigned)m * (unsigned)(p.lda * 2) + ((spos ^ ((r >> 1) & 7)) << 4);
+            gW[q] = (unsigned)n * (unsigned)(p.ldw * 2) + ((spos ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1))) << 4);
+        }
+    };
+    auto issue_next = [&]() -> bool {  // issues one half-stage; false when the stream is exhausted
+        if (itile >= hi) return false;
+        char* base = lds + islot * HALF + wave * 1024;
+        const size_t koff = (size_t)iv * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* src = ihalf ? Wb + koff + gW[q] : Ab + koff + gA[q];
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
+        }
+        islot = islot == 4 ? 0 : islot + 1;
+        if (ihalf) {
+            ihalf = 0;
+            if (++iv == nk) {
+                iv = 0;
+                itile += wpx;
+                if (itile < hi) set_sources(itile);
+            }
+        } else {
+            ihalf = 1;
+        }
+        return true;
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int xkey = (rho >> 1) & 7, wkey = ((rho >> 1) & 1) | ((rho >> 2) << 1);
+    const int xrow = (wm * TM * 16 + rho) * RB;
+    const int wrow = (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB;
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    auto epilogue = [&](int t) {
+        int tm_, tn_;
+        tile_coords(p, t, tm_, tn_);
+        wave_tile_epilogue<EPI, ABL, false>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
+    };
+
+    // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase
+    set_sources(tile);
+    issue_next();
+    issue_next();
+    bool more = issue_next();
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int sa = 0, sw = 1;  // slots of the A and W halves of the stage being consumed
+    int after_e = 0;
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < nk; ++v) {
+            const char* ba = lds + sa * HALF;
+            const char* bw = lds + sw * HALF;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // ---- L(v, ks)
+                {
+                    const int cx = ((ks * 4 + qd) ^ xkey) << 4, cw = ((ks * 4 + qd) ^ wkey) << 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(bw + wrow + i * 4 * RB + cw);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(ba + xrow + j * 16 * RB + cx);
+                }
+                bool issued = false;
+                if constexpr (!(ABL & 1)) issued = issue_next();
+                // ks = 0 issued W(G+1): A(G+1) (issued one phase ago) may also stay in flight -> 8; ks = 1 issued A(G+2): the
+                // whole stage G+1 must have landed -> 4 (only the new one in flight).  In the first phase after an epilogue its
+                // 16 stores sit between A(G+1) and W(G+1) in issue order and may stay in flight too; one phase later W(G+1),
+                // which is younger than the stores, must have landed, so the stores must have drained as well.
+                if (issued) {
+                    if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0 && ks == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                    else if (ks == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (after_e > 0) --after_e;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                // ---- C(v, ks)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (ks == 1 && v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
+                PHASE_BARRIER();
+            }
+            sa = sa >= 3 ? sa - 3 : sa + 2;
+            sw = sw >= 3 ? sw - 3 : sw + 2;
+        }
+        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
+        after_e = 2;
+        if (!has_next) break;
+        tile = next;
+    }
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
+}
+
+template <int EPI>
+int launch_k64(const GemmParams& p0, hipStream_t s);
+
 
 // ---------------------------------------------------------------------------------------------------------
 // Variant 8: ONE WAVE PER SIMD.  4 waves, each owns a 128 x 128 quadrant of the 256 x 256 tile (64 accumulator tiles =
@@ -1434,7 +1820,7 @@ int launch_cfg(const GemmParams& p0, hipStream_t s) {
     return BSI_OK;
 }
 
-int g_variant = 6;  // 0: two-barrier double buffer, 1: ping-pong wave groups, 2: two workgroups per CU,
+int g_variant = 12;  // 0: two-barrier double buffer, 1: ping-pong wave groups, 2: two workgroups per CU,
                     // 3: persistent ping-pong (default)
 int g_stagger = 0;
 int g_gm = 4;  // band height: 4 m-tiles x 8 n-tiles per XCD round minimises L2 misses (PMC: fc1 605 -> 403 MB per launch)
@@ -1470,7 +1856,49 @@ int launch_ring(const GemmParams& p0, hipStream_t s) {
 
 int num_cus();
 
-template <int EPI, bool ROLL = false>
+template <int EPI>
+int launch_k64(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const size_t lds = 2 * (size_t)512 * 128 + 32768;
+    auto kern = gemm_bf16_k64_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+template <int EPI>
+int launch_k64r(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const size_t lds = 5 * (size_t)256 * 128;
+    auto kern = gemm_bf16_k64r_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+    return BSI_OK;
+}
+
+template <int EPI, bool ROLL = false, bool CDMA = false>
 int launch_pring(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + 255) / 256;
@@ -1481,7 +1909,7 @@ int launch_pring(const GemmParams& p0, hipStream_t s) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
-    auto kern = gemm_bf16_pring_kernel<EPI, 0, ROLL>;
+    auto kern = gemm_bf16_pring_kernel<EPI, 0, ROLL, 4, CDMA>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1556,8 +1984,11 @@ int launch_pp(const GemmParams& p0, hipStream_t s) {
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t s) {
     if (g_variant == 8 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 256 && p.K % 128 == 0) return launch_w1<EPI>(p, s);
+    if (g_variant == 12 && EpiTraits<EPI>::out_bf16 && p.M > 128 && p.K >= 128 && p.K % 64 == 0) return launch_k64r<EPI>(p, s);
+    if (g_variant == 11 && p.M > 128 && p.K >= 96) return launch_pring<EPI, false, true>(p, s);
+    if (g_variant == 10 && p.M > 128 && p.K >= 64 && p.K % 64 == 0) return launch_k64<EPI>(p, s);
     if (g_variant == 9 && p.M > 128 && p.K >= 96) return launch_pring<EPI, true>(p, s);
-    if ((g_variant == 6 || g_variant == 8) && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
+    if ((g_variant == 6 || g_variant == 8 || g_variant == 10 || g_variant == 12) && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
     if (g_variant == 4 && p.M > 128) return launch_ring<EPI, 5>(p, s);
     if (g_variant == 5 && p.M > 128) return launch_ring<EPI, 4>(p, s);
     if (g_variant == 3 && p.M > 128) return launch_ppp<EPI>(p, s);
@@ -1573,7 +2004,7 @@ int launch_epi(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int bsi_gemm_set_variant(int v) {
-    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 9, "bsi_gemm_set_variant: unknown variant %d", v);
+    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 12, "bsi_gemm_set_variant: unknown variant %d", v);
     g_variant = v & 0xff;
     g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger of variant 3, in units of 64 clocks per step
     g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of variant 6

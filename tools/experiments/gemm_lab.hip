@@ -71,7 +71,54 @@ float time_w1(GemmParams p, int iters) {
     return ms / iters;
 }
 
+// L2 -> LDS fill-rate microbenchmark: 8 waves per CU issue nothing but global_load_lds_dwordx4 over an L2-resident region.
+// seg = bytes each group of lanes reads contiguously (64: lanes 0..3 form a row segment as in the K=32 GEMM stage,
+// 128: lanes 0..7 as in a K=64 stage, 1024: the whole wave reads 1 KB contiguously).
+__global__ __launch_bounds__(512) void dma_bw_kernel(const char* src, unsigned region, int iters, int seg, int ld) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lps = seg / 16;                       // lanes per contiguous segment
+    const unsigned lane_off = (unsigned)(lane / lps) * ld + (lane % lps) * 16;
+    unsigned base = (blockIdx.x * 8 + wave) * 4096u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned off = (base + q * 1024u * 37u + lane_off) % region;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src + (off & ~15u)), LDS_PTR(lds + ((it & 3) * 32 + q * 8 + wave) * 1024), 16, 0, 0);
+        }
+        base += 8 * 4096u * 61u;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static void dma_bench() {
+    const unsigned region = 2u << 20;  // 2 MB: resident in every XCD's L2
+    char* d;
+    hipMalloc(&d, region + (1 << 20));
+    hipMemset(d, 1, region + (1 << 20));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dma_bw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const int iters = 4000;
+    for (int seg : {64, 128, 256, 1024}) {
+        const int ld = seg == 1024 ? 1024 : 2048;  // row pitch of the source matrix
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, 100, seg, ld);
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, iters, seg, ld);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        const double bytes = 256.0 * 8 * 4 * 1024.0 * iters;
+        printf("LDS-DMA fill, %4d-B segments: %7.2f TB/s aggregate = %6.1f GB/s per CU (%.1f B/clk at 2.1 GHz)\n", seg, bytes / ms / 1e9,
+               bytes / ms / 1e6 / 256, bytes / ms / 1e6 / 256 / 2.1);
+    }
+    hipFree(d);
+}
+
 int main() {
+    if (getenv("LAB_DMA")) { dma_bench(); return 0; }
     const int M = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 65536;
     struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 3072, 1024}, {"fc2", 1024, 4096}};
     for (auto sh : shapes) {
@@ -128,6 +175,7 @@ int main() {
             rep("v6 no epilogue", time_pring<E, 4>(p, 20));
             rep("v6 no epi, ring 5", time_pring<E, 4, 5>(p, 20));
             rep("v6 no epi, ring 3", time_pring<E, 4, 3>(p, 20));
+            rep("v6 no epi, ring 2", time_pring<E, 4, 2>(p, 20));
             rep("v6 no epi, no glds", time_pring<E, 5>(p, 20));
             rep("v6 no epi, no frag reads", time_pring<E, 6>(p, 20));
             rep("v6 no epi, no glds, no frag reads", time_pring<E, 7>(p, 20));

@@ -899,7 +899,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p)
 // SCRATCH = false: no LDS at all.  Lanes rho and rho^1 (rows m and m+1 of the same 16-column group) swap one half of their
 // 16 columns with a DPP quad permute, after which every lane holds 8 columns of ONE row per store and the 8 lanes of a row
 // pair write a complete 128-B line per store instruction (even rows, then odd rows).
-template <int EPI, int ABL, bool SCRATCH = true>
+// BIAS_IN_ACC: the accumulators were initialised with the bias (free: a register move instead of a zero), no add here.
+template <int EPI, int ABL, bool SCRATCH = true, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane, char* scratch) {
     constexpr int TM = 8;
     constexpr bool BF16_OUT = EpiTraits<EPI>::out_bf16;
@@ -919,7 +920,7 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
             float bias[16];
 #pragma unroll
             for (int e = 0; e < 16; e += 4) {
-                f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 bv = (!BIAS_IN_ACC && p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
                 bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
             }
             const int rr = lane >> 3, ch = lane & 7;
@@ -933,7 +934,7 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+                        for (int r = 0; r < 4; ++r) v[4 * i + r] = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bias[4 * i + r];
                     if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
                         const int m = mw0 + 16 * j + rho;
                         if (m < p.M && nb_ok) {
@@ -1511,7 +1512,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     auto epilogue = [&](int t) {
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
-        wave_tile_epilogue<EPI, ABL, false>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
+        wave_tile_epilogue<EPI, ABL, false, BF16_OUT>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
+    };
+    auto init_acc = [&](int t) {  // bf16 epilogues: accumulators start at the bias of their column (lane owns n = nb .. nb+15)
+        f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (BF16_OUT) {
+            int tm_, tn_;
+            tile_coords(p, t, tm_, tn_);
+            const int nb = tn_ * BN + wn * 64 + 16 * qd;
+            if (p.bias && nb < p.N) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
     };
 
     // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase
@@ -1529,10 +1546,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     while (true) {
         const int next = tile + wpx;
         const bool has_next = next < hi;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        init_acc(tile);
         for (int v = 0; v < nk; ++v) {
             const char* ba = lds + sa * HALF;
             const char* bw = lds + sw * HALF;

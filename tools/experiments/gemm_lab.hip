@@ -117,6 +117,26 @@ static void dma_bench() {
     hipFree(d);
 }
 
+template <int EPI, int ABL>
+float time_k64r(GemmParams p, int iters) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = 4;
+    const size_t lds = 5 * 256 * 128;
+    auto kern = gemm_bf16_k64r_kernel<EPI, ABL>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, p);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, p);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
 int main() {
     if (getenv("LAB_DMA")) { dma_bench(); return 0; }
     const int M = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 65536;
@@ -163,6 +183,17 @@ int main() {
                            fl / ms / 1e9, 100.0 * hc[0] / hc[1]);
                 }
             }
+            continue;
+        }
+        if (getenv("LAB_V12")) {
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            rep("v6 full (wb stores)", time_pring<E, 32>(p, 20));
+            rep("v6 no epilogue", time_pring<E, 4>(p, 20));
+            rep("v6 no epi, no glds", time_pring<E, 5>(p, 20));
+            rep("v12 full", time_k64r<E, 0>(p, 20));
+            rep("v12 gelu full", time_k64r<G, 0>(p, 20));
+            rep("v12 no epilogue", time_k64r<E, 4>(p, 20));
+            rep("v12 no epi, no glds", time_k64r<E, 5>(p, 20));
             continue;
         }
         if (getenv("LAB_W1")) {

@@ -4,13 +4,13 @@
 //
 // Activations are NHWC bf16 ([B*H*W pixels][C channels]); weights are pre-arranged [C_out][tap][C_in] so that the GEMM
 // K index is (tap, channel).  No im2col buffer exists: the A tile of K step v (32 channels of one filter tap) is
-// fetched by global_load_lds straight from the input pixel (y+dy, x+dx) of each output pixel; taps that fall outside the
-// image read a zero page instead.  An optional second source adds 1x1 "skip" K steps (the 1x1 conv on the residual path
+// fetched by LDS-DMA (buffer_load ... lds) straight from the input pixel (y+dy, x+dx) of each output pixel; lanes whose
+// tap falls outside the image use an out-of-range buffer offset, for which the DMA writes zeros.  An optional second source adds 1x1 "skip" K steps (the 1x1 conv on the residual path
 // of the up blocks, residual_block.py:40,63, folded into the second 3x3 conv's accumulation).
 //
 // Schedule = the persistent deep-ring ping-pong of gemm_bf16.hip variant 6 with tile 512 (pixels) x 128 (C_out):
 // C_out is 128 everywhere in the UNet, so the tile is made tall instead of wide; waves keep the 128 x 64 sub-tile.
-// LDS: 3 stages of (512 + 128) rows x 64 B = 120 KB + 32 KB epilogue scratch.
+// LDS: a ring of 4 stages of (512 + 128) rows x 64 B = 160 KB; the epilogue needs no scratch (DPP row-pair exchange).
 #include "common.h"
 
 namespace {
@@ -20,7 +20,6 @@ struct ConvParams {
     const __bf16* A2;     // optional second source [B*H*W, Cin2] for the 1x1 skip K steps
     const __bf16* W;      // [N][taps*Cin + Cin2]
     const float* bias;    // [N]
-    const __bf16* zeros;  // >= 64 B of zeros
     void* out;            // bf16 or fp32 [M, ldo]
     const float* film;    // FILM: [rows][2N] = (scale, shift) per image row
     const float* resid;   // BIAS_RESID_F32: fp32 [M, ldo] or null
@@ -30,16 +29,67 @@ struct ConvParams {
     int tiles_m, tiles_n;
 };
 
-constexpr int C_BM = 512, C_BN = 128, C_RB = 64, C_R = 3, C_D = C_R - 1;
+constexpr int C_BM = 512, C_BN = 128, C_RB = 64, C_R = 4, C_D = C_R - 1;
 constexpr int C_SLOT = (C_BM + C_BN) * C_RB;  // 40 KB
 constexpr int C_ABYTES = C_BM * C_RB;
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // buffer offset beyond num_records: the LDS-DMA writes zeros for that lane
+constexpr unsigned BUF_RECORDS = 0x80000000u;  // every valid offset is below 2 GB (checked by the launcher)
 
 enum { CEPI_BIAS_BF16 = 0, CEPI_FILM_SILU_BF16 = 1, CEPI_BIAS_RESID_F32 = 2 };
+
+// Padding code of a pixel: which of the four image borders it touches.  A tap (dy, dx) reads outside the image exactly
+// when (code & tap_mask(dy, dx)) != 0.
+__device__ __forceinline__ int border_code(int y, int x, int H, int W) {
+    return (y == 0 ? 1 : 0) | (y == H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == W - 1 ? 8 : 0);
+}
+__device__ __forceinline__ int tap_mask(int dy, int dx) { return (dy < 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dx < 0 ? 4 : 0) | (dx > 0 ? 8 : 0); }
+
+// Store a wave's 16-row x 64-column bf16 block whose lane (rho, qd) holds row rho, columns 16 qd .. 16 qd + 15 as (w0 = first
+// 8 columns, w1 = last 8): lanes rho and rho^1 swap one half (DPP quad permute), after which the 8 lanes of a row pair write
+// one complete 128-B line per store instruction (even rows, then odd rows).  No LDS.
+__device__ __forceinline__ void store_rows_dpp(__bf16* out, int ldo, int M, int m0, int nb, int rho, u32x4 w0, u32x4 w1) {
+    const bool odd = rho & 1;
+    u32x4 recv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned send = odd ? w0[e] : w1[e];
+        recv[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);
+    }
+    const u32x4 st_even = odd ? recv : w0, st_odd = odd ? w1 : recv;
+    const int m_even = m0 + (rho & ~1);
+    __bf16* dst = out + (size_t)m_even * ldo + nb + (odd ? 8 : 0);
+    if (m_even < M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(dst));
+    if (m_even + 1 < M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(dst + ldo));
+}
+
+// 4 x 4 transpose of r[0..3] across the four 16-lane groups of a wave: afterwards lane group g holds in r[s] what lane group s
+// held in r[g].  v_permlane32_swap exchanges (vdst lanes 32..63) <-> (vsrc lanes 0..31), v_permlane16_swap exchanges
+// (vdst odd groups) <-> (vsrc even groups).
+__device__ __forceinline__ void transpose_lane_groups(f32x4 (&r)[4]) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u2v t = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 2][d]), false, false);
+            r[pr][d] = __uint_as_float(t[0]);
+            r[pr + 2][d] = __uint_as_float(t[1]);
+        }
+#pragma unroll
+    for (int pr = 0; pr < 4; pr += 2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 1][d]), false, false);
+            r[pr][d] = __uint_as_float(t[0]);
+            r[pr + 1][d] = __uint_as_float(t[1]);
+        }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;
     constexpr bool BF16_OUT = (EPI != CEPI_BIAS_RESID_F32);
+    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM;  // store instructions of one wave's epilogue
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,7 +97,6 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const int wm = wave >> 2;          // ping-pong group = 256-row half of the tile
     const int wmm = (wave >> 1) & 1;   // 128-row quarter inside the group
     const int wn = wave & 1;           // 64-column half
-    char* scratch = lds + C_R * C_SLOT + wave * 4096;
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
@@ -57,14 +106,18 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + wl;
     if (tile >= hi) return;
-
-    // staging: 40 wave-instructions (16 rows x 64 B) per stage, wave w issues instruction slots q*8 + w, q < 5:
-    // slots 0..31 = activation rows (pixels), 32..39 = weight rows
-    const int srow = lane >> 2, spos = lane & 3;
+    const int nk = p.K / 32;
     const int HW = p.H * p.Wd;
-    int pix_m[4], pix_yx[4];  // per A slot: (clamped) output pixel index of this lane's row and its packed (y << 16 | x)
+
+    // ---- issue stream.  A stage = 40 wave-instructions (16 rows x 64 B): wave w issues instruction slots q*8 + w, q < 5:
+    // slots 0..31 = activation rows (pixels), 32..39 = weight rows.  Pixel rows go through a buffer resource whose base is
+    // moved by the tap's (wave-uniform) byte shift, so a lane's offset is a per-tile constant; padding lanes use an
+    // out-of-range offset and the DMA writes zeros for them.  Per instruction: and, compare, select.
+    const int srow = lane >> 2, spos = lane & 3;
     const int achunk = (spos ^ ((-(srow >> 2)) & 3)) * 16;  // swizzled 16-B chunk of this lane (same for every slot)
-    unsigned woffs;           // byte offset of this lane's weight row (+ chunk) from p.W
+    unsigned aoff[4], aoff2[4];  // byte offset of this lane's row (+ chunk) in the first / second source
+    int code[4];                 // border_code of the row's pixel
+    unsigned woffs;              // byte offset of this lane's weight row (+ chunk) from p.W
     auto set_sources = [&](int t) {
         const int m0 = (t / p.tiles_n) * C_BM, n0 = (t % p.tiles_n) * C_BN;
 #pragma unroll
@@ -73,8 +126,9 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
             int m = m0 + r;
             m = m < p.M ? m : p.M - 1;
             const int rem = m % HW;
-            pix_m[q] = m;
-            pix_yx[q] = ((rem / p.Wd) << 16) | (rem % p.Wd);
+            aoff[q] = (unsigned)m * (unsigned)(p.Cin * 2) + achunk;
+            aoff2[q] = (unsigned)m * (unsigned)(p.Cin2 * 2) + achunk;
+            code[q] = border_code(rem / p.Wd, rem % p.Wd, p.H, p.Wd);
         }
         const int rw = wave * 16 + srow;  // slot 32 + wave
         const int c = spos ^ ((-(rw >> 4)) & 3);
@@ -85,36 +139,33 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* A2b = reinterpret_cast<const char*>(p.A2);
     const char* Wb = reinterpret_cast<const char*>(p.W);
-    const char* Zb = reinterpret_cast<const char*>(p.zeros);
-    auto stage = [&](int v, int slot) {
-        char* base = lds + slot * C_SLOT;
-        const int k0 = v * 32;
-        const int conv_k = p.taps * p.Cin;
-        int dy = 0, dx = 0, cbytes, rowb;
-        const char* srcb;  // wave-uniform source tensor
-        if (k0 < conv_k) {
-            const int tap = k0 / p.Cin;
-            cbytes = (k0 - tap * p.Cin) * 2;
-            if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; }
-            srcb = Ab;
-            rowb = p.Cin * 2;
-        } else {
-            cbytes = (k0 - conv_k) * 2;
-            srcb = A2b;
-            rowb = p.Cin2 * 2;
-        }
-        const int shift = dy * p.Wd + dx;
+    int itile = tile, ik = 0, itap = 0, icb = 0, islot = 0;  // next stage: K step, its tap / channel byte offset, ring slot
+    auto issue_next = [&]() -> bool {
+        if (itile >= hi) return false;
+        char* base = lds + islot * C_SLOT;
+        const bool src2 = itap >= p.taps;
+        int dy = 0, dx = 0;
+        if (!src2 && p.taps == 9) { dy = itap / 3 - 1; dx = itap - (itap / 3) * 3 - 1; }
+        const int rowb = src2 ? p.Cin2 * 2 : p.Cin * 2;
+        const long delta = (long)(dy * p.Wd + dx) * rowb + icb;
+        const int tmask = tap_mask(dy, dx);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((src2 ? A2b : Ab) + delta), 0, BUF_RECORDS, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int yy = (pix_yx[q] >> 16) + dy, xx = (pix_yx[q] & 0xffff) + dx;
-            const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-            const unsigned off = (unsigned)(pix_m[q] + shift) * (unsigned)rowb + cbytes + achunk;
-            const char* src = ok ? srcb + off : Zb + achunk;
-            char* dst = base + (q * NW + wave) * 1024;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+            const unsigned vo = (code[q] & tmask) ? OOB_OFFSET : (src2 ? aoff2[q] : aoff[q]);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, 0, 0, 0);
         }
-        char* dstw = base + (32 + wave) * 1024;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(Wb + (size_t)v * 64 + woffs), LDS_PTR(dstw), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(Wb + (size_t)ik * 64 + woffs), LDS_PTR(base + (32 + wave) * 1024), 16, 0, 0);
+        icb += 64;
+        if (!src2 && icb == p.Cin * 2) { icb = 0; ++itap; }
+        if (++ik == nk) {
+            ik = 0; itap = 0; icb = 0;
+            itile += wpx;
+            if (itile < hi) set_sources(itile);
+        }
+        islot = (islot + 1) & (C_R - 1);
+        return true;
     };
 
     const int rho = lane & 15, qd = lane >> 4;
@@ -131,110 +182,97 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
 
-    auto epilogue = [&](int t) {
-        const int mw0 = (t / p.tiles_n) * C_BM + (wm * 2 + wmm) * 128, nw0 = (t % p.tiles_n) * C_BN + wn * 64;
-        const int nb = nw0 + 16 * qd;
-        const bool nb_ok = nb < p.N;
-        float bias[16];
+    auto init_acc = [&](int t) {  // accumulators start at the bias of their column (lane owns n = nb .. nb+15)
+        f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int nb = (t % p.tiles_n) * C_BN + wn * 64 + 16 * qd;
+        if (p.bias && nb < p.N) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) {
-            f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+            for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * i);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
+    };
+    auto epilogue = [&](int t) {
+        const int mw0 = (t / p.tiles_n) * C_BM + (wm * 2 + wmm) * 128, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
+        if (nb0 >= p.N) return;  // wave-uniform: the lane-group exchanges below need every lane
         if constexpr (BF16_OUT) {
-            const int rr = lane >> 3, ch = lane & 7;
-            const bool cols_ok = nw0 + 8 * ch < p.N;
-#pragma unroll
-            for (int rnd = 0; rnd < TM / 2; ++rnd) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = 2 * rnd + jj;
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
-                    if constexpr (EPI == CEPI_FILM_SILU_BF16) {
-                        // y*(scale+1)+shift (FeatureModulation, residual_block.py:21-24: addcmul(shift, scale+1, y)), then SiLU
-                        int m = mw0 + 16 * j + rho;
-                        m = m < p.M ? m : p.M - 1;
-                        const float* fr = p.film + (size_t)((m / HW) % p.film_rows) * p.film_stride;
-                        if (nb_ok) {
-#pragma unroll
-                            for (int e = 0; e < 16; e += 4) {
-                                const f32x4 sc = *reinterpret_cast<const f32x4*>(fr + nb + e);
-                                const f32x4 sh = *reinterpret_cast<const f32x4*>(fr + p.N + nb + e);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[e + r] = silu_f(__fmaf_rn(sc[r] + 1.0f, v[e + r], sh[r]));
-                            }
-                        }
-                    }
-                    u32x4 w0, w1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                        w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-                    }
-                    const int r = 16 * jj + rho;
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4 d[4];
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int r = 8 * t4 + rr;
-                    d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int m = mw0 + 32 * rnd + 8 * t4 + rr;
-                    if (m < p.M && cols_ok)
-                        __builtin_nontemporal_store(d[t4], reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nw0 + 8 * ch));
-                }
-            }
-        } else {
+            if (nb >= p.N) return;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int m = mw0 + 16 * j + rho;
-                if (m >= p.M || !nb_ok) continue;
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + nb;
-                const float* rs = p.resid ? p.resid + (size_t)m * p.ldo + nb : nullptr;
+                float v[16];
 #pragma unroll
-                for (int e = 0; e < 16; e += 4) {
-                    f32x4 v;
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[e / 4][j][r] + bias[e + r];
-                    if (rs) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + e);
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
+                if constexpr (EPI == CEPI_FILM_SILU_BF16) {
+                    // y*(scale+1)+shift (FeatureModulation, residual_block.py:21-24: addcmul(shift, scale+1, y)), then SiLU
+                    int m = mw0 + 16 * j + rho;
+                    m = m < p.M ? m : p.M - 1;
+                    const float* fr = p.film + (size_t)((m / HW) % p.film_rows) * p.film_stride;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    for (int e = 0; e < 16; e += 4) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(fr + nb + e);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(fr + p.N + nb + e);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[e + r] = silu_f(__fmaf_rn(sc[r] + 1.0f, v[e + r], sh[r]));
                     }
-                    *reinterpret_cast<f32x4*>(o + e) = v;
+                }
+                u32x4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                    w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                }
+                store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
+            }
+        } else {
+            // fp32 rows: lane (rho, qd) holds 16 consecutive floats of row rho.  A 4 x 4 transpose across the four 16-lane
+            // groups (two rounds of gfx950 lane-group swaps) makes the 4 lanes of a row write 64 contiguous bytes per store
+            // instruction instead of four 16-B pieces 64 B apart; the residual is read in the same pattern.
+            const int col = nb0 + 4 * qd;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+                transpose_lane_groups(r);
+                const int m = mw0 + 16 * j + rho;
+                if (m >= p.M) continue;
+                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
+                const float* rsd = p.resid ? p.resid + (size_t)m * p.ldo + col : nullptr;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (col + 16 * s4 >= p.N) continue;
+                    f32x4 v = r[s4];
+                    if (rsd) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rsd + 16 * s4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
 
-    const int nk = p.K / 32;  // launcher guarantees nk >= D
+    // prologue: C_D stages in flight; stage 0 must have landed before the first load phase
     set_sources(tile);
+    {
+        bool all = true;
 #pragma unroll
-    for (int d = 0; d < C_D; ++d) stage(d, d);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (C_D - 1)) : "memory");
+        for (int d = 0; d < C_D; ++d) all = issue_next() && all;
+        if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (C_D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     PHASE_BARRIER();
-    if (wm == 1) PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
 
-    int slot = 0, pslot = C_D;
+    int slot = 0;
     int after_e = 0;
     while (true) {
         const int next = tile + wpx;
         const bool has_next = next < hi;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        init_acc(tile);
         for (int v = 0; v < nk; ++v) {
             {
                 const char* b = lds + slot * C_SLOT;
@@ -243,17 +281,10 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * C_RB);
             }
-            bool issued = false;
-            if (v + C_D < nk) {
-                stage(v + C_D, pslot);
-                issued = true;
-            } else if (has_next) {
-                if (v + C_D == nk) set_sources(next);
-                stage(v + C_D - nk, pslot);
-                issued = true;
-            }
-            if (issued) {
-                if (BF16_OUT && after_e > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (C_D - 1) + 16) : "memory");
+            // stage v+1 must have landed before the barrier: the C_D - 1 younger stages may stay in flight, and so may the
+            // stores of an epilogue that sit behind stage v+1 in issue order (true for the C_D - 1 phases after it)
+            if (issue_next()) {
+                if (after_e > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (C_D - 1) + NSTORE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (C_D - 1)) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -268,13 +299,12 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
                 for (int i = 0; i < 4; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if (v == nk - 1 && wm == 1) epilogue(tile);
+            if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
             PHASE_BARRIER();
-            slot = (slot == C_R - 1) ? 0 : slot + 1;
-            pslot = (pslot == C_R - 1) ? 0 : pslot + 1;
+            slot = (slot + 1) & (C_R - 1);
         }
-        if (wm == 0) epilogue(tile);
-        after_e = 2;
+        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
+        after_e = C_D - 1;
         if (!has_next) break;
         tile = next;
     }
@@ -283,20 +313,26 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 }
 
 int g_conv_cus = 0;
+int g_conv_grid_limit = 0;  // > 0: at most this many workgroups (tests: several tiles per workgroup on small inputs)
 
-template <int EPI>
-int launch_conv(ConvParams p, hipStream_t s) {
-    p.tiles_m = (p.M + C_BM - 1) / C_BM;
-    p.tiles_n = (p.N + C_BN - 1) / C_BN;
+int conv_cus() {
     if (g_conv_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_conv_cus = prop.multiProcessorCount;
         if (g_conv_cus <= 0) g_conv_cus = 256;
     }
+    if (g_conv_grid_limit > 0 && g_conv_grid_limit < g_conv_cus) return g_conv_grid_limit;
+    return g_conv_cus;
+}
+
+template <int EPI>
+int launch_conv(ConvParams p, hipStream_t s) {
+    p.tiles_m = (p.M + C_BM - 1) / C_BM;
+    p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < g_conv_cus ? nwg : g_conv_cus;
-    const size_t lds = (size_t)C_R * C_SLOT + 32768;
+    const int grid = nwg < conv_cus() ? nwg : conv_cus();
+    const size_t lds = (size_t)C_R * C_SLOT;
     auto kern = conv_ring_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -310,8 +346,17 @@ int launch_conv(ConvParams p, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int bsi_conv_set_grid_limit(int max_workgroups) {
+    if (max_workgroups < 0 || max_workgroups % 8) {  // tiles are partitioned over the 8 XCDs: every XCD needs a workgroup
+        bsi_set_error("bsi_conv_set_grid_limit: limit must be 0 or a multiple of 8, got %d", max_workgroups);
+        return BSI_EINVAL;
+    }
+    g_conv_grid_limit = max_workgroups;
+    return BSI_OK;
+}
+
 extern "C" int bsi_conv_nhwc_bf16(const bsi_conv_args* a, bsi_stream_t stream) {
-    BSI_CHECK_ARG(a && a->x && a->w && a->out && a->zeros, "bsi_conv_nhwc_bf16: null pointer");
+    BSI_CHECK_ARG(a && a->x && a->w && a->out, "bsi_conv_nhwc_bf16: null pointer");
     BSI_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, "bsi_conv_nhwc_bf16: bad sizes");
     BSI_CHECK_ARG(a->taps == 9 || a->taps == 1, "bsi_conv_nhwc_bf16: taps must be 9 (3x3) or 1 (1x1), got %d", a->taps);
     BSI_CHECK_ARG(a->Cin % 32 == 0 && a->Cin2 % 32 == 0 && a->Cout % 16 == 0,
@@ -323,7 +368,6 @@ extern "C" int bsi_conv_nhwc_bf16(const bsi_conv_args* a, bsi_stream_t stream) {
     p.A2 = reinterpret_cast<const __bf16*>(a->x2);
     p.W = reinterpret_cast<const __bf16*>(a->w);
     p.bias = a->bias;
-    p.zeros = reinterpret_cast<const __bf16*>(a->zeros);
     p.out = a->out;
     p.film = a->film; p.film_rows = a->film_rows > 0 ? a->film_rows : 1; p.film_stride = a->film_stride;
     p.resid = a->resid;
@@ -331,7 +375,7 @@ extern "C" int bsi_conv_nhwc_bf16(const bsi_conv_args* a, bsi_stream_t stream) {
     p.H = a->H; p.Wd = a->W; p.ldo = a->ldo;
     p.K = a->taps * a->Cin + a->Cin2;
     BSI_CHECK_ARG(p.K / 32 >= C_D, "bsi_conv_nhwc_bf16: K=%d too small", p.K);
-    BSI_CHECK_ARG((size_t)p.M * (a->Cin > a->Cin2 ? a->Cin : a->Cin2) * 2 < (1ull << 32) && (size_t)p.N * p.K * 2 < (1ull << 32),
+    BSI_CHECK_ARG((size_t)p.M * (a->Cin > a->Cin2 ? a->Cin : a->Cin2) * 2 < (size_t)BUF_RECORDS - 256 && (size_t)p.N * p.K * 2 < (1ull << 32),
                   "bsi_conv_nhwc_bf16: tensors exceed the 32-bit offset range");
     BSI_CHECK_ARG(a->H < 65536 && a->W < 65536, "bsi_conv_nhwc_bf16: image too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -335,7 +335,7 @@ typedef struct bsi_conv_args {
     const void* x2;    /* optional bf16 NHWC [B*H*W, Cin2]: extra 1x1 K steps (skip conv folded in) */
     const void* w;     /* bf16 [Cout][taps*Cin + Cin2] from bsi_conv_weight_pack */
     const float* bias; /* [Cout] */
-    const void* zeros; /* >= 64 bytes of zeros (padding taps read it) */
+    const void* zeros; /* unused by the forward kernel (padding taps use out-of-range buffer offsets); wgrad reads 256 zero bytes */
     void* out;         /* bf16 or fp32 [B*H*W, ldo] */
     const float* film; /* FILM: fp32 [film_rows][film_stride], scale at [0, Cout), shift at [Cout, 2 Cout) */
     const float* resid;/* BIAS_RESID_F32: fp32 [B*H*W, ldo] or NULL */
@@ -344,6 +344,8 @@ typedef struct bsi_conv_args {
 } bsi_conv_args;
 /* Conv2d(stride 1, zero padding) as implicit GEMM on bf16 MFMA; Cin, Cin2 multiples of 32, Cout of 16. */
 int bsi_conv_nhwc_bf16(const bsi_conv_args* a /*host*/, bsi_stream_t stream);
+/* > 0 (a multiple of 8, one share per XCD): launch at most this many (persistent) workgroups, 0 = one per CU.  Lets small inputs exercise several tiles per workgroup. */
+int bsi_conv_set_grid_limit(int max_workgroups);
 /* fp32 Conv2d weight [Cout][Cin][kh][kw] -> bf16 [Cout][ld] at column col0 with K index (tap, channel), Cin padded. */
 int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, void* out,
                          bsi_stream_t stream);

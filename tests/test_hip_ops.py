@@ -462,8 +462,15 @@ def _nhwc(x):
 @pytest.mark.parametrize("B,H,Cin,Cin2,Cout,taps,epi", [
     (2, 8, 64, 0, 64, 9, "bias"), (3, 32, 128, 0, 128, 9, "film"), (2, 32, 128, 0, 128, 9, "resid"),
     (2, 32, 128, 256, 128, 9, "resid_skip"), (2, 32, 32, 0, 128, 9, "resid0"), (2, 32, 128, 0, 384, 9, "bias"),
-    (9, 8, 256, 0, 64, 1, "bias")])
+    (9, 8, 256, 0, 64, 1, "bias"), (3, 16, 384, 0, 128, 9, "bias"), (5, 16, 256, 128, 128, 9, "resid_skip"),
+    (12, 32, 128, 0, 128, 9, "bias_persistent"), (12, 32, 64, 0, 128, 9, "resid_persistent"), (3, 8, 128, 0, 384, 1, "resid")])
 def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
+    if epi.endswith("_persistent"):  # 8 workgroups walk 24 tiles: tile-to-tile hand-over of the DMA ring and the epilogue stores
+        N.check(N.lib().bsi_conv_set_grid_limit(8))
+        try:
+            return test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi[:-len("_persistent")])
+        finally:
+            N.check(N.lib().bsi_conv_set_grid_limit(0))
     gen = torch.Generator().manual_seed(B + H + Cin + Cout)
     ks = 3 if taps == 9 else 1
     x = bf16r(torch.randn((B, Cin, H, H), generator=gen))
@@ -473,7 +480,7 @@ def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
     K = taps * Cin + Cin2
     wp = empty(Cout, K, dtype=torch.bfloat16)
     N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w)), Cout, Cin, taps, Cin, K, 0, N.ptr(wp), N.stream()))
-    zeros = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
     a = N.ConvArgs(x=dev(_nhwc(x).to(torch.bfloat16)).data_ptr(), w=wp.data_ptr(), bias=dev(bias).data_ptr(),
                    zeros=zeros.data_ptr(), B=B, H=H, W=H, Cin=Cin, Cin2=Cin2, Cout=Cout, taps=taps, ldo=Cout)
     if Cin2:

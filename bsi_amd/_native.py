@@ -147,6 +147,7 @@ _PROTOS = {
     "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
     "bsi_gemm_set_variant": (_i, [_i]),
     "bsi_conv_set_grid_limit": (_i, [_i]),
+    "bsi_conv_set_ablation": (_i, [_i]),
     "bsi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "bsi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "bsi_gemm_tn_bias_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),

@@ -27,6 +27,7 @@ struct ConvParams {
     int M, N, Cin, Cin2, taps, H, Wd, ldo;
     int K;                // taps*Cin + Cin2
     int tiles_m, tiles_n;
+    int abl;              // experiments (bsi_conv_set_ablation): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 every pixel row out of range, 16 no fragment reads
 };
 
 constexpr int C_BM = 512, C_BN = 128, C_RB = 64, C_R = 4, C_D = C_R - 1;
@@ -142,21 +143,25 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     int itile = tile, ik = 0, itap = 0, icb = 0, islot = 0;  // next stage: K step, its tap / channel byte offset, ring slot
     auto issue_next = [&]() -> bool {
         if (itile >= hi) return false;
+        if (p.abl & 1) { if (++ik == nk) { ik = 0; itile += wpx; } return true; }
         char* base = lds + islot * C_SLOT;
         const bool src2 = itap >= p.taps;
         int dy = 0, dx = 0;
         if (!src2 && p.taps == 9) { dy = itap / 3 - 1; dx = itap - (itap / 3) * 3 - 1; }
         const int rowb = src2 ? p.Cin2 * 2 : p.Cin * 2;
         const long delta = (long)(dy * p.Wd + dx) * rowb + icb;
-        const int tmask = tap_mask(dy, dx);
+        const int tmask = (p.abl & 8) ? 15 : tap_mask(dy, dx);
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((src2 ? A2b : Ab) + delta), 0, BUF_RECORDS, 0x00020000);
+        if (!(p.abl & 64)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned vo = (code[q] & tmask) ? OOB_OFFSET : (src2 ? aoff2[q] : aoff[q]);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const unsigned vo = (code[q] & tmask) ? OOB_OFFSET : (src2 ? aoff2[q] : aoff[q]);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, 0, 0, 0);
+            }
         }
-        __builtin_amdgcn_global_load_lds(GLB_PTR(Wb + (size_t)ik * 64 + woffs), LDS_PTR(base + (32 + wave) * 1024), 16, 0, 0);
+        if (!(p.abl & 32))
+            __builtin_amdgcn_global_load_lds(GLB_PTR(Wb + (size_t)ik * 64 + woffs), LDS_PTR(base + (32 + wave) * 1024), 16, 0, 0);
         icb += 64;
         if (!src2 && icb == p.Cin * 2) { icb = 0; ++itap; }
         if (++ik == nk) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     };
     auto epilogue = [&](int t) {
         const int mw0 = (t / p.tiles_n) * C_BM + (wm * 2 + wmm) * 128, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
-        if (nb0 >= p.N) return;  // wave-uniform: the lane-group exchanges below need every lane
+        if (nb0 >= p.N || (p.abl & 4)) return;  // wave-uniform: the lane-group exchanges below need every lane
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
 #pragma unroll
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         const bool has_next = next < hi;
         init_acc(tile);
         for (int v = 0; v < nk; ++v) {
-            {
+            if (!(p.abl & 16)) {
                 const char* b = lds + slot * C_SLOT;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * C_RB);
@@ -293,11 +298,13 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PHASE_BARRIER();
             __builtin_amdgcn_s_setprio(1);
+            if (!(p.abl & 2)) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
+                for (int j = 0; j < TM; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
             PHASE_BARRIER();
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 }
 
 int g_conv_cus = 0;
+int g_conv_abl = 0;
 int g_conv_grid_limit = 0;  // > 0: at most this many workgroups (tests: several tiles per workgroup on small inputs)
 
 int conv_cus() {
@@ -329,6 +337,7 @@ int conv_cus() {
 template <int EPI>
 int launch_conv(ConvParams p, hipStream_t s) {
     p.tiles_m = (p.M + C_BM - 1) / C_BM;
+    p.abl = g_conv_abl;
     p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < conv_cus() ? nwg : conv_cus();
@@ -345,6 +354,11 @@ int launch_conv(ConvParams p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int bsi_conv_set_ablation(int flags) {  // kernel experiments only (tools/conv_bench.py); results are wrong with flags != 0
+    g_conv_abl = flags;
+    return BSI_OK;
+}
 
 extern "C" int bsi_conv_set_grid_limit(int max_workgroups) {
     if (max_workgroups < 0 || max_workgroups % 8) {  // tiles are partitioned over the 8 XCDs: every XCD needs a workgroup

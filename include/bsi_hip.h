@@ -346,6 +346,8 @@ typedef struct bsi_conv_args {
 int bsi_conv_nhwc_bf16(const bsi_conv_args* a /*host*/, bsi_stream_t stream);
 /* > 0 (a multiple of 8, one share per XCD): launch at most this many (persistent) workgroups, 0 = one per CU.  Lets small inputs exercise several tiles per workgroup. */
 int bsi_conv_set_grid_limit(int max_workgroups);
+/* Kernel experiments only: switch parts of the convolution kernel off (ConvParams::abl in conv_igemm.hip); 0 = normal. */
+int bsi_conv_set_ablation(int flags);
 /* fp32 Conv2d weight [Cout][Cin][kh][kw] -> bf16 [Cout][ld] at column col0 with K index (tap, channel), Cin padded. */
 int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, void* out,
                          bsi_stream_t stream);

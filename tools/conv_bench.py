@@ -1,5 +1,5 @@
 """Implicit-GEMM convolution throughput at the VDM-UNet shapes (32x32 images, 128 output channels).
-usage: [B=128] python tools/conv_bench.py"""
+usage: [B=128] [ABL=0,1,2,...] python tools/conv_bench.py   (ABL: ablation flags of bsi_conv_set_ablation, one column each)"""
 import ctypes as C
 import os
 import sys
@@ -37,7 +37,8 @@ def main():
         if res is not None and not Cin2:
             a.resid = res.data_ptr()
         line = f"{name:36s}"
-        if True:
+        for abl in [int(v) for v in os.environ.get("ABL", "0").split(",")]:
+            N.check(lib.bsi_conv_set_ablation(abl))
             for _ in range(3):
                 N.check(lib.bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +48,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
-            line += f"  {ms * 1e3:6.1f} us {2.0 * M * K * Cout / ms / 1e9:6.1f} TF"
+            line += f"  [{abl}] {ms * 1e3:6.1f} us {2.0 * M * K * Cout / ms / 1e9:6.1f} TF"
+        N.check(lib.bsi_conv_set_ablation(0))
         print(line, flush=True)
 
 

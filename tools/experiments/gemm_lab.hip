@@ -74,7 +74,8 @@ float time_w1(GemmParams p, int iters) {
 // L2 -> LDS fill-rate microbenchmark: 8 waves per CU issue nothing but global_load_lds_dwordx4 over an L2-resident region.
 // seg = bytes each group of lanes reads contiguously (64: lanes 0..3 form a row segment as in the K=32 GEMM stage,
 // 128: lanes 0..7 as in a K=64 stage, 1024: the whole wave reads 1 KB contiguously).
-__global__ __launch_bounds__(512) void dma_bw_kernel(const char* src, unsigned region, int iters, int seg, int ld) {
+// mode 0: global_load_lds; mode 1: buffer_load ... lds (offen, what the convolution uses); mode 2: buffer, every 4th row out of range
+__global__ __launch_bounds__(512) void dma_bw_kernel(const char* src, unsigned region, int iters, int seg, int ld, int mode) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lps = seg / 16;                       // lanes per contiguous segment
@@ -84,7 +85,13 @@ __global__ __launch_bounds__(512) void dma_bw_kernel(const char* src, unsigned r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned off = (base + q * 1024u * 37u + lane_off) % region;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src + (off & ~15u)), LDS_PTR(lds + ((it & 3) * 32 + q * 8 + wave) * 1024), 16, 0, 0);
+            if (mode == 0) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src + (off & ~15u)), LDS_PTR(lds + ((it & 3) * 32 + q * 8 + wave) * 1024), 16, 0, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 0x80000000u, 0x00020000);
+                const unsigned vo = (mode == 2 && ((lane / lps) & 3) == 3) ? 0xFFFFFF00u : (off & ~15u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + ((it & 3) * 32 + q * 8 + wave) * 1024), 16, vo, 0, 0, 0);
+            }
         }
         base += 8 * 4096u * 61u;
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -99,19 +106,21 @@ static void dma_bench() {
     hipMemset(d, 1, region + (1 << 20));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dma_bw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     const int iters = 4000;
-    for (int seg : {64, 128, 256, 1024}) {
-        const int ld = seg == 1024 ? 1024 : 2048;  // row pitch of the source matrix
+    struct Case { int seg, ld, mode; } cases[] = {{64, 2048, 0}, {128, 2048, 0}, {256, 2048, 0}, {1024, 1024, 0}, {64, 256, 0}, {64, 512, 0},
+                                                   {128, 256, 0}, {64, 2048, 1}, {64, 256, 1}, {64, 256, 2}, {128, 2048, 1}};
+    for (auto cs : cases) {
+        const int seg = cs.seg, ld = cs.ld, mode = cs.mode;  // segment bytes, row pitch of the source matrix
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
-        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, 100, seg, ld);
+        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, 100, seg, ld, mode);
         hipEventRecord(a, 0);
-        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, iters, seg, ld);
+        hipLaunchKernelGGL(dma_bw_kernel, dim3(256), dim3(512), 131072, 0, d, region, iters, seg, ld, mode);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
         hipEventElapsedTime(&ms, a, b);
         const double bytes = 256.0 * 8 * 4 * 1024.0 * iters;
-        printf("LDS-DMA fill, %4d-B segments: %7.2f TB/s aggregate = %6.1f GB/s per CU (%.1f B/clk at 2.1 GHz)\n", seg, bytes / ms / 1e9,
+        printf("LDS-DMA fill, %4d-B segments, pitch %4d, %s: %7.2f TB/s aggregate = %6.1f GB/s per CU (%.1f B/clk at 2.1 GHz)\n", seg, ld, mode == 0 ? "global" : mode == 1 ? "buffer" : "buffer 1/4 OOB", bytes / ms / 1e9,
                bytes / ms / 1e6 / 256, bytes / ms / 1e6 / 256 / 2.1);
     }
     hipFree(d);

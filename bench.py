@@ -219,7 +219,7 @@ def main():
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.batch),
-                         "kernel": "gemm_bf16_pring_kernel<BSI_EPI_BIAS_GELU_BF16=2, 0> (fc1)",
+                         "kernel": "gemm_bf16_k64r_kernel<BSI_EPI_BIAS_GELU_BF16=2, 0> (fc1)",
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }
 

@@ -244,6 +244,8 @@ def lib():
             fn.argtypes = args
         if os.environ.get("BSI_GEMM_VARIANT"):  # kernel experiments (tools/gemm_bench.py documents the encoding)
             _lib.bsi_gemm_set_variant(int(os.environ["BSI_GEMM_VARIANT"]))
+        if os.environ.get("BSI_CONV_ABL"):  # convolution kernel choice / ablations (bsi_conv_set_ablation)
+            _lib.bsi_conv_set_ablation(int(os.environ["BSI_CONV_ABL"]))
     return _lib
 
 

@@ -311,7 +311,317 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
             slot = (slot + 1) & (C_R - 1);
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        after_e = C_D - 1;
+        // the store allowance is valid only if every store instruction of the epilogue was issued (no row / column tail)
+        after_e = ((tile / p.tiles_n) * C_BM + C_BM <= p.M && (tile % p.tiles_n) * C_BN + C_BN <= p.N && !(p.abl & 4)) ? C_D - 1 : 0;
+        if (!has_next) break;
+        tile = next;
+    }
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 convolution with the PIXEL SLAB kept in LDS across the 9 taps.
+// conv_ring_kernel re-fetches its 512 pixel rows for every tap: 40 KB of LDS-DMA per 256 MFMAs per CU, which is what bounds
+// it (the DMA engine delivers 55-75 GB/s per CU for 64-B segments at NHWC row pitch).  Here the K loop is ordered
+// (32-channel chunk, tap): the chunk's slab = the tile's 512 pixels + a halo of 48 pixels on either side, 608 rows x 64 B =
+// 38 KB, is DMA'd ONCE and the 9 taps read their fragments from it at row offset dy*W + dx (any 16 consecutive rows of the
+// swizzled image are bank-conflict free).  Border handling moves to the read side: a fragment = 16 consecutive pixels of
+// one image row (W % 16 == 0), so "tap row outside the image" is wave-uniform per fragment (registers zeroed) and "tap
+// column outside" concerns lane 0 or 15 of fragments at a row end (those lanes read a zero row of LDS instead).
+// DMA per phase: 8 KB of weights + 1/9 of the next slab = 12.3 KB instead of 40 KB.
+// LDS: 2 slabs (double buffer) 76 KB + ring of 8 weight stages x 8 KB (6 in flight) + zero row.
+// Issue order per phase and wave: [epilogue stores] [slab piece, taps 0..4] [weight stage P+6]; the vmcnt allowance is the
+// exact number of instructions issued after the one that must have landed (sum of the last five phases' counts).
+constexpr int S_HALO = 48, S_ROWS = C_BM + 2 * S_HALO, S_INSTR = S_ROWS / 16;  // 608 rows, 38 DMA instructions
+constexpr int S_SLAB = S_ROWS * C_RB;                                             // 38912 B
+constexpr int S_WSLOTS = 8, S_WD = 6, S_WSTAGE = C_BN * C_RB;                     // 8 KB weight stages, 6 in flight
+constexpr int S_WRING = 2 * S_SLAB, S_ZERO = S_WRING + S_WSLOTS * S_WSTAGE, S_LDS = S_ZERO + 64;
+
+template <int NSTORE>
+__device__ __forceinline__ void wait_vm_allowed(int n) {  // s_waitcnt vmcnt(n) for a wave-uniform runtime n (rounded down where rare)
+#define BSI_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    if (n >= NSTORE + 5) {
+        switch (n - NSTORE) {
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 5) : "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 6) : "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 7) : "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 8) : "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 9) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 10) : "memory"); break;
+        }
+        return;
+    }
+    switch (n) {
+        BSI_WVM(0) BSI_WVM(1) BSI_WVM(2) BSI_WVM(3) BSI_WVM(4) BSI_WVM(5) BSI_WVM(6) BSI_WVM(7) BSI_WVM(8) BSI_WVM(9)
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+#undef BSI_WVM
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr bool BF16_OUT = (EPI != CEPI_BIAS_RESID_F32);
+    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM;
+    static_assert(EPI != CEPI_FILM_SILU_BF16, "FILM epilogue lives in conv_ring_kernel");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wmm = (wave >> 1) & 1, wn = wave & 1;
+    const int wrow0 = (wm * 2 + wmm) * 128;  // first tile row of this wave
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;
+    const int nc = p.Cin / 32;
+    const int HW = p.H * p.Wd;
+
+    if (tid < 16) reinterpret_cast<float*>(lds + S_ZERO)[tid] = 0.f;  // visible after the prologue's barrier
+
+    // ---- slab stream (runs one slab ahead of the compute): 5 DMA instructions per wave and slab, 16 rows x 64 B each.
+    // The buffer base is the slab's first row, so a lane's offset never changes; rows past the end of the tensor fall outside
+    // num_records (zeros), rows before its start (first tile only) are sent out of range explicitly.
+    const int srow = lane >> 2, spos = lane & 3;
+    const int achunk = (spos ^ ((-(srow >> 2)) & 3)) * 16;
+    const int rowb = p.Cin * 2;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    asm volatile("" : "+s"(Ab), "+s"(Wb));  // keep the kernel arguments in SGPRs (no reloads inside the loop)
+    unsigned soff[5];
+    unsigned before = 0;  // bit q: this lane's row of piece q lies in the leading halo (before the tensor when the tile is the first)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int ins = q * NW + wave;
+        ins = ins < S_INSTR ? ins : S_INSTR - 1;  // waves 6, 7: the 5th piece repeats the last rows (same data)
+        const int r = ins * 16 + srow;
+        soff[q] = (unsigned)r * (unsigned)rowb + achunk;
+        before |= (r < S_HALO ? 1u : 0u) << q;
+    }
+    int st_tile = tile, st_c = 0, sg = 0;  // slab being filled: tile, chunk, running slab index (buffer = sg & 1)
+    int st_m0 = (tile / p.tiles_n) * C_BM - S_HALO;  // its first pixel row (negative for the tensor's first tile)
+    __amdgpu_buffer_rsrc_t srs;                      // buffer resource of that slab: base = its first row, chunk st_c
+    auto slab_resource = [&]() {
+        const long rec = ((long)p.M - st_m0) * rowb - st_c * 64;
+        srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab + (long)st_m0 * rowb + st_c * 64), 0,
+                                                (unsigned)(rec < (long)BUF_RECORDS ? rec : (long)BUF_RECORDS), 0x00020000);
+    };
+    slab_resource();
+    auto issue_slab_piece = [&](int q) {  // caller checked st_tile < hi
+        int ins = q * NW + wave;
+        ins = ins < S_INSTR ? ins : S_INSTR - 1;
+        unsigned vo = soff[q];
+        if (st_m0 < 0) vo = ((before >> q) & 1) ? OOB_OFFSET : vo;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, LDS_PTR(lds + (sg & 1) * S_SLAB + ins * 1024), 16, vo, 0, 0, 0);
+    };
+    auto advance_slab = [&]() {  // after piece 4
+        ++sg;
+        if (++st_c == nc) {
+            st_c = 0;
+            st_tile += wpx;
+            st_m0 = (st_tile / p.tiles_n) * C_BM - S_HALO;
+        }
+        if (st_tile < hi) slab_resource();
+    };
+    // ---- weight stream: stage of global phase wP (tile, chunk, tap), 16 rows x 64 B per wave; N % 128 == 0 (launcher)
+    const unsigned woffs = (unsigned)(wave * 16 + srow) * (unsigned)(p.K * 2) + (spos ^ ((-wave) & 3)) * 16;
+    int wt_tile = tile, wt_c = 0, wP = 0;
+    const char* wptr = Wb + (size_t)(tile % p.tiles_n) * C_BN * p.K * 2;  // + K offset of (chunk, tap), advanced incrementally
+    auto issue_w = [&]() {  // caller checked wt_tile < hi
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wptr + woffs), LDS_PTR(lds + S_WRING + (wP & (S_WSLOTS - 1)) * S_WSTAGE + wave * 1024), 16, 0, 0);
+        ++wP;
+        wptr += rowb;  // next tap: + Cin channels
+    };
+    auto advance_w_chunk = [&]() {  // after tap 8: the stream always runs S_WD phases ahead, so the tap is known at compile time
+        wptr += 64 - 9 * rowb;  // next chunk: + 32 channels of tap 0
+        if (++wt_c == nc) {
+            wt_c = 0;
+            wt_tile += wpx;
+            wptr = Wb + (size_t)(wt_tile % p.tiles_n) * C_BN * p.K * 2;
+        }
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int wcc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
+    const int woff = S_WRING + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * C_RB + wcc;
+    const int xrow0 = S_HALO + wrow0 + rho;  // slab row of this lane's pixel in fragment 0, before the tap shift
+    const int zaddr = S_ZERO + qd * 16;
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    auto init_acc = [&](int t) {
+        f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int nb = (t % p.tiles_n) * C_BN + wn * 64 + 16 * qd;
+        if (p.bias && nb < p.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
+    };
+    auto epilogue = [&](int t) {
+        const int mw0 = (t / p.tiles_n) * C_BM + wrow0, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
+        if (nb0 >= p.N) return;
+        if constexpr (BF16_OUT) {
+            if (nb >= p.N) return;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                u32x4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    w0[e] = pack_bf16x2(acc[0][j][2 * e], acc[0][j][2 * e + 1]);
+                    w0[2 + e] = pack_bf16x2(acc[1][j][2 * e], acc[1][j][2 * e + 1]);
+                    w1[e] = pack_bf16x2(acc[2][j][2 * e], acc[2][j][2 * e + 1]);
+                    w1[2 + e] = pack_bf16x2(acc[3][j][2 * e], acc[3][j][2 * e + 1]);
+                }
+                store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
+            }
+        } else {
+            const int col = nb0 + 4 * qd;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+                transpose_lane_groups(r);
+                const int m = mw0 + 16 * j + rho;
+                if (m >= p.M) continue;
+                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
+                const float* rsd = p.resid ? p.resid + (size_t)m * p.ldo + col : nullptr;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (col + 16 * s4 >= p.N) continue;
+                    f32x4 v = r[s4];
+                    if (rsd) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rsd + 16 * s4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
+                }
+            }
+        }
+    };
+
+    // the vmcnt allowance may count an epilogue's stores only when every one of them is issued (no row / column tail)
+    auto full_tile = [&](int t) {
+        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N;
+    };
+    // prologue: slab 0 and weight stages 0 .. S_WD-1; slab 0 and stage 0 must have landed before the first load phase
+#pragma unroll
+    for (int q = 0; q < 5; ++q) issue_slab_piece(q);
+    advance_slab();
+    int nw_issued = 0;
+#pragma unroll
+    for (int d = 0; d < S_WD; ++d)
+        if (wt_tile < hi) { issue_w(); ++nw_issued; }
+    wait_vm_allowed<NSTORE>(nw_issued - 1);
+    // issue counts of the last five phases (n4 = oldest); weight stages 2 .. S_WD-1 count as issued in phases -4 .. -1
+    int n4 = nw_issued > 2, n3 = nw_issued > 3, n2 = nw_issued > 4, n1 = nw_issued > 5, n0 = 0;
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
+
+    int irr = nw_issued == S_WD ? 0 : 5;  // phases until the last five issue counts are the regular ones again
+    int P = 0, cg = 0;    // global phase and slab counters of the compute side
+    int pending_stores = 0;
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+        init_acc(tile);
+        // border masks of this wave's 8 fragments (16 pixels of one image row each): lane j < 8 evaluates fragment j
+        unsigned ytop, ybot, xl, xr;
+        {
+            const int R = (tile / p.tiles_n) * C_BM + wrow0 + 16 * (lane & 7);
+            const int rem = R % HW, y = rem / p.Wd, x0 = rem % p.Wd;
+            ytop = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == 0) & 0xff));
+            ybot = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == p.H - 1) & 0xff));
+            xl = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(x0 == 0) & 0xff));
+            xr = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(x0 + 16 == p.Wd) & 0xff));
+        }
+        for (int c = 0; c < nc; ++c) {
+            const int slab_off = (cg & 1) * S_SLAB;
+            const char* slab = lds + slab_off;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                // ---- L phase: fragments of (chunk c, tap t)
+                {
+                    const char* wb = lds + (P & (S_WSLOTS - 1)) * S_WSTAGE;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + woff + i * 4 * C_RB);
+                    int row = xrow0 + dy * p.Wd + dx;
+                    asm volatile("" : "+v"(row));  // recompute per phase: hoisting the 9 taps' addresses out of the chunk loop costs 20+ VGPRs
+                    const int xaddr = row * C_RB + ((qd ^ ((-(row >> 2)) & 3)) << 4);
+                    const unsigned zall = dy < 0 ? ytop : dy > 0 ? ybot : 0u;
+                    const unsigned zlane = dx < 0 ? xl : dx > 0 ? xr : 0u;
+                    if ((zall | zlane) == 0) {  // no fragment of this wave touches a border under this tap
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(slab + xaddr + j * 16 * C_RB);
+                    } else {
+                        const bool edge_lane = rho == (dx < 0 ? 0 : 15);
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) {
+                            const bool z = ((zall >> j) & 1) || (((zlane >> j) & 1) && edge_lane);
+                            const int a = z ? zaddr : slab_off + xaddr + j * 16 * C_RB;
+                            xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
+                        }
+                    }
+                }
+                // ---- issue: next slab piece (taps 0..4), weight stage P + S_WD
+                const bool sp = t < 5 && st_tile < hi, wv = wt_tile < hi;
+                const bool normal = wv && (t >= 5 || sp) && pending_stores == 0;
+                irr = normal ? (irr > 0 ? irr - 1 : 0) : 5;
+                n0 = pending_stores + (sp ? 1 : 0) + (wv ? 1 : 0);
+                pending_stores = 0;
+                if (sp) {
+                    issue_slab_piece(t < 5 ? t : 0);
+                    if (t == 4) advance_slab();
+                }
+                if (wv) {
+                    issue_w();
+                    if ((t + S_WD) % 9 == 8) advance_w_chunk();
+                }
+                // must have landed: weight stage P+1 (issued in phase P-5) and, at the last tap, the whole next slab (its last
+                // piece was the first instruction of phase P-4): everything issued after those may stay in flight.  Steady state
+                // (five regular phases in a row): the count is a constant of the tap; otherwise the sum of the recorded counts.
+                if (irr == 0) {
+                    constexpr int pieces[9] = {1, 2, 3, 4, 5, 4, 3, 2, 0};
+                    if (t == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + pieces[t < 9 ? t : 0]) : "memory");
+                } else {
+                    wait_vm_allowed<NSTORE>(t == 8 ? n3 + n2 + n1 + n0 : n4 + n3 + n2 + n1 + n0);
+                }
+                n4 = n3; n3 = n2; n2 = n1; n1 = n0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                // ---- C phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (t == 8 && c == nc - 1 && wm == 1) { epilogue(tile); pending_stores = full_tile(tile) ? NSTORE : 0; }  // group B: before its last barrier
+                PHASE_BARRIER();
+                ++P;
+            }
+            ++cg;
+        }
+        if (wm == 0) { epilogue(tile); pending_stores = full_tile(tile) ? NSTORE : 0; }  // group A: merged with its next L phase
         if (!has_next) break;
         tile = next;
     }
@@ -335,12 +645,35 @@ int conv_cus() {
 }
 
 template <int EPI>
+int launch_conv_slab(const ConvParams& p, int grid, hipStream_t s) {
+    auto kern = conv_slab_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_LDS, s, p);
+    BSI_CHECK_LAUNCH("bsi_conv_nhwc_bf16");
+    return BSI_OK;
+}
+
+template <int EPI>
 int launch_conv(ConvParams p, hipStream_t s) {
     p.tiles_m = (p.M + C_BM - 1) / C_BM;
     p.abl = g_conv_abl;
     p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < conv_cus() ? nwg : conv_cus();
+    if constexpr (EPI != CEPI_FILM_SILU_BF16) {
+        // 3x3 without folded skip steps on images whose rows are whole fragments run the slab kernel.  Measured on one MI355X
+        // (tools/conv_bench.py, 128 / 512 images): fp32-output epilogue 71 / 317 us against 84 / 349 us for the ring kernel (its
+        // stores get five phases to drain instead of two), 256 -> 128 channels bf16 93 / 336 against 94 / 341, 128 -> 128 bf16
+        // 57 / 214 against 50 / 189 (longer load phase: tap address arithmetic); UNet sampling at 256 images: 510 images/s (k=16)
+        // with the slab kernel wherever possible, 505 with it for fp32 outputs only, 497 without it.  Ablation flag 256 = never.
+        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
+        const bool want = !(g_conv_abl & 256);
+        if (can && want) return launch_conv_slab<EPI>(p, grid, s);
+    }
     const size_t lds = (size_t)C_R * C_SLOT;
     auto kern = conv_ring_kernel<EPI>;
     static bool attr_set = false;

@@ -1251,7 +1251,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             pslot = (pslot == R - 1) ? 0 : pslot + 1;
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        after_e = 2;
+        {   // the store allowance of the next phases is valid only if every store of the epilogue was issued (no M / N tail)
+            int tm_, tn_;
+            tile_coords(p, tile, tm_, tn_);
+            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 2 : 0;
+        }
         if (!has_next) break;
         tile = next;
     }
@@ -1591,7 +1595,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             sw = sw >= 3 ? sw - 3 : sw + 2;
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        after_e = 2;
+        {   // the store allowance of the next phases is valid only if every store of the epilogue was issued (no M / N tail)
+            int tm_, tn_;
+            tile_coords(p, tile, tm_, tn_);
+            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 2 : 0;
+        }
         if (!has_next) break;
         tile = next;
     }

@@ -64,9 +64,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// tanh-approximated GELU, evaluated as torch does: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))).
-// 0.5*x*(1+tanh(u)) == x * sigmoid(2u) == x / (1 + 2^(-2u*log2 e)):  2 transcendentals (v_exp_f32, v_rcp_f32),
-// ~1e-6 relative error, far below the bf16 rounding that follows in every epilogue that uses it.
+// tanh-approximated GELU, 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))) == x * sigmoid(2u) == x / (1 + 2^(-2u*log2 e)):
+// 2 transcendentals (v_exp_f32, v_rcp_f32), ~1e-6 relative error.  (A transcendental-free packed-fp32 polynomial form was
+// measured in the fc1 epilogue: no gain -- the epilogue's cost is its 16 store instructions on the VMEM path)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2*sqrt(2/pi)*log2(e)
     const float b = a * 0.044715f;

@@ -991,8 +991,15 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
                         const int col = nb + (odd ? 8 : 0);
                         if (nb_ok) {
                             __bf16* ob = reinterpret_cast<__bf16*>(p.out) + col;
-                            if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
-                            if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
+                            if constexpr (ABL & 128) {  // laboratory: everything but the global stores
+                                if ((st_even[0] ^ st_odd[1] ^ st_even[2] ^ st_odd[3]) == 0x12345678u) *reinterpret_cast<u32x4*>(ob) = st_even;
+                            } else if constexpr (ABL & 32) {  // laboratory: ordinary (write-back) stores
+                                if (m_even < p.M) *reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo) = st_even;
+                                if (m_even + 1 < p.M) *reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo) = st_odd;
+                            } else {
+                                if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
+                                if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
+                            }
                         }
                         continue;
                     }
@@ -1546,7 +1553,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
 
     int sa = 0, sw = 1;  // slots of the A and W halves of the stage being consumed
-    int after_e = 0;
+    // Epilogue stores and the in-order vmcnt: a DMA half-stage issued AFTER the stores cannot be waited for without draining
+    // them (measured: with the stores first, they had one phase to complete and cost 16 % of the kernel).  So the half-stage
+    // of the load phase that follows an epilogue is issued IN FRONT of the epilogue's stores (its slot is free: group A is
+    // already in that load phase, group B half a step before it), and the NST stores may stay in flight for the next three
+    // phases (allowances 8+NST, 4+NST, 8+NST).
+    constexpr int NST = EPI == BSI_EPI_BIAS_GELU_DUAL ? 32 : 16;
+    int after_e = 0;          // 3, 2, 1: phases after an epilogue whose stores may still be in flight
+    bool pre = false, pre_status = false;  // the next load phase's half-stage was issued in front of the epilogue
     while (true) {
         const int next = tile + wpx;
         const bool has_next = next < hi;
@@ -1556,7 +1570,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             const char* bw = lds + sw * HALF;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                // ---- L(v, ks)
+                // ---- L(v, ks): DMA issue (unless it went out in front of an epilogue), fragment reads
+                bool issued = false;
+                if constexpr (!(ABL & 1)) {
+                    if (pre) { issued = pre_status; pre = false; }
+                    else issued = issue_next();
+                }
                 {
                     const int cx = ((ks * 4 + qd) ^ xkey) << 4, cw = ((ks * 4 + qd) ^ wkey) << 4;
 #pragma unroll
@@ -1564,15 +1583,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(ba + xrow + j * 16 * RB + cx);
                 }
-                bool issued = false;
-                if constexpr (!(ABL & 1)) issued = issue_next();
                 // ks = 0 issued W(G+1): A(G+1) (issued one phase ago) may also stay in flight -> 8; ks = 1 issued A(G+2): the
-                // whole stage G+1 must have landed -> 4 (only the new one in flight).  In the first phase after an epilogue its
-                // 16 stores sit between A(G+1) and W(G+1) in issue order and may stay in flight too; one phase later W(G+1),
-                // which is younger than the stores, must have landed, so the stores must have drained as well.
+                // whole stage G+1 must have landed -> 4 (only the new one in flight); + the stores of a recent epilogue.
                 if (issued) {
-                    if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0 && ks == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                    else if (ks == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    if (BF16_OUT && after_e > 0) {
+                        if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
+                    } else if (ks == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1588,17 +1605,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                     for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
-                if (ks == 1 && v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
+                if (ks == 1 && v == nk - 1 && wm == 1) {  // group B: before the barrier that ends its last C phase
+                    if constexpr (!(ABL & 1)) { pre_status = issue_next(); pre = true; }
+                    epilogue(tile);
+                }
                 PHASE_BARRIER();
             }
             sa = sa >= 3 ? sa - 3 : sa + 2;
             sw = sw >= 3 ? sw - 3 : sw + 2;
         }
-        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        {   // the store allowance of the next phases is valid only if every store of the epilogue was issued (no M / N tail)
+        if (wm == 0) {  // group A: after that barrier, i.e. at the start of its next load phase
+            if constexpr (!(ABL & 1)) { pre_status = issue_next(); pre = true; }
+            epilogue(tile);
+        }
+        {   // the store allowance of the next phases is valid only if every store of the epilogue is issued (no M / N tail)
             int tm_, tn_;
             tile_coords(p, tile, tm_, tn_);
-            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 2 : 0;
+            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N && !(ABL & (4 | 128))) ? 3 : 0;
         }
         if (!has_next) break;
         tile = next;

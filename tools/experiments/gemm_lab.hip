@@ -201,6 +201,9 @@ int main() {
             rep("v6 no epi, no glds", time_pring<E, 5>(p, 20));
             rep("v12 full", time_k64r<E, 0>(p, 20));
             rep("v12 gelu full", time_k64r<G, 0>(p, 20));
+            rep("v12 epilogue w/o global stores", time_k64r<E, 128>(p, 20));
+            rep("v12 gelu w/o global stores", time_k64r<G, 128>(p, 20));
+            rep("v12 ordinary (wb) stores", time_k64r<E, 32>(p, 20));
             rep("v12 no epilogue", time_k64r<E, 4>(p, 20));
             rep("v12 no epi, no glds", time_k64r<E, 5>(p, 20));
             continue;

@@ -51,49 +51,81 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     const int nk = (mend - mbeg + 31) / 32;
     if (nk <= 0) return;  // uniform per workgroup
 
-    // staging: a wave-instruction covers 4 pixel rows x 256 B; wave w fills rows 4w..4w+3 of every sub-tile (5 per stage)
+    // staging: a wave-instruction covers 4 pixel rows x 256 B; wave w fills rows 4w..4w+3 of every sub-tile (5 per stage).
+    // Sources are buffer resources (X, X2, dY); a lane's byte offset is pixel*pitch + a per-lane constant (tap shift and channel
+    // of its im2col column), and anything that must read as zero -- taps outside the image, columns beyond K, pixels beyond the
+    // split -- gets an out-of-range offset, for which the LDS-DMA writes zeros (conv_igemm.hip).  The pixel's (y, x) is carried
+    // from stage to stage instead of being divided out (stages are issued in order).
+    constexpr unsigned OOB = 0xC0000000u;  // >= num_records even after adding a second OOB or a small negative constant
     const int srow = 4 * wave + (lane >> 4), spos = lane & 15;
     const int schunk = spos ^ wg_swz(srow);  // source chunk that lands at this lane's LDS position
-    const char* ubase[4];  // source tensor + channel byte offset of this lane's chunk, per unit; null = beyond Ktot
-    int upitch[4], ushift[4], udyx[4];
     const int conv_k = p.taps * p.Cin;
+    unsigned uconst[4];  // per unit: shift*pitch + channel bytes of this lane's chunk, or OOB beyond Ktot
+    int utap[4];         // per unit: border bits that invalidate this lane's tap (conv_igemm.hip: tap_mask)
+    bool lsrc2[4];       // per unit: this lane's column belongs to the second source
+    bool usrc2[4];       // per unit (wave-uniform): every column belongs to the second source
+    bool ustr[4];        // per unit (wave-uniform): the unit straddles the two sources -> one DMA instruction per source
+    int extra = 0;       // straddling units of this tile (0 or 1): DMA instructions per stage = 5 + extra
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int vc = (u0 + q) * 128 + schunk * 8;
-        ubase[q] = nullptr; upitch[q] = 0; ushift[q] = 0; udyx[q] = 0;
+        usrc2[q] = (u0 + q) * 128 >= conv_k;
+        ustr[q] = p.Cin2 > 0 && (u0 + q) * 128 < conv_k && (u0 + q) * 128 + 128 > conv_k;
+        extra += ustr[q] ? 1 : 0;
+        lsrc2[q] = vc >= conv_k;
+        uconst[q] = OOB; utap[q] = 0;
         if (vc < conv_k) {
             const int tap = vc / p.Cin, c = vc - tap * p.Cin;
             int dy = 0, dx = 0;
             if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; }
-            ubase[q] = reinterpret_cast<const char*>(p.X + c);
-            upitch[q] = p.Cin * 2;
-            ushift[q] = dy * p.Wd + dx;
-            udyx[q] = ((dy + 1) << 2) | (dx + 1);
+            uconst[q] = (unsigned)((dy * p.Wd + dx) * p.Cin * 2 + c * 2);
+            utap[q] = (dy < 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dx < 0 ? 4 : 0) | (dx > 0 ? 8 : 0);
         } else if (vc < p.Ktot) {
-            ubase[q] = reinterpret_cast<const char*>(p.X2 + (vc - conv_k));
-            upitch[q] = p.Cin2 * 2;
-            udyx[q] = (1 << 2) | 1;
+            uconst[q] = (unsigned)((vc - conv_k) * 2);
         }
     }
     const int ycol = n0 + schunk * 8;
-    const char* ybase = ycol < p.Cout ? reinterpret_cast<const char*>(p.dY + ycol) : nullptr;
-    const char* zsrc = reinterpret_cast<const char*>(p.zeros) + spos * 16;
+    const unsigned yconst = ycol < p.Cout ? (unsigned)(ycol * 2) : OOB;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X2 ? p.X2 : p.X), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dY), 0, 0x80000000u, 0x00020000);
+    // running pixel of this lane's row in the stage to issue next
+    int sm = mbeg + srow, sy, sx;
+    {
+        const int rem = sm % p.HW;
+        sy = rem / p.Wd;
+        sx = rem - sy * p.Wd;
+    }
+    const int q32 = 32 / p.Wd, r32 = 32 - q32 * p.Wd;
+    const bool small_h = p.H < q32 + 2;  // rare: more than one image per step
 
-    auto stage = [&](int v, int slot_i) {
+    auto stage = [&](int slot_i) {  // stages are issued in order: v = 0, 1, 2, ...
         char* base = lds + slot_i * G_SLOT + wave * 1024;
-        const int m = mbeg + v * 32 + srow;
-        const bool m_ok = m < mend;
-        const int rem = m % p.HW;
-        const int y = rem / p.Wd, x = rem - y * p.Wd;
+        const bool m_ok = sm < mend;
+        const int code = (sy == 0 ? 1 : 0) | (sy == p.H - 1 ? 2 : 0) | (sx == 0 ? 4 : 0) | (sx == p.Wd - 1 ? 8 : 0);
+        const unsigned mpx = m_ok ? (unsigned)sm * (unsigned)(p.Cin * 2) : OOB;
+        const unsigned mpx2 = m_ok ? (unsigned)sm * (unsigned)(p.Cin2 * 2) : OOB;
+        const unsigned mpy = m_ok ? (unsigned)sm * (unsigned)(p.ldy * 2) : OOB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int yy = y + (udyx[q] >> 2) - 1, xx = x + (udyx[q] & 3) - 1;
-            const bool ok = m_ok && ubase[q] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-            const char* src = ok ? ubase[q] + (size_t)(m + ushift[q]) * upitch[q] : zsrc;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * G_SUB), 16, 0, 0);
+            const unsigned vo = (code & utap[q]) ? OOB : (lsrc2[q] ? mpx2 : mpx) + uconst[q];
+            if (ustr[q]) {  // divergent on purpose: two instructions with complementary exec masks fill disjoint lanes
+                if (lsrc2[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
+            } else if (usrc2[q]) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
+            }
         }
-        const char* src = (m_ok && ybase) ? ybase + (size_t)m * p.ldy * 2 : zsrc;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + 4 * G_SUB), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + 4 * G_SUB), 16, mpy + yconst, 0, 0, 0);
+        // next stage: 32 pixels on
+        sm += 32;
+        sx += r32;
+        sy += q32;
+        if (sx >= p.Wd) { sx -= p.Wd; ++sy; }
+        if (small_h) sy %= p.H;
+        else if (sy >= p.H) sy -= p.H;
     };
 
     // fragments (gemm_tn.hip): lane = (q4, qp, pp): q4 = lane>>4 selects pixels 8q4..8q4+7 of the stage, qp the row inside
@@ -142,8 +174,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 
 #pragma unroll
     for (int d = 0; d < G_D; ++d)
-        if (d < nk) stage(d, d);
-    if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+        if (d < nk) stage(d);
+    extra = __builtin_amdgcn_readfirstlane(extra);
+    if (nk >= G_D && !extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+    else if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (G_D - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_BARRIER();
     if (grp == 1) WG_BARRIER();
@@ -152,8 +186,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     for (int v = 0; v < nk; ++v) {
         load_frags(lds + slot * G_SLOT);
         if (v + G_D < nk) {
-            stage(v + G_D, pslot);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+            stage(pslot);
+            if (!extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (G_D - 1)) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -243,6 +278,8 @@ extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, 
     BSI_CHECK_ARG(Cin % 8 == 0 && Cin2 % 8 == 0 && Cout % 8 == 0 && ldy % 8 == 0 && ldy >= Cout,
                   "bsi_conv_wgrad: Cin=%d Cin2=%d Cout=%d ldy=%d must be multiples of 8", Cin, Cin2, Cout, ldy);
     BSI_CHECK_ARG(Cin2 == 0 || x2, "bsi_conv_wgrad: second source missing");
+    BSI_CHECK_ARG((size_t)B * H * W * (size_t)(Cin > Cin2 ? (Cin > ldy ? Cin : ldy) : (Cin2 > ldy ? Cin2 : ldy)) * 2 < 0x7FF00000ull,
+                  "bsi_conv_wgrad: tensors exceed the 31-bit buffer offset range");
     WgParams p{};
     p.dY = reinterpret_cast<const __bf16*>(dy);
     p.X = reinterpret_cast<const __bf16*>(x);

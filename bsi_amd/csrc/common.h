@@ -85,6 +85,29 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     return s + x * s * (1.0f - s) * (2.0f * k0) * (1.0f + 3.0f * k1 * x2);
 }
 
+// 4 x 4 transpose of r[0..3] across the four 16-lane groups of a wave: afterwards lane group g holds in r[s] what lane group s
+// held in r[g].  v_permlane32_swap exchanges (vdst lanes 32..63) <-> (vsrc lanes 0..31), v_permlane16_swap exchanges
+// (vdst odd groups) <-> (vsrc even groups).
+__device__ __forceinline__ void transpose_lane_groups(f32x4 (&r)[4]) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u2v t = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 2][d]), false, false);
+            r[pr][d] = __uint_as_float(t[0]);
+            r[pr + 2][d] = __uint_as_float(t[1]);
+        }
+#pragma unroll
+    for (int pr = 0; pr < 4; pr += 2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 1][d]), false, false);
+            r[pr][d] = __uint_as_float(t[0]);
+            r[pr + 1][d] = __uint_as_float(t[1]);
+        }
+}
+
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

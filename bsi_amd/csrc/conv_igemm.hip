@@ -63,29 +63,6 @@ __device__ __forceinline__ void store_rows_dpp(__bf16* out, int ldo, int M, int 
     if (m_even + 1 < M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(dst + ldo));
 }
 
-// 4 x 4 transpose of r[0..3] across the four 16-lane groups of a wave: afterwards lane group g holds in r[s] what lane group s
-// held in r[g].  v_permlane32_swap exchanges (vdst lanes 32..63) <-> (vsrc lanes 0..31), v_permlane16_swap exchanges
-// (vdst odd groups) <-> (vsrc even groups).
-__device__ __forceinline__ void transpose_lane_groups(f32x4 (&r)[4]) {
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const u2v t = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 2][d]), false, false);
-            r[pr][d] = __uint_as_float(t[0]);
-            r[pr + 2][d] = __uint_as_float(t[1]);
-        }
-#pragma unroll
-    for (int pr = 0; pr < 4; pr += 2)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[pr][d]), __float_as_uint(r[pr + 1][d]), false, false);
-            r[pr][d] = __uint_as_float(t[0]);
-            r[pr + 1][d] = __uint_as_float(t[1]);
-        }
-}
-
 template <int EPI>
 __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;

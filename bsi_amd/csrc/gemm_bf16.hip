@@ -90,8 +90,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mw0 + 16 * j + (lane & 15);
-        if ((m >= p.M || !nb_ok) && !(EpiTraits<EPI>::out_bf16 && scratch && EPI != BSI_EPI_BIAS_GELU_DUAL &&
-                                      EPI != BSI_EPI_MUL_GELUGRAD_BF16))
+        constexpr bool F32_PLAIN = !EpiTraits<EPI>::out_bf16 && EPI != BSI_EPI_GATE_RESID;  // cross-lane exchange: every lane stays
+        if ((m >= p.M || !nb_ok) && !F32_PLAIN && !(EpiTraits<EPI>::out_bf16 && scratch && EPI != BSI_EPI_BIAS_GELU_DUAL &&
+                                                   EPI != BSI_EPI_MUL_GELUGRAD_BF16))
             continue;
         float v[16];
 #pragma unroll
@@ -167,15 +168,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 if constexpr (EPI == BSI_EPI_BIAS_POS_F32) {
                     const float* ps = p.pos + (size_t)(m % p.tokens) * p.N + nb;
 #pragma unroll
-                    for (int e = 0; e < 16; e += 4) {
+                    for (int e = 0; e < 16 && m < p.M && nb_ok; e += 4) {
                         const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + e);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[e + r] += pv[r];
                     }
                 }
+                // fp32 rows: 4 x 4 transpose across the four 16-lane groups, so that the 4 lanes of a row write 64 contiguous
+                // bytes per store instruction instead of four 16-B pieces 64 B apart (the skip-convolution input gradient of the
+                // UNet, M x 256 x 128, ran at 0.7 TB/s of fp32 output with the scattered non-temporal pieces)
+                f32x4 r4[4];
 #pragma unroll
-                for (int e = 0; e < 16; e += 4)
-                    __builtin_nontemporal_store(f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]}, reinterpret_cast<f32x4*>(o + e));
+                for (int e = 0; e < 4; ++e) r4[e] = f32x4{v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]};
+                transpose_lane_groups(r4);
+                if (m < p.M) {
+                    const int col = nw0 + 4 * (lane >> 4);
+                    float* ot = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        if (col + 16 * s4 < p.N) *reinterpret_cast<f32x4*>(ot + 16 * s4) = r4[s4];
+                }
             }
         }
     }

@@ -235,10 +235,15 @@ void plan(WgParams& p) {
     p.tiles_u = (p.Ktot + 511) / 512;
     p.tiles_n = (p.Cout + 127) / 128;
     const int tiles = p.tiles_u * p.tiles_n;
-    int s = (g_wg_cus + tiles - 1) / tiles;
     const int max_s = (p.M + 255) / 256;  // at least 8 stages per split
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
+    // one workgroup per CU at a time (160 KB of LDS): time ~ rounds(s) / s with rounds = ceil(tiles * s / CUs); the smallest s
+    // among the best (rounding CUs / tiles UP gave 3 x 86 = 258 workgroups = two rounds for the 128 -> 128 convolution)
+    int s = 1;
+    double best_t = 1e30;
+    for (int c = 1; c <= g_wg_cus && c <= max_s; ++c) {
+        const double t = (double)((tiles * c + g_wg_cus - 1) / g_wg_cus) / c;
+        if (t < best_t * 0.97) { best_t = t; s = c; }  // more splits only for a real gain: every split is a slab to write and reduce
+    }
     int mps = (p.M + s - 1) / s;
     mps = (mps + 31) / 32 * 32;
     p.m_per_split = mps;

@@ -290,11 +290,16 @@ extern "C" size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K) {
 
 static int tn_splits(int M, int N, int K, int num_cus) {
     const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
-    int s = (num_cus + tiles - 1) / tiles;
-    if (s > 16) s = 16;
     const int max_by_m = M / 512 > 0 ? M / 512 : 1;  // keep at least 16 K steps per workgroup
-    if (s > max_by_m) s = max_by_m;
-    return s < 1 ? 1 : s;
+    // one workgroup per CU at a time (160 KB of LDS): time ~ rounds(s) / s with rounds = ceil(tiles * s / CUs); the smallest s
+    // among the best (rounding num_cus / tiles UP put the qkv weight gradient, 48 tiles, into 288 workgroups = two rounds)
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 16 && s <= max_by_m; ++s) {
+        const double t = (double)((tiles * s + num_cus - 1) / num_cus) / s;
+        if (t < best_t * 0.9) { best_t = t; best = s; }  // more splits only for a real gain: every split is a slab to write and reduce
+    }
+    return best;
 }
 
 static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc, float* colsum_out,

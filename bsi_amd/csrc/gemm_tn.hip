@@ -222,6 +222,48 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, size_t slab
     }
 }
 
+// Same sum for many slabs of a small tensor (conv weight gradients: 85 slabs of 147k floats): one output per thread would
+// leave most CUs idle behind 85 dependent-latency loads, so 4 threads share an output (slabs s = g, g+4, ... each, 4 loads in
+// flight) and their partial sums are added in fixed order through LDS -- still deterministic.
+__global__ __launch_bounds__(256) void reduce_slabs_par_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits, size_t n4,
+                                                               int accumulate, float* __restrict__ out) {
+    __shared__ f32x4 part[3][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + o;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = g;
+        for (; s + 12 < splits; s += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 4 * u) * slab_stride) + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += v[u][e];
+        }
+        for (; s < splits; s += 4) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slabs + (size_t)s * slab_stride) + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+    }
+    if (g > 0) part[g - 1][o] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += part[k][o][e];
+        if (accumulate) {
+            const f32x4 prev = reinterpret_cast<const f32x4*>(out)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += prev[e];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = a;
+    }
+}
+
 // column sums of a bf16 [M, ld] matrix (bias gradients): out[n] (+)= sum_m Y[m, n].
 // A block owns a 256-column strip and a row range: 32 threads x 16 B cover the strip, 8 row lanes run in parallel and
 // each walks its rows with 4 independent 16-B loads in flight; partial sums go to a slab per row split and are summed
@@ -275,6 +317,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out,
                             hipStream_t s) {
     const size_t n4 = n / 4;
+    if (splits >= 8 && n4 <= (size_t)256 * 1024) {  // few outputs, many slabs: 4 threads per output
+        hipLaunchKernelGGL(reduce_slabs_par_kernel, dim3((int)((n4 + 63) / 64)), dim3(256), 0, s, slabs, slab_stride, splits, n4, accumulate, out);
+        BSI_CHECK_LAUNCH("bsi_reduce_slabs");
+        return BSI_OK;
+    }
     size_t g = (n4 + 255) / 256;
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;

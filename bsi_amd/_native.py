@@ -181,6 +181,7 @@ _PROTOS = {
     "bsi_conv_weight_pack_t": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "bsi_conv_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "bsi_conv_wgrad_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "bsi_conv_wgrad_bias_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "bsi_conv_wgrad_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "bsi_groupnorm_bwd_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -25,6 +25,7 @@ struct WgParams {
     const __bf16* X2;     // [M, Cin2] or null
     const __bf16* zeros;  // >= 256 B of zeros
     float* out;           // [splits][Cout][Ktot]
+    float* colsum;        // optional [splits][Cout]: column sums of dY (bias gradient), written by the first unit tile's workgroups
     int M, H, Wd, HW, Cin, Cin2, taps, Cout, ldy, Ktot;
     int tiles_u, tiles_n, splits, m_per_split;
     size_t slab_stride;
@@ -143,6 +144,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4], bf[8];
+    // fused bias gradient (gemm_tn.hip): column sums of the dY tile = one extra MFMA per stage with an all-ones A operand
+    // (pixels beyond the split are zero rows already); wave w takes output channels 16w .. 16w+15 of the tile
+    const bool do_colsum = p.colsum != nullptr && (tile % p.tiles_u) == 0;
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 onesf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) onesf[e] = (__bf16)1.0f;
 
 #define WG_BARRIER()                             \
     do {                                         \
@@ -200,6 +208,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (do_colsum) {
+            bf16x8 bsel = bf[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) bsel = wave == j ? bf[j] : bsel;
+            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bsel, accb, 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         WG_BARRIER();
         slot = (slot == G_R - 1) ? 0 : slot + 1;
@@ -209,6 +223,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 #undef WG_BARRIER
 #undef TR
 
+    if (do_colsum && lane < 16) {  // D row 0 (lanes 0..15, register 0) holds the column sums
+        const int n = n0 + 16 * wave + lane;
+        if (n < p.Cout) p.colsum[(size_t)split * p.Cout + n] = accb[0];
+    }
     // D rows = im2col column (4*(lane>>4) + reg inside slice tile i), D cols = output channel (lane & 15 inside tile j)
     float* out = p.out + (size_t)split * p.slab_stride;
 #pragma unroll
@@ -272,12 +290,12 @@ extern "C" size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int C
     WgParams p{};
     p.M = M; p.Cin = Cin; p.Cin2 = Cin2; p.Cout = Cout; p.taps = taps; p.Ktot = taps * Cin + Cin2;
     plan(p);
-    return (size_t)p.splits * p.slab_stride * sizeof(float);
+    return (size_t)p.splits * p.slab_stride * sizeof(float) + (size_t)p.splits * (size_t)Cout * sizeof(float);  // + bias-gradient slabs
 }
 
-extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B,
-                                        int H, int W, int Cin, int Cin2, int Cout, int taps, float* out_packed, int accumulate,
-                                        void* workspace, bsi_stream_t stream) {
+static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W, int Cin,
+                           int Cin2, int Cout, int taps, float* out_packed, float* dbias, int accumulate, void* workspace,
+                           bsi_stream_t stream) {
     BSI_CHECK_ARG(dy && x && zeros && out_packed && workspace, "bsi_conv_wgrad: null pointer");
     BSI_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 9 || taps == 1), "bsi_conv_wgrad: bad sizes");
     BSI_CHECK_ARG(Cin % 8 == 0 && Cin2 % 8 == 0 && Cout % 8 == 0 && ldy % 8 == 0 && ldy >= Cout,
@@ -301,9 +319,27 @@ extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, 
                                   G_R * G_SLOT);
         attr_set = true;
     }
+    p.colsum = dbias ? p.out + (size_t)p.splits * p.slab_stride : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_u * p.splits), dim3(512), G_R * G_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");
+    if (dbias) {
+        const int rc = bsi_reduce_slabs_launch(p.colsum, (size_t)Cout, p.splits, (size_t)Cout, accumulate, dbias, s);
+        if (rc != BSI_OK) return rc;
+    }
     return bsi_reduce_slabs_launch(p.out, p.slab_stride, p.splits, p.slab_stride, accumulate, out_packed, s);
+}
+
+extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B,
+                                        int H, int W, int Cin, int Cin2, int Cout, int taps, float* out_packed, int accumulate,
+                                        void* workspace, bsi_stream_t stream) {
+    return conv_wgrad_impl(dy, ldy, x, x2, zeros, B, H, W, Cin, Cin2, Cout, taps, out_packed, nullptr, accumulate, workspace, stream);
+}
+
+extern "C" int bsi_conv_wgrad_bias_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B,
+                                             int H, int W, int Cin, int Cin2, int Cout, int taps, float* out_packed, float* dbias,
+                                             int accumulate, void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dbias && Cout % 4 == 0, "bsi_conv_wgrad_bias: bias gradient pointer missing or Cout %% 4");
+    return conv_wgrad_impl(dy, ldy, x, x2, zeros, B, H, W, Cin, Cin2, Cout, taps, out_packed, dbias, accumulate, workspace, stream);
 }
 
 extern "C" int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int cin_pad, int ld, int col0,

@@ -365,6 +365,11 @@ size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int Cout, int ta
 int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
                              int Cin, int Cin2, int Cout, int taps, float* out_packed, int accumulate, void* workspace,
                              bsi_stream_t stream);
+/* Same, plus the bias gradient dbias[co] (+)= sum_m dY[m, co] from one extra MFMA per stage (all-ones operand) in the same
+ * kernel: autograd of nn.Conv2d w.r.t. bias without a second pass over dY. */
+int bsi_conv_wgrad_bias_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
+                                  int Cin, int Cin2, int Cout, int taps, float* out_packed, float* dbias, int accumulate,
+                                  void* workspace, bsi_stream_t stream);
 int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int cin_pad, int ld, int col0, int accumulate,
                           float* out, bsi_stream_t stream);
 /* GroupNorm(32 groups, affine, eps) over cat(x1, x2) channels (x2 nullable) per image, optional SiLU -> bf16 NHWC

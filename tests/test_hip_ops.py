@@ -577,6 +577,14 @@ def test_conv_weight_and_input_gradients(N, B, H, W, Cin, Cin2, Cout, taps):
         gw2 = empty(Cout, Cin2, 1, 1)
         N.check(lib.bsi_conv_wgrad_unpack(N.ptr(packed), Cout, Cin2, 1, Cin2, K, taps * Cin, 0, N.ptr(gw2), N.stream()))
         assert rel_linf(gw2, w2.grad) < 2e-5
+    # fused bias gradient: dbias[co] = sum over pixels of dY (autograd of the conv bias), same weight gradient
+    if Cout % 4 == 0:
+        packed_b, dbias = empty(Cout, K), empty(Cout)
+        N.check(lib.bsi_conv_wgrad_bias_nhwc_bf16(N.ptr(dyd), Cout, N.ptr(xd), N.ptr(x2d) if Cin2 else None, N.ptr(zeros), B, H, W, Cin,
+                                                  Cin2, Cout, taps, N.ptr(packed_b), N.ptr(dbias), 0, N.ptr(ws), N.stream()))
+        assert torch.equal(packed_b.cpu(), packed.cpu())
+        want_b = dyd.cpu().double().sum(0)
+        assert rel_linf(dbias, want_b) < 2e-5, rel_linf(dbias, want_b)
     # accumulate flag
     N.check(lib.bsi_conv_wgrad_nhwc_bf16(N.ptr(dyd), Cout, N.ptr(xd), N.ptr(x2d) if Cin2 else None, N.ptr(zeros), B, H, W, Cin,
                                          Cin2, Cout, taps, N.ptr(packed), 1, N.ptr(ws), N.stream()))

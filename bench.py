@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU per sample() call")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call")
     ap.add_argument("--k", type=int, default=128, help="sampling steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")

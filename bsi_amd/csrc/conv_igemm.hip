@@ -341,7 +341,6 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;
     constexpr bool BF16_OUT = (EPI != CEPI_BIAS_RESID_F32);
     constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM;
-    static_assert(EPI != CEPI_FILM_SILU_BF16, "FILM epilogue lives in conv_ring_kernel");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -456,15 +455,36 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         if (nb0 >= p.N) return;
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
+            // FiLM + SiLU (residual_block.py:21-24,44-46): y*(scale+1)+shift per (image, channel).  The wave's 128 rows lie in ONE
+            // image (launcher: H*W % 128 == 0), so the 2 x 16 coefficients of this lane's columns are loaded once per tile.
+            f32x4 fsc[4], fsh[4];
+            if constexpr (EPI == CEPI_FILM_SILU_BF16) {
+                int m0w = mw0 < p.M ? mw0 : p.M - 1;
+                const float* fr = p.film + (size_t)((m0w / HW) % p.film_rows) * p.film_stride + nb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fsc[i] = *reinterpret_cast<const f32x4*>(fr + 4 * i);
+                    fsh[i] = *reinterpret_cast<const f32x4*>(fr + p.N + 4 * i);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fsc[i][r] += 1.0f;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
+                f32x4 v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+                if constexpr (EPI == CEPI_FILM_SILU_BF16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[i][r] = silu_f(__fmaf_rn(fsc[i][r], v[i][r], fsh[i][r]));
+                }
                 u32x4 w0, w1;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    w0[e] = pack_bf16x2(acc[0][j][2 * e], acc[0][j][2 * e + 1]);
-                    w0[2 + e] = pack_bf16x2(acc[1][j][2 * e], acc[1][j][2 * e + 1]);
-                    w1[e] = pack_bf16x2(acc[2][j][2 * e], acc[2][j][2 * e + 1]);
-                    w1[2 + e] = pack_bf16x2(acc[3][j][2 * e], acc[3][j][2 * e + 1]);
+                    w0[e] = pack_bf16x2(v[0][2 * e], v[0][2 * e + 1]);
+                    w0[2 + e] = pack_bf16x2(v[1][2 * e], v[1][2 * e + 1]);
+                    w1[e] = pack_bf16x2(v[2][2 * e], v[2][2 * e + 1]);
+                    w1[2 + e] = pack_bf16x2(v[3][2 * e], v[3][2 * e + 1]);
                 }
                 store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
             }
@@ -641,13 +661,14 @@ int launch_conv(ConvParams p, hipStream_t s) {
     p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < conv_cus() ? nwg : conv_cus();
-    if constexpr (EPI != CEPI_FILM_SILU_BF16) {
+    {
         // 3x3 without folded skip steps on images whose rows are whole fragments run the slab kernel.  Measured on one MI355X
         // (tools/conv_bench.py, 128 / 512 images): fp32-output epilogue 71 / 317 us against 84 / 349 us for the ring kernel (its
         // stores get five phases to drain instead of two), 256 -> 128 channels bf16 93 / 336 against 94 / 341, 128 -> 128 bf16
         // 57 / 214 against 50 / 189 (longer load phase: tap address arithmetic); UNet sampling at 256 images: 510 images/s (k=16)
         // with the slab kernel wherever possible, 505 with it for fp32 outputs only, 497 without it.  Ablation flag 256 = never.
-        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
+        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0 &&
+                         (EPI != CEPI_FILM_SILU_BF16 || (p.H * p.Wd) % 128 == 0);  // FiLM: a wave's 128 rows within one image
         const bool want = !(g_conv_abl & 256);
         if (can && want) return launch_conv_slab<EPI>(p, grid, s);
     }

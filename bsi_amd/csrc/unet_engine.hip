@@ -1,6 +1,8 @@
 // Host-side sequencing of one DenoisingVDMUNet evaluation (bsi/models/vdm_unet.py:92-100,
 // bsi/nn/simplified_unet.py:33-48, bsi/nn/residual_block.py:61-64 of the reference) on a HIP stream.
 // No allocation, no synchronisation: the caller owns the workspace.  Activations are NHWC.
+#include <stdlib.h>
+
 #include "common.h"
 #include "dit_ops.h"
 #include "unet_ops.h"
@@ -148,11 +150,17 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
         const int cin2 = x2 ? dim : 0;
         TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, ws.a, x2 ? ws.raw : nullptr, stream));
-        // conv1 -> bf16, then FiLM + SiLU in one HBM pass: faster than the fused FiLM epilogue, whose per-row (scale, shift)
-        // loads push the 512 x 128 tile kernel over its register budget (measured 390 vs 162 + 30 us at 256 images)
-        TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.h1, nullptr, 0, 0, nullptr, B, H, W, dim + cin2, 0, dim, 9,
-                 BSI_CONV_BIAS_BF16, stream));
-        TRY(bsi_film_silu_drop(ws.h1, (int)d.M, dim, d.HW, film + (size_t)blk * 2 * dim, film_rows, fstride, DropCfg{}, ws.y, stream));
+        // conv1 with the FiLM + SiLU epilogue of the slab kernel (one image per wave: the (scale, shift) coefficients are loaded once
+        // per tile); BSI_UNET_SPLIT_FILM=1 keeps conv1 -> bf16 + a separate FiLM/SiLU pass for comparison
+        static const bool split_film = getenv("BSI_UNET_SPLIT_FILM") != nullptr;
+        if (split_film || d.HW % 128 != 0) {
+            TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.h1, nullptr, 0, 0, nullptr, B, H, W, dim + cin2, 0, dim, 9,
+                     BSI_CONV_BIAS_BF16, stream));
+            TRY(bsi_film_silu_drop(ws.h1, (int)d.M, dim, d.HW, film + (size_t)blk * 2 * dim, film_rows, fstride, DropCfg{}, ws.y, stream));
+        } else {
+            TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.y, film + (size_t)blk * 2 * dim, film_rows, fstride, nullptr, B, H, W,
+                     dim + cin2, 0, dim, 9, BSI_CONV_FILM_SILU_BF16, stream));
+        }
         // conv2 (+ the 1x1 skip conv of cat(x, x_skip) folded in as extra K steps; its bias is folded into conv2_b)
         return conv(ws.y, x2 ? ws.raw : nullptr, rb.conv2_w, rb.conv2_b, ws.zeros, dst, nullptr, 0, 0, x2 ? nullptr : x1, B, H, W, dim,
                     x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream);

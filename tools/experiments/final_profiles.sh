@@ -5,7 +5,7 @@ O=gpurun_out/final; mkdir -p $O
 # PMC traffic of the dominant kernel first (bench.py reads profiles/fc1_traffic.json): two separate --pmc passes, k=4
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --k 4 --steps 1 --warmup 1 --train-steps 0 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --k 4 --steps 1 --warmup 1 --train-steps 0 --no-cpu-baseline > /dev/null 2>&1
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 'gemm_bf16_k64r_kernel<2, 0>' $O/fc1_traffic.json 128 && cp $O/fc1_traffic.json profiles/fc1_traffic.json
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 'gemm_bf16_k64r_kernel<2, 0>' $O/fc1_traffic.json 256 && cp $O/fc1_traffic.json profiles/fc1_traffic.json
 rm -rf $O/pmc_fetch $O/pmc_write
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-400 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -- python3 bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.json 2>/dev/null

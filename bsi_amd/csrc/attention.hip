@@ -26,6 +26,24 @@ __device__ __forceinline__ int v_block_swz(int row, int blk) {  // 32-B block in
     else return blk ^ (row & 7);
 }
 
+// max / sum over the four 16-lane groups of a wave (lanes c, c+16, c+32, c+48) without LDS: the gfx950 lane-group swaps
+// (v_permlane16_swap: odd groups of a <-> even groups of b; v_permlane32_swap: upper half of a <-> lower half of b) applied
+// to two copies of the value leave "mine" in one result and "the partner group's" in the other.
+__device__ __forceinline__ float lane_group_max(float v) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+__device__ __forceinline__ float lane_group_sum(float v) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
 template <int DH, int KC, bool DROP>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
                                                             int heads, __bf16* __restrict__ out, int ld_out,
@@ -110,26 +128,29 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][jq][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = lane_group_max(mx);
             const float m_new = fmaxf(m_run[jq], mx);
             alpha[jq] = __builtin_amdgcn_exp2f((m_run[jq] - m_new) * scale_log2e);
             m_run[jq] = m_new;
             const float mb = m_new * scale_log2e;
-            float ps = 0.f;
+            f32x2 ps2 = {0.f, 0.f};  // two partial sums on the packed fp32 pipe
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], scale_log2e, -mb));
-                    ps += pv;  // the normaliser uses the undropped probabilities
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 arg = __builtin_elementwise_fma(f32x2{s[kt][jq][r], s[kt][jq][r + 1]}, f32x2{scale_log2e, scale_log2e},
+                                                                f32x2{-mb, -mb});
+                    f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                    ps2 += pv;  // the normaliser uses the undropped probabilities
                     if constexpr (DROP) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only:
                         // element (row = (b, h, query), column = key)
-                        pv = drop_keep_rc(dc, rowh[jq], kc0 + 16 * kt + 4 * g + r) ? pv * dc.scale : 0.0f;
+                        pv[0] = drop_keep_rc(dc, rowh[jq], kc0 + 16 * kt + 4 * g + r) ? pv[0] * dc.scale : 0.0f;
+                        pv[1] = drop_keep_rc(dc, rowh[jq], kc0 + 16 * kt + 4 * g + r + 1) ? pv[1] * dc.scale : 0.0f;
                     }
-                    s[kt][jq][r] = pv;
+                    s[kt][jq][r] = pv[0];
+                    s[kt][jq][r + 1] = pv[1];
                 }
-            l_run[jq] = l_run[jq] * alpha[jq] + ps;
+            l_run[jq] = l_run[jq] * alpha[jq] + (ps2[0] + ps2[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -177,8 +198,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
         float l = l_run[jq];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = lane_group_sum(l);
         const float inv = 1.0f / l;
         // log-sum-exp of the scaled scores (natural log), saved for the backward pass
         if (lse && g == 0) lse[(size_t)bh * tokens + q0 + 16 * jq + c16] = (m_run[jq] * scale_log2e + __log2f(l)) * 0.6931471805599453f;

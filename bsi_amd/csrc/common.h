@@ -108,6 +108,8 @@ __device__ __forceinline__ void transpose_lane_groups(f32x4 (&r)[4]) {
         }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

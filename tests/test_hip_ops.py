@@ -265,6 +265,44 @@ def test_gemm_epilogues(N, M, Nn, K):
     assert rel_linf(o, ref + pos[torch.arange(M) % tokens].double()) < 2e-5
 
 
+@pytest.mark.parametrize("epi_name", ["bias", "gelu"])
+def test_gemm_persistent_tile_handover_full_size(N, epi_name):
+    """768 tiles on 256 CUs: every persistent workgroup walks 3 tiles, so the DMA ring, the epilogue's store allowance and the
+    half-stage issued in front of the epilogue are exercised across tile boundaries.  Production schedule (variant 12) against
+    the K = 32 ring (variant 6) on the whole output, and against fp64 on sampled rows."""
+    M, Nn, K = 16384, 3072, 1024
+    gen = torch.Generator().manual_seed(11)
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Nn, generator=gen)
+    dA, dW, db = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias)
+    epi = N.EPI_BIAS_BF16 if epi_name == "bias" else N.EPI_BIAS_GELU_BF16
+    outs = {}
+    try:
+        for variant in (12, 6):
+            N.check(N.lib().bsi_gemm_set_variant(variant))
+            for rep in range(2):  # twice: a race would rarely repeat identically
+                out = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+                a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K,
+                               ldo=Nn, epilogue=epi)
+                N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+                torch.cuda.synchronize()
+                if rep:
+                    assert torch.equal(out, outs[variant]), f"variant {variant} is not reproducible"
+                outs[variant] = out
+    finally:
+        N.check(N.lib().bsi_gemm_set_variant(12))
+    o12, o6 = outs[12].float(), outs[6].float()
+    assert bool(torch.isfinite(o12).all())
+    # the two schedules differ only in where the bias joins the fp32 sum: at most a bf16 ulp apart
+    assert float(((o12 - o6).abs() / (o6.abs() + 0.05)).max()) < 1.6e-2
+    rows = torch.randint(0, M, (192,), generator=gen)
+    ref = A[rows].double() @ W.double().t() + bias.double()
+    if epi_name == "gelu":
+        ref = do.gelu_tanh(ref)
+    assert rel_linf(o12[rows.to(DEV)].cpu(), ref) < 5e-3
+
+
 def test_gemm_rejects_bad_shapes(N):
     a = N.GemmArgs(A=1, W=1, out=1, M=4, N=24, K=64, lda=64, ldw=64, ldo=24, epilogue=0)
     assert N.lib().bsi_gemm_bf16(C.byref(a), None) == -1
@@ -517,6 +555,54 @@ def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
         N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
         want = _nhwc(ref).reshape(-1, Cout) + (res.double() if res is not None else 0)
         assert rel_linf(out, want) < 3e-5, rel_linf(out, want)
+
+
+@pytest.mark.parametrize("epi_name", ["bias", "resid"])
+def test_conv_full_size_slab_against_ring(N, epi_name):
+    """256 images (512 tiles on 256 CUs, two per persistent workgroup) at the UNet's up-block shape 256 -> 128: the pixel-slab
+    kernel against the ring kernel on the whole output, each run twice (reproducible), and against fp64 on one image."""
+    B, H, Cin, Cout = 256, 32, 256, 128
+    gen = torch.Generator().manual_seed(5)
+    M, K = B * H * H, 9 * Cin
+    x = torch.randn((M, Cin), generator=gen).to(torch.bfloat16)
+    w = bf16r(torch.randn((Cout, Cin, 3, 3), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Cout, generator=gen)
+    xd, bd = dev(x), dev(bias)
+    wp = empty(Cout, K, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w)), Cout, Cin, 9, Cin, K, 0, N.ptr(wp), N.stream()))
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    f32 = epi_name == "resid"
+    res = dev(torch.randn((M, Cout), generator=gen)) if f32 else None
+    outs = {}
+    try:
+        for abl in (0, 256):  # 0 = slab kernel, 256 = ring kernel
+            N.check(N.lib().bsi_conv_set_ablation(abl))
+            for rep in range(2):
+                out = torch.full((M, Cout), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+                a = N.ConvArgs(x=xd.data_ptr(), w=wp.data_ptr(), bias=bd.data_ptr(), zeros=zeros.data_ptr(), B=B, H=H, W=H, Cin=Cin, Cin2=0,
+                               Cout=Cout, taps=9, ldo=Cout, out=out.data_ptr(),
+                               epilogue=N.CONV_BIAS_RESID_F32 if f32 else N.CONV_BIAS_BF16)
+                if f32:
+                    a.resid = res.data_ptr()
+                N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+                torch.cuda.synchronize()
+                if rep:
+                    assert torch.equal(out, outs[abl]), f"kernel choice {abl} is not reproducible"
+                outs[abl] = out
+    finally:
+        N.check(N.lib().bsi_conv_set_ablation(0))
+    a0, a1 = outs[0].float(), outs[256].float()
+    assert bool(torch.isfinite(a0).all())
+    # different fp32 summation orders (chunk-major vs tap-major K), bf16 rounding on top for the bf16 epilogue
+    tol = 2e-5 if f32 else 1.6e-2
+    assert float(((a0 - a1).abs() / (a1.abs() + 0.05)).max()) < tol * (1 if not f32 else 50)
+    img = 171  # one image against fp64 (second tile of a workgroup)
+    xi = x[img * H * H:(img + 1) * H * H].double().reshape(1, H, H, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xi, w.double(), bias.double(), padding=1)
+    ref = _nhwc(ref).reshape(-1, Cout)
+    if f32:
+        ref = ref + res[img * H * H:(img + 1) * H * H].cpu().double()
+    assert rel_linf(a0[img * H * H:(img + 1) * H * H].cpu(), ref) < (3e-5 if f32 else 5e-3)
 
 
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(3, 64, 64, 0, 1), (2, 1024, 128, 0, 1), (2, 1024, 128, 128, 1), (2, 1024, 128, 0, 0)])

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
                                                              float eps, int silu, const float* __restrict__ add,
                                                              const float* __restrict__ add_b, float* __restrict__ out1,
                                                              float* __restrict__ out2, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta) {
+                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf) {
     __shared__ float red_s[512], red_q[512];
     __shared__ float red_g[1024], red_b[1024];  // [pixel row][channel of the slice]
     __shared__ float mean_s[16], rstd_s[16], m1_s[16], m2_s[16];
@@ -227,6 +227,12 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
             for (int k = 0; k < 4; ++k) o[k] += a4[k];
         }
         *reinterpret_cast<f32x4*>(dst + (size_t)p * sstride) = o;
+        if (out1_bf && !second) {  // bf16 copy of the x1 gradient: the next block's convolutions take it as their dY operand
+            u32x2 w2;
+            w2[0] = pack_bf16x2(o[0], o[1]);
+            w2[1] = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<u32x2*>(out1_bf + ((size_t)b * HW + p) * C1 + c0) = w2;
+        }
     }
 }
 
@@ -324,18 +330,32 @@ extern "C" int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, i
                                   dfilm_stride, stream);
 }
 
-extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
-                                      const float* gamma, const float* beta, float eps, int silu, const float* add,
-                                      const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
-                                      bsi_stream_t stream) {
+static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                              const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1, float* out2,
+                              float* dgamma, float* dbeta, void* out1_bf16, bsi_stream_t stream) {
     BSI_CHECK_ARG(da && x1 && gamma && beta && out1 && dgamma && dbeta && B > 0 && HW > 0, "bsi_groupnorm_bwd_nhwc: bad args");
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
     hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
-                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta);
+                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16));
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
     return BSI_OK;
+}
+
+extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
+                                      const float* gamma, const float* beta, float eps, int silu, const float* add,
+                                      const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
+                                      bsi_stream_t stream) {
+    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, nullptr, stream);
+}
+
+extern "C" int bsi_groupnorm_bwd_cast_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
+                                           const float* gamma, const float* beta, float eps, int silu, const float* add,
+                                           const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
+                                           void* out1_bf16, bsi_stream_t stream) {
+    BSI_CHECK_ARG(out1_bf16, "bsi_groupnorm_bwd_cast_nhwc: bf16 output missing");
+    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, out1_bf16, stream);
 }
 
 extern "C" int bsi_unet_decode_bwd(const float* g_xhat, const float* c_out, int coef_stride, const float* h, int B, int HW, int C,

@@ -293,6 +293,8 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
     }
 
     // residual block backward: dOut fp32 [M, dim] -> out1 (gradient of x1, + add_b) and out2 (gradient of the skip tensor x2)
+    // `g_ready`: ws.g already holds the bf16 copy of dOut (written by the GroupNorm backward that produced dOut)
+    bool g_ready = false;
     auto resblock_bwd = [&](int blk, const float* dOut, const float* x1, const float* x2, const float* add_b, float* out1,
                             float* out2) -> int {
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
@@ -300,7 +302,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         const bsi_unet_resblock_grads& rg = g->blocks[blk];
         BlockTape bt = block_tape(tp, d, blk);
         const int cin2 = x2 ? dim : 0, cx = dim + cin2;
-        TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));  // bf16 copy of dOut
+        if (!g_ready) TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));  // bf16 copy of dOut
         TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, bt.y, x2 ? bt.raw : nullptr, tp.zeros, B, H, W, dim, x2 ? 2 * dim : 0, dim, 9,
                                           rg.conv2_w, rg.conv2_b, 0, ws.wg, stream));
         TRY(conv(ws.g, nullptr, rT.conv2_wT, nullptr, tp.zeros, ws.dy, nullptr, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
@@ -315,8 +317,10 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
             add = ws.dcat;
         }
         (void)rb;
-        return bsi_groupnorm_bwd_nhwc(ws.da, x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, add, add_b, out1, out2, rg.gn_w,
-                                      rg.gn_b, stream);
+        // out1 is the next block's dOut: its bf16 copy goes straight into ws.g (no longer read by this block)
+        g_ready = true;
+        return bsi_groupnorm_bwd_cast_nhwc(ws.da, x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, add, add_b, out1, out2, rg.gn_w,
+                                           rg.gn_b, ws.g, stream);
     };
 
     int cur = 0;
@@ -334,15 +338,16 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
     {   // Residual(GroupNorm -> Attention2D) (vdm_unet.py:83-87)
         const float* dOut = ws.dcur[cur];
         const float* hin = block_tape(tp, d, L).out;
-        TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));
+        if (!g_ready) TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));
         TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, tp.ay, nullptr, tp.zeros, B, H, W, dim, 0, dim, 9, g->aout_w, g->aout_b, 0, ws.wg, stream));
         TRY(conv(ws.g, nullptr, wT->aout_wT, nullptr, tp.zeros, ws.dy, nullptr, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_attention_bwd_long(tp.qkv, 3 * dim, tp.ay, ws.dy, dim, tp.lse, B, d.HW, cfg->heads, d.dh, ws.dqkv, 3 * dim, stream));
         TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.dqkv, 3 * dim, tp.agn, nullptr, tp.zeros, B, H, W, dim, 0, 3 * dim, 9, g->aqkv_w, g->aqkv_b, 0,
                                           ws.wg, stream));
         TRY(conv(ws.dqkv, nullptr, wT->aqkv_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, 3 * dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
-        TRY(bsi_groupnorm_bwd_nhwc(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
-                                   nullptr, g->agn_w, g->agn_b, stream));
+        TRY(bsi_groupnorm_bwd_cast_nhwc(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
+                                        nullptr, g->agn_w, g->agn_b, ws.g, stream));
+        g_ready = true;
         cur ^= 1;
     }
     // centre block 0 and the down path: the output of down block i is also the skip tensor of up block L-1-i
@@ -355,7 +360,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         cur ^= 1;
     }
     // encode convolution (vdm_unet.py:71,99)
-    TRY(bsi_silu_bwd_bf16(ws.dcur[cur], nullptr, (size_t)M * dim, ws.g, stream));
+    if (!g_ready) TRY(bsi_silu_bwd_bf16(ws.dcur[cur], nullptr, (size_t)M * dim, ws.g, stream));
     TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, tp.xin, nullptr, tp.zeros, B, H, W, d.cin_pad, 0, dim, 9, g->enc_w, g->enc_b, 0, ws.wg, stream));
 
     // FiLM projections and pos_map (rows = samples)

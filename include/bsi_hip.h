@@ -382,6 +382,11 @@ int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, 
 int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
                            const float* gamma, const float* beta, float eps, int silu, const float* add, const float* add_b,
                            float* out1, float* out2, float* dgamma, float* dbeta, bsi_stream_t stream);
+/* Same, and also writes the x1 gradient as bf16 [B*HW, C1] (the dY operand of the next block's weight / input gradient
+ * convolutions: saves a separate fp32 -> bf16 pass over it). */
+int bsi_groupnorm_bwd_cast_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                                const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1,
+                                float* out2, float* dgamma, float* dbeta, void* out1_bf16, bsi_stream_t stream);
 /* Training form of the FiLM stage (residual_block.py:21-24,44-46): y = Dropout_p(SiLU(h1*(scale+1)+shift)), h1 and y bf16
  * [M, N], film fp32 rows (scale at [0,N), shift at [N,2N)) selected by (m / HW) % film_rows; the dropout mask is the
  * counter hash of (seed, site, row m, column n) (bsi_dropout_mask exports the same mask).  _bwd: dh1 = bf16(dU*(scale+1)) with

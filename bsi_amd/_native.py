@@ -184,8 +184,9 @@ _PROTOS = {
     "bsi_conv_wgrad_bias_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "bsi_conv_wgrad_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "bsi_groupnorm_stats_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "bsi_groupnorm_bwd_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "bsi_groupnorm_bwd_cast_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bsi_groupnorm_bwd_cast_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bsi_film_silu": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "bsi_film_silu_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp, _i, _vp]),
     "bsi_unet_decode_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
                                                              float eps, int silu, const float* __restrict__ add,
                                                              const float* __restrict__ add_b, float* __restrict__ out1,
                                                              float* __restrict__ out2, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf) {
+                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf, const float* __restrict__ stats) {
     __shared__ float red_s[512], red_q[512];
     __shared__ float red_g[1024], red_b[1024];  // [pixel row][channel of the slice]
     __shared__ float mean_s[16], rstd_s[16], m1_s[16], m2_s[16];
@@ -125,31 +125,40 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
     const float* src = second ? x2 + (size_t)b * HW * C2 + (c0 - C1) : x1 + (size_t)b * HW * C1 + c0;
     const int sstride = second ? C2 : C1;
     const int NS = CH4 * 2;
-    // ---- pass 0: statistics
-    {
-        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-        for (int p = prow; p < HW; p += PPI) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
-            s0 += v[0] + v[1];
-            q0 += v[0] * v[0] + v[1] * v[1];
-            s1 += v[2] + v[3];
-            q1 += v[2] * v[2] + v[3] * v[3];
+    // ---- pass 0: statistics (taken from the forward pass when it saved them: one pass over x less)
+    if (stats) {
+        if (t < GN_CS / cpg) {
+            const float* st = stats + ((size_t)b * 32 + cs0 / cpg + t) * 2;
+            mean_s[t] = st[0];
+            rstd_s[t] = st[1];
         }
-        red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
-        red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+        __syncthreads();
+    } else {
+        {
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+            for (int p = prow; p < HW; p += PPI) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
+                s0 += v[0] + v[1];
+                q0 += v[0] * v[0] + v[1] * v[1];
+                s1 += v[2] + v[3];
+                q1 += v[2] * v[2] + v[3] * v[3];
+            }
+            red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+            red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+        }
+        __syncthreads();
+        if (t < GN_CS / cpg) {
+            const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+            float ts = 0.f, tq = 0.f;
+            for (int r = 0; r < PPI; ++r)
+                for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+            const float n = (float)HW * cpg;
+            const float mean = ts / n;
+            mean_s[t] = mean;
+            rstd_s[t] = 1.0f / sqrtf(fmaxf(tq / n - mean * mean, 0.f) + eps);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (t < GN_CS / cpg) {
-        const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
-        float ts = 0.f, tq = 0.f;
-        for (int r = 0; r < PPI; ++r)
-            for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
-        const float n = (float)HW * cpg;
-        const float mean = ts / n;
-        mean_s[t] = mean;
-        rstd_s[t] = 1.0f / sqrtf(fmaxf(tq / n - mean * mean, 0.f) + eps);
-    }
-    __syncthreads();
     float mean[4], rstd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(cl + k) / cpg]; rstd[k] = rstd_s[(cl + k) / cpg]; }
@@ -332,13 +341,13 @@ extern "C" int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, i
 
 static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                               const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1, float* out2,
-                              float* dgamma, float* dbeta, void* out1_bf16, bsi_stream_t stream) {
+                              float* dgamma, float* dbeta, void* out1_bf16, const float* stats, bsi_stream_t stream) {
     BSI_CHECK_ARG(da && x1 && gamma && beta && out1 && dgamma && dbeta && B > 0 && HW > 0, "bsi_groupnorm_bwd_nhwc: bad args");
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
     hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
-                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16));
+                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats);
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
     return BSI_OK;
 }
@@ -347,15 +356,15 @@ extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, c
                                       const float* gamma, const float* beta, float eps, int silu, const float* add,
                                       const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
                                       bsi_stream_t stream) {
-    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, nullptr, stream);
+    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, nullptr, nullptr, stream);
 }
 
 extern "C" int bsi_groupnorm_bwd_cast_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
                                            const float* gamma, const float* beta, float eps, int silu, const float* add,
                                            const float* add_b, float* out1, float* out2, float* dgamma, float* dbeta,
-                                           void* out1_bf16, bsi_stream_t stream) {
+                                           void* out1_bf16, const float* stats, bsi_stream_t stream) {
     BSI_CHECK_ARG(out1_bf16, "bsi_groupnorm_bwd_cast_nhwc: bf16 output missing");
-    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, out1_bf16, stream);
+    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, out1_bf16, stats, stream);
 }
 
 extern "C" int bsi_unet_decode_bwd(const float* g_xhat, const float* c_out, int coef_stride, const float* h, int B, int HW, int C,

@@ -90,9 +90,10 @@ template <int CS, int GN_RP>     // channels per slice, pixel rows per thread: C
 __global__ __launch_bounds__(GN_RTPB) void groupnorm_reg_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
                                                              int C2, int HW, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int silu,
-                                                             __bf16* __restrict__ out, __bf16* __restrict__ raw) {
+                                                             __bf16* __restrict__ out, __bf16* __restrict__ raw,
+                                                             float* __restrict__ stats) {
     __shared__ float red_a[GN_RTPB / 64 * CS / 2], red_b[GN_RTPB / 64 * CS / 2];  // [wave][2-channel sub-chunk]
-    __shared__ float mean_s[16], rstd_s[16];
+    __shared__ float mean_s[CS / 2], rstd_s[CS / 2];  // up to CS / 2 groups per slice (2 channels per group at C = 64)
     const int C = C1 + C2;
     constexpr int CH4 = CS / 4, PPI = GN_RTPB / CH4, NS = CH4 * 2, NWV = GN_RTPB / 64;
     const int cpg = C / 32;
@@ -150,6 +151,11 @@ __global__ __launch_bounds__(GN_RTPB) void groupnorm_reg_kernel(const float* __r
         for (int r = 0; r < NWV; ++r)
             for (int k = k0; k < k1; ++k) tq += red_b[r * NS + k];
         rstd_s[t] = 1.0f / sqrtf(tq / n + eps);
+        if (stats) {  // (mean, rstd) of group cs0/cpg + t of image b: the backward kernel starts from them (training tape)
+            float* st = stats + ((size_t)b * 32 + cs0 / cpg + t) * 2;
+            st[0] = mean_s[t];
+            st[1] = rstd_s[t];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -248,25 +254,38 @@ extern "C" int bsi_conv_weight_pack_t(const float* w, int Cout, int Cin, int tap
     return BSI_OK;
 }
 
-extern "C" int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
-                                  const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16,
-                                  bsi_stream_t stream) {
+static int groupnorm_impl(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma, const float* beta, float eps,
+                          int silu, void* out_bf16, void* raw_bf16, float* stats, bsi_stream_t stream) {
     BSI_CHECK_ARG(x1 && gamma && beta && out_bf16 && B > 0 && HW > 0, "bsi_groupnorm_nhwc: bad args");
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || x2),
                   "bsi_groupnorm_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
+    BSI_CHECK_ARG(!stats || HW <= 1024, "bsi_groupnorm_stats_nhwc: statistics output needs H*W <= 1024");
     __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
     __bf16* r = reinterpret_cast<__bf16*>(raw_bf16);
     if (HW <= 1024 && C1 % 64 == 0 && C2 % 64 == 0)  // 64-channel slices: whole 128-B lines of bf16 output (measured 60 / 126 us vs 67 / 154)
         hipLaunchKernelGGL((groupnorm_reg_kernel<64, 16>), dim3(B, C / 64), dim3(GN_RTPB), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps,
-                           silu, o, r);
+                           silu, o, r, stats);
     else if (HW <= 1024)
         hipLaunchKernelGGL((groupnorm_reg_kernel<32, 8>), dim3(B, C / 32), dim3(GN_RTPB), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps,
-                           silu, o, r);
+                           silu, o, r, stats);
     else
         hipLaunchKernelGGL(groupnorm_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S(stream), x1, C1, x2, C2, HW, gamma, beta, eps, silu, o, r);
     BSI_CHECK_LAUNCH("bsi_groupnorm_nhwc");
     return BSI_OK;
+}
+
+extern "C" int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                                  const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16,
+                                  bsi_stream_t stream) {
+    return groupnorm_impl(x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, out_bf16, raw_bf16, nullptr, stream);
+}
+
+extern "C" int bsi_groupnorm_stats_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                                        const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16, float* stats,
+                                        bsi_stream_t stream) {
+    BSI_CHECK_ARG(stats, "bsi_groupnorm_stats_nhwc: statistics pointer missing");
+    return groupnorm_impl(x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, out_bf16, raw_bf16, stats, stream);
 }
 
 extern "C" int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout,

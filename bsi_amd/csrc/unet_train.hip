@@ -56,6 +56,7 @@ struct UTape {
     char* ay;       // bf16 [M, dim]   attention output
     float* lse;     // fp32 [B, heads, HW]
     float* hatt;    // fp32 [M, dim]
+    float* gnstats; // fp32 [nblocks + 1][B][32][2]: (mean, rstd) of every GroupNorm (block i; last = the attention's)
     char* blocks;
     size_t plain_bytes, up_bytes, total;
 };
@@ -80,6 +81,7 @@ inline UTape carve_tape(const bsi_unet_config* c, int B, void* base) {
     t.ay = p + off; off += au(M * dim * 2);
     t.lse = reinterpret_cast<float*>(p + off); off += au((size_t)B * c->heads * d.HW * 4);
     t.hatt = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
+    t.gnstats = reinterpret_cast<float*>(p + off); off += au((size_t)(d.nblocks + 1) * B * 64 * 4);
     t.blocks = p + off;
     t.plain_bytes = au(M * dim * 2) * 3 + au(M * dim * 4);
     t.up_bytes = au(M * 2 * dim * 2) * 2 + au(M * dim * 2) * 2 + au(M * dim * 4);
@@ -237,7 +239,11 @@ extern "C" int bsi_unet_train_forward(const bsi_unet_config* cfg, const bsi_unet
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
         BlockTape bt = block_tape(tp, d, blk);
         const int cin2 = x2 ? dim : 0;
-        TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, bt.a, x2 ? bt.raw : nullptr, stream));
+        if (d.HW <= 1024)  // the register-resident kernel also saves (mean, rstd) for the backward pass
+            TRY(bsi_groupnorm_stats_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, bt.a, x2 ? bt.raw : nullptr,
+                                         tp.gnstats + (size_t)blk * B * 64, stream));
+        else
+            TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, bt.a, x2 ? bt.raw : nullptr, stream));
         TRY(conv(bt.a, nullptr, rb.conv1_w, rb.conv1_b, tp.zeros, bt.h1, nullptr, B, H, W, dim + cin2, 0, dim, 9, BSI_CONV_BIAS_BF16,
                  stream));
         TRY(bsi_film_silu_drop(bt.h1, M, dim, d.HW, tp.film + (size_t)blk * 2 * dim, B, d.F, make_drop(dropout_p, seed, blk), bt.y,
@@ -252,7 +258,11 @@ extern "C" int bsi_unet_train_forward(const bsi_unet_config* cfg, const bsi_unet
     }
     TRY(resblock(L, h, nullptr));
     h = block_tape(tp, d, L).out;
-    TRY(bsi_groupnorm_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, tp.agn, nullptr, stream));
+    if (d.HW <= 1024)
+        TRY(bsi_groupnorm_stats_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, tp.agn, nullptr,
+                                     tp.gnstats + (size_t)d.nblocks * B * 64, stream));
+    else
+        TRY(bsi_groupnorm_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, tp.agn, nullptr, stream));
     TRY(conv(tp.agn, nullptr, w->aqkv_w, w->aqkv_b, tp.zeros, tp.qkv, nullptr, B, H, W, dim, 0, 3 * dim, 9, BSI_CONV_BIAS_BF16, stream));
     TRY(bsi_attention_fwd_lse(tp.qkv, 3 * dim, B, d.HW, cfg->heads, d.dh, tp.ay, dim, tp.lse, stream));
     TRY(conv(tp.ay, nullptr, w->aout_w, w->aout_b, tp.zeros, tp.hatt, h, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream));
@@ -320,7 +330,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         // out1 is the next block's dOut: its bf16 copy goes straight into ws.g (no longer read by this block)
         g_ready = true;
         return bsi_groupnorm_bwd_cast_nhwc(ws.da, x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, add, add_b, out1, out2, rg.gn_w,
-                                           rg.gn_b, ws.g, stream);
+                                           rg.gn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)blk * B * 64 : nullptr, stream);
     };
 
     int cur = 0;
@@ -346,7 +356,8 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
                                           ws.wg, stream));
         TRY(conv(ws.dqkv, nullptr, wT->aqkv_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, 3 * dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_groupnorm_bwd_cast_nhwc(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
-                                        nullptr, g->agn_w, g->agn_b, ws.g, stream));
+                                        nullptr, g->agn_w, g->agn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)d.nblocks * B * 64 : nullptr,
+                                        stream));
         g_ready = true;
         cur ^= 1;
     }

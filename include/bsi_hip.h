@@ -376,6 +376,9 @@ int bsi_conv_wgrad_unpack(const float* packed, int Cout, int Cin, int taps, int 
  * (residual_block.py:42-43, vdm_unet.py:52,84); raw_bf16 (nullable) receives the un-normalised bf16 copy. */
 int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                        const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16, bsi_stream_t stream);
+/* Same, and saves (mean, rstd) of every (image, group) to stats[B][32][2] for the backward pass (H*W <= 1024). */
+int bsi_groupnorm_stats_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma, const float* beta,
+                             float eps, int silu, void* out_bf16, void* raw_bf16, float* stats, bsi_stream_t stream);
 /* Backward of bsi_groupnorm_nhwc: da bf16 [B*HW, C1+C2] is the gradient of the (SiLU'd) output.
  *   out1 [B*HW, C1] = dx1 (+ add[:, :C1]) (+ add_b),  out2 [B*HW, C2] = dx2 (+ add[:, C1:]);  add: fp32 [B*HW, C1+C2] or NULL,
  *   add_b: fp32 [B*HW, C1] or NULL (out1 may alias add when C2 == 0);  dgamma, dbeta [C1+C2] are ACCUMULATED (atomics). */
@@ -383,10 +386,12 @@ int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float*
                            const float* gamma, const float* beta, float eps, int silu, const float* add, const float* add_b,
                            float* out1, float* out2, float* dgamma, float* dbeta, bsi_stream_t stream);
 /* Same, and also writes the x1 gradient as bf16 [B*HW, C1] (the dY operand of the next block's weight / input gradient
- * convolutions: saves a separate fp32 -> bf16 pass over it). */
+ * convolutions: saves a separate fp32 -> bf16 pass over it); `stats` = the (mean, rstd) pairs bsi_groupnorm_stats_nhwc saved in the
+ * forward pass ([B][32][2] floats), NULL = recompute them. */
 int bsi_groupnorm_bwd_cast_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                                 const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1,
-                                float* out2, float* dgamma, float* dbeta, void* out1_bf16, bsi_stream_t stream);
+                                float* out2, float* dgamma, float* dbeta, void* out1_bf16, const float* stats /* or NULL */,
+                                bsi_stream_t stream);
 /* Training form of the FiLM stage (residual_block.py:21-24,44-46): y = Dropout_p(SiLU(h1*(scale+1)+shift)), h1 and y bf16
  * [M, N], film fp32 rows (scale at [0,N), shift at [N,2N)) selected by (m / HW) % film_rows; the dropout mask is the
  * counter hash of (seed, site, row m, column n) (bsi_dropout_mask exports the same mask).  _bwd: dh1 = bf16(dU*(scale+1)) with

@@ -176,16 +176,27 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
     // ---- pass 1: group sums of dn and dn*n, per-channel dgamma / dbeta
     {
         float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f, gg[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = prow; p < HW; p += PPI) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
-            const u32x2 gw = *reinterpret_cast<const u32x2*>(dap + (size_t)p * C);
-            float nrm[4], dz[4];
-            dz_of(v, gw, nrm, dz);
+        // 4 pixel rows per trip, all 8 loads in flight before the (exp + rcp) arithmetic of the first: the loop is latency bound
+        for (int p0 = prow; p0 < HW; p0 += 4 * PPI) {
+            f32x4 vv[4];
+            u32x2 gv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { gg[k] = __fmaf_rn(dz[k], nrm[k], gg[k]); gb[k] += dz[k]; }
-            const float d0 = dz[0] * ga[0], d1 = dz[1] * ga[1], d2 = dz[2] * ga[2], d3 = dz[3] * ga[3];
-            s0 += d0 + d1; q0 += d0 * nrm[0] + d1 * nrm[1];
-            s1 += d2 + d3; q1 += d2 * nrm[2] + d3 * nrm[3];
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * PPI;
+                vv[u] = p < HW ? *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+                gv[u] = p < HW ? *reinterpret_cast<const u32x2*>(dap + (size_t)p * C) : u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u * PPI >= HW) continue;
+                float nrm[4], dz[4];
+                dz_of(vv[u], gv[u], nrm, dz);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { gg[k] = __fmaf_rn(dz[k], nrm[k], gg[k]); gb[k] += dz[k]; }
+                const float d0 = dz[0] * ga[0], d1 = dz[1] * ga[1], d2 = dz[2] * ga[2], d3 = dz[3] * ga[3];
+                s0 += d0 + d1; q0 += d0 * nrm[0] + d1 * nrm[1];
+                s1 += d2 + d3; q1 += d2 * nrm[2] + d3 * nrm[3];
+            }
         }
         red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
         red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
@@ -217,30 +228,34 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
     float* dst = second ? out2 + (size_t)b * HW * C2 + (c0 - C1) : out1 + (size_t)b * HW * C1 + c0;
     const float* ab = (!second && add_b) ? add_b + (size_t)b * HW * C1 + c0 : nullptr;
     const float* aa = add ? add + (size_t)b * HW * C + c0 : nullptr;
-    for (int p = prow; p < HW; p += PPI) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride);
-        const u32x2 gw = *reinterpret_cast<const u32x2*>(dap + (size_t)p * C);
-        float nrm[4], dz[4];
-        dz_of(v, gw, nrm, dz);
-        f32x4 o;
+    for (int p0 = prow; p0 < HW; p0 += 4 * PPI) {
+        f32x4 vv[4], a4[4], b4[4];
+        u32x2 gv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (dz[k] * ga[k] - m1[k] - nrm[k] * m2[k]);
-        if (aa) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(aa + (size_t)p * C);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] += a4[k];
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PPI;
+            const bool ok = p < HW;
+            vv[u] = ok ? *reinterpret_cast<const f32x4*>(src + (size_t)p * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gv[u] = ok ? *reinterpret_cast<const u32x2*>(dap + (size_t)p * C) : u32x2{0u, 0u};
+            a4[u] = (ok && aa) ? *reinterpret_cast<const f32x4*>(aa + (size_t)p * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b4[u] = (ok && ab) ? *reinterpret_cast<const f32x4*>(ab + (size_t)p * C1) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (ab) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + (size_t)p * C1);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] += a4[k];
-        }
-        *reinterpret_cast<f32x4*>(dst + (size_t)p * sstride) = o;
-        if (out1_bf && !second) {  // bf16 copy of the x1 gradient: the next block's convolutions take it as their dY operand
-            u32x2 w2;
-            w2[0] = pack_bf16x2(o[0], o[1]);
-            w2[1] = pack_bf16x2(o[2], o[3]);
-            *reinterpret_cast<u32x2*>(out1_bf + ((size_t)b * HW + p) * C1 + c0) = w2;
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PPI;
+            if (p >= HW) continue;
+            float nrm[4], dz[4];
+            dz_of(vv[u], gv[u], nrm, dz);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (dz[k] * ga[k] - m1[k] - nrm[k] * m2[k]) + a4[u][k] + b4[u][k];
+            *reinterpret_cast<f32x4*>(dst + (size_t)p * sstride) = o;
+            if (out1_bf && !second) {  // bf16 copy of the x1 gradient: the next block's convolutions take it as their dY operand
+                u32x2 w2;
+                w2[0] = pack_bf16x2(o[0], o[1]);
+                w2[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(out1_bf + ((size_t)b * HW + p) * C1 + c0) = w2;
+            }
         }
     }
 }

@@ -27,18 +27,23 @@ struct WgParams {
     float* out;           // [splits][Cout][Ktot]
     float* colsum;        // optional [splits][Cout]: column sums of dY (bias gradient), written by the first unit tile's workgroups
     int M, H, Wd, HW, Cin, Cin2, taps, Cout, ldy, Ktot;
-    int tiles_u, tiles_n, splits, m_per_split;
+    int tiles_u, tiles_n, splits, m_per_split, units;
     size_t slab_stride;
 };
 
 constexpr int G_RB = 256;          // bytes per sub-tile row (128 bf16 columns)
 constexpr int G_SUB = 32 * G_RB;   // one sub-tile of a stage: 32 pixels
-constexpr int G_SLOT = 5 * G_SUB;  // 4 im2col units + dY = 40 KB
-constexpr int G_R = 4, G_D = G_R - 1;
+// A stage = UNITS im2col units + dY; UNITS = 4: 40 KB stages, ring of 4; UNITS = 3: 32 KB stages, ring of 5 (160 KB either way).
+// UNITS = 3 when the K range is a multiple of 384 columns but not of 512 (K = 1152 = 9 units: 3 tiles of 3 units instead of
+// 3 tiles of 4 with a quarter of the MFMAs wasted on padding; K = 2304: 6 x 3 instead of 5 x 4).
 
 __device__ __forceinline__ int wg_swz(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
 
+template <int UNITS>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
+    constexpr int G_SLOT = (UNITS + 1) * G_SUB;
+    constexpr int G_R = 160 * 1024 / G_SLOT, G_D = G_R - 1;  // 4 slots of 40 KB or 5 of 32 KB
+    constexpr int NI = UNITS + 1;                           // DMA instructions per stage and wave
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 
     const int tiles = p.tiles_n * p.tiles_u;
     const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
-    const int n0 = (tile / p.tiles_u) * 128, u0 = (tile % p.tiles_u) * 4;
+    const int n0 = (tile / p.tiles_u) * 128, u0 = (tile % p.tiles_u) * UNITS;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
     const int nk = (mend - mbeg + 31) / 32;
@@ -61,14 +66,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     const int srow = 4 * wave + (lane >> 4), spos = lane & 15;
     const int schunk = spos ^ wg_swz(srow);  // source chunk that lands at this lane's LDS position
     const int conv_k = p.taps * p.Cin;
-    unsigned uconst[4];  // per unit: shift*pitch + channel bytes of this lane's chunk, or OOB beyond Ktot
-    int utap[4];         // per unit: border bits that invalidate this lane's tap (conv_igemm.hip: tap_mask)
-    bool lsrc2[4];       // per unit: this lane's column belongs to the second source
-    bool usrc2[4];       // per unit (wave-uniform): every column belongs to the second source
-    bool ustr[4];        // per unit (wave-uniform): the unit straddles the two sources -> one DMA instruction per source
-    int extra = 0;       // straddling units of this tile (0 or 1): DMA instructions per stage = 5 + extra
+    unsigned uconst[UNITS];  // per unit: shift*pitch + channel bytes of this lane's chunk, or OOB beyond Ktot
+    int utap[UNITS];         // per unit: border bits that invalidate this lane's tap (conv_igemm.hip: tap_mask)
+    bool lsrc2[UNITS];       // per unit: this lane's column belongs to the second source
+    bool usrc2[UNITS];       // per unit (wave-uniform): every column belongs to the second source
+    bool ustr[UNITS];        // per unit (wave-uniform): the unit straddles the two sources -> one DMA instruction per source
+    int extra = 0;       // straddling units of this tile (0 or 1): DMA instructions per stage = NI + extra
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < UNITS; ++q) {
         const int vc = (u0 + q) * 128 + schunk * 8;
         usrc2[q] = (u0 + q) * 128 >= conv_k;
         ustr[q] = p.Cin2 > 0 && (u0 + q) * 128 < conv_k && (u0 + q) * 128 + 128 > conv_k;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         const unsigned mpx2 = m_ok ? (unsigned)sm * (unsigned)(p.Cin2 * 2) : OOB;
         const unsigned mpy = m_ok ? (unsigned)sm * (unsigned)(p.ldy * 2) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UNITS; ++q) {
             const unsigned vo = (code & utap[q]) ? OOB : (lsrc2[q] ? mpx2 : mpx) + uconst[q];
             if (ustr[q]) {  // divergent on purpose: two instructions with complementary exec masks fill disjoint lanes
                 if (lsrc2[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + q * G_SUB), 16, vo, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + 4 * G_SUB), 16, mpy + yconst, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + UNITS * G_SUB), 16, mpy + yconst, 0, 0, 0);
         // next stage: 32 pixels on
         sm += 32;
         sx += r32;
@@ -136,14 +141,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     const int swA = wg_swz(mA), swB = wg_swz(mB);
     const int rowA = mA * G_RB, rowB = mB * G_RB;
     const int half8 = 8 * (pp & 1), chp = pp >> 1;
-    const int xunit = (wave >> 1) * G_SUB, xch0 = (wave & 1) * 8;
+    const int wcol0 = 16 * UNITS * wave;  // first im2col column (inside the tile) of this wave's slice of 16 * UNITS columns
 
-    f32x4 acc[4][8];
+    f32x4 acc[UNITS][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < UNITS; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4], bf[8];
+    bf16x8 af[UNITS], bf[8];
     // fused bias gradient (gemm_tn.hip): column sums of the dY tile = one extra MFMA per stage with an all-ones A operand
     // (pixels beyond the split are zero rows already); wave w takes output channels 16w .. 16w+15 of the tile
     const bool do_colsum = p.colsum != nullptr && (tile % p.tiles_u) == 0;
@@ -163,8 +168,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     auto load_frags = [&](const char* b) {
         union U { bf16x8 v; s16x4 h[2]; };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // im2col columns 64*(wave&1) + 16i + 4pp of unit wave>>1
-            const int ch = xch0 + 2 * i + chp;
+        for (int i = 0; i < UNITS; ++i) {  // im2col columns wcol0 + 16i + 4pp: unit (wcol0 + 16i) / 128, 16-B chunk pair inside it
+            const int col = wcol0 + 16 * i;
+            const int xunit = (col >> 7) * G_SUB, ch = ((col & 127) >> 3) + chp;
             U u;
             u.h[0] = TR(b + xunit + rowA + ((ch ^ swA) << 4) + half8);
             u.h[1] = TR(b + xunit + rowB + ((ch ^ swB) << 4) + half8);
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         for (int j = 0; j < 8; ++j) {  // dY columns 16j + 4pp
             const int ch = 2 * j + chp;
             U u;
-            u.h[0] = TR(b + 4 * G_SUB + rowA + ((ch ^ swA) << 4) + half8);
-            u.h[1] = TR(b + 4 * G_SUB + rowB + ((ch ^ swB) << 4) + half8);
+            u.h[0] = TR(b + UNITS * G_SUB + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + UNITS * G_SUB + rowB + ((ch ^ swB) << 4) + half8);
             bf[j] = u.v;
         }
     };
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     for (int d = 0; d < G_D; ++d)
         if (d < nk) stage(d);
     extra = __builtin_amdgcn_readfirstlane(extra);
-    if (nk >= G_D && !extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
-    else if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (G_D - 1)) : "memory");
+    if (nk >= G_D && !extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
+    else if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI + 1) * (G_D - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_BARRIER();
     if (grp == 1) WG_BARRIER();
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         load_frags(lds + slot * G_SLOT);
         if (v + G_D < nk) {
             stage(pslot);
-            if (!extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (G_D - 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (G_D - 1)) : "memory");
+            if (!extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI + 1) * (G_D - 1)) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < UNITS; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         if (do_colsum) {
             bf16x8 bsel = bf[0];
@@ -234,8 +240,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         const int n = n0 + 16 * j + (lane & 15);
         if (n >= p.Cout) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = u0 * 128 + 64 * wave + 16 * i + 4 * q4;
+        for (int i = 0; i < UNITS; ++i) {
+            const int k = u0 * 128 + wcol0 + 16 * i + 4 * q4;
             if (k < p.Ktot) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(out + (size_t)n * p.Ktot + k));
         }
     }
@@ -250,7 +256,12 @@ void plan(WgParams& p) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_wg_cus = prop.multiProcessorCount;
         if (g_wg_cus <= 0) g_wg_cus = 256;
     }
-    p.tiles_u = (p.Ktot + 511) / 512;
+    {   // 3 or 4 units of 128 im2col columns per tile: whichever pads the K range less (4 on a tie)
+        const int nu = (p.Ktot + 127) / 128;
+        const int pad4 = (nu + 3) / 4 * 4 - nu, pad3 = (nu + 2) / 3 * 3 - nu;
+        p.units = pad3 < pad4 ? 3 : 4;
+    }
+    p.tiles_u = (p.Ktot + 128 * p.units - 1) / (128 * p.units);
     p.tiles_n = (p.Cout + 127) / 128;
     const int tiles = p.tiles_u * p.tiles_n;
     const int max_s = (p.M + 255) / 256;  // at least 8 stages per split
@@ -313,14 +324,16 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     p.Ktot = taps * Cin + Cin2;
     plan(p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    p.colsum = dbias ? p.out + (size_t)p.splits * p.slab_stride : nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  G_R * G_SLOT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    p.colsum = dbias ? p.out + (size_t)p.splits * p.slab_stride : nullptr;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_u * p.splits), dim3(512), G_R * G_SLOT, s, p);
+    const dim3 grid(p.tiles_n * p.tiles_u * p.splits);
+    if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");
     if (dbias) {
         const int rc = bsi_reduce_slabs_launch(p.colsum, (size_t)Cout, p.splits, (size_t)Cout, accumulate, dbias, s);

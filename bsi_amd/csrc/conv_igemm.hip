@@ -313,7 +313,8 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 constexpr int S_HALO = 48, S_ROWS = C_BM + 2 * S_HALO, S_INSTR = S_ROWS / 16;  // 608 rows, 38 DMA instructions
 constexpr int S_SLAB = S_ROWS * C_RB;                                             // 38912 B
 constexpr int S_WSLOTS = 8, S_WD = 6, S_WSTAGE = C_BN * C_RB;                     // 8 KB weight stages, 6 in flight
-constexpr int S_WRING = 2 * S_SLAB, S_ZERO = S_WRING + S_WSLOTS * S_WSTAGE, S_LDS = S_ZERO + 64;
+constexpr int S_WRING = 2 * S_SLAB, S_ZERO = S_WRING + S_WSLOTS * S_WSTAGE, S_LDS = S_ZERO + 256;  // S_ZERO is 256-B aligned
+static_assert(S_ZERO % 256 == 0, "the zero region mirrors the bank position of the address it replaces");
 
 template <int NSTORE>
 __device__ __forceinline__ void wait_vm_allowed(int n) {  // s_waitcnt vmcnt(n) for a wave-uniform runtime n (rounded down where rare)
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     const int nc = p.Cin / 32;
     const int HW = p.H * p.Wd;
 
-    if (tid < 16) reinterpret_cast<float*>(lds + S_ZERO)[tid] = 0.f;  // visible after the prologue's barrier
+    if (tid < 64) reinterpret_cast<float*>(lds + S_ZERO)[tid] = 0.f;  // 256 B of zeros, visible after the prologue's barrier
 
     // ---- slab stream (runs one slab ahead of the compute): 5 DMA instructions per wave and slab, 16 rows x 64 B each.
     // The buffer base is the slab's first row, so a lane's offset never changes; rows past the end of the tensor fall outside
@@ -427,7 +428,6 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     const int wcc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
     const int woff = S_WRING + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * C_RB + wcc;
     const int xrow0 = S_HALO + wrow0 + rho;  // slab row of this lane's pixel in fragment 0, before the tap shift
-    const int zaddr = S_ZERO + qd * 16;
 
     f32x4 acc[4][TM];
     bf16x8 wf[4], xf[TM];
@@ -572,7 +572,11 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 #pragma unroll
                         for (int j = 0; j < TM; ++j) {
                             const bool z = ((zall >> j) & 1) || (((zlane >> j) & 1) && edge_lane);
-                            const int a = z ? zaddr : slab_off + xaddr + j * 16 * C_RB;
+                            // a zeroed lane reads the zero region at the bank position of the address it replaces: the other
+                            // 15 rows of its group leave exactly that slot free (a fixed zero address cost a 2-way conflict on
+                            // a third of the fragment reads: SQ_LDS_BANK_CONFLICT = 30 % of the LDS cycles)
+                            const int a0 = slab_off + xaddr + j * 16 * C_RB;
+                            const int a = z ? S_ZERO + (a0 & 255) : a0;
                             xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
                         }
                     }

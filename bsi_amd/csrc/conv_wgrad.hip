@@ -49,8 +49,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;  // ping-pong group
 
+    // XCD-aware order: workgroup b runs on XCD b % 8, which has its own L2.  The tiles of one split read the same dY rows and the
+    // same X rows (shifted by their taps), so each XCD gets a contiguous range of (split, tile) pairs with the tile index fastest.
     const int tiles = p.tiles_n * p.tiles_u;
-    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int total = tiles * p.splits, per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= total) return;
+    const int tile = logical % tiles, split = logical / tiles;
     const int n0 = (tile / p.tiles_u) * 128, u0 = (tile % p.tiles_u) * UNITS;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
@@ -331,7 +336,7 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const dim3 grid(p.tiles_n * p.tiles_u * p.splits);
+    const dim3 grid(8 * ((p.tiles_n * p.tiles_u * p.splits + 7) / 8));  // whole rounds of the 8 XCDs (the kernel drops the excess)
     if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");

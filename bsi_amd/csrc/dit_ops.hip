@@ -209,76 +209,125 @@ __global__ void dit_final_kernel(const float* __restrict__ x, int Mtok, int d, i
     const int nw = W / ps;
     const int tokens = (H / ps) * nw;
     const int HW = H * W;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Mtok; row += gridDim.x * wpb) {
-        const float* xr = x + (size_t)row * d;
-        const int b_idx = row / tokens, tok = row % tokens;
-        f32x4 v[VPL];
-        float s = 0.f;
+    // FR rows per trip and wave: every decoder weight fragment read from LDS (or L2) serves FR tokens, and the FR x 4 wave
+    // reductions of a group of four outputs are independent chains whose shuffle latencies overlap.
+    constexpr int FR = 4;
+    for (int row0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * FR; row0 < Mtok; row0 += gridDim.x * wpb * FR) {
+        f32x4 v[FR][VPL];
+        float s[FR], q[FR];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (delta && c < d4) {  // pending gated residual of the last block's MLP branch (dit.py:98-102)
-                const u32x2 dw = reinterpret_cast<const u32x2*>(delta + (size_t)row * d)[c];
-                const f32x4 g = reinterpret_cast<const f32x4*>(gate + (size_t)(b_idx % gate_rows) * gate_stride)[c];
-                v[i][0] = __fmaf_rn(g[0], __uint_as_float(dw[0] << 16), v[i][0]);
-                v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
-                v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
-                v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
+        for (int r = 0; r < FR; ++r) {
+            const int row = row0 + r < Mtok ? row0 + r : Mtok - 1;
+            const float* xr = x + (size_t)row * d;
+            const int b_idx = row / tokens;
+            s[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                v[r][i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (delta && c < d4) {  // pending gated residual of the last block's MLP branch (dit.py:98-102)
+                    const u32x2 dw = reinterpret_cast<const u32x2*>(delta + (size_t)row * d)[c];
+                    const f32x4 g = reinterpret_cast<const f32x4*>(gate + (size_t)(b_idx % gate_rows) * gate_stride)[c];
+                    v[r][i][0] = __fmaf_rn(g[0], __uint_as_float(dw[0] << 16), v[r][i][0]);
+                    v[r][i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[r][i][1]);
+                    v[r][i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[r][i][2]);
+                    v[r][i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[r][i][3]);
+                }
+                s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
             }
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
-        const float mean = wave_sum(s) / (float)d;
-        float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < d4) {
+        for (int m = 32; m > 0; m >>= 1)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dd = v[i][k] - mean;
-                    q = __fmaf_rn(dd, dd, q);
+            for (int r = 0; r < FR; ++r) s[r] += __shfl_xor(s[r], m, 64);
+#pragma unroll
+        for (int r = 0; r < FR; ++r) {
+            const float mean = s[r] / (float)d;
+            s[r] = mean;
+            q[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dd = v[r][i][k] - mean;
+                        q[r] = __fmaf_rn(dd, dd, q[r]);
+                    }
                 }
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1)
+#pragma unroll
+            for (int r = 0; r < FR; ++r) q[r] += __shfl_xor(q[r], m, 64);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = i * 64 + lane;
             if (c < d4) {
                 const f32x4 a = reinterpret_cast<const f32x4*>(ln_w)[c];
-                const f32x4 b = reinterpret_cast<const f32x4*>(ln_b)[c];
+                const f32x4 bb = reinterpret_cast<const f32x4*>(ln_b)[c];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = __fmaf_rn((v[i][k] - mean) * rstd, a[k], b[k]);
-            }
-        }
-        const int th = tok / nw, tw = tok % nw;
-        float mine = 0.f;
-        for (int o = 0; o < P; ++o) {  // P <= 64: lane o keeps output o
-            float acc = 0.f;
+                for (int r = 0; r < FR; ++r) {
+                    const float rstd = 1.0f / sqrtf(q[r] / (float)d + 1e-5f);
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const int c = i * 64 + lane;
-                if (c < d4) {
-                    const f32x4 wv = WLDS ? reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c]
-                                          : reinterpret_cast<const f32x4*>(dec_w + (size_t)o * d)[c];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc = __fmaf_rn(v[i][k], wv[k], acc);
+                    for (int k = 0; k < 4; ++k) v[r][i][k] = __fmaf_rn((v[r][i][k] - s[r]) * rstd, a[k], bb[k]);
                 }
             }
-            acc = wave_sum(acc);
-            if (lane == o) mine = acc + dec_b[o];
+        }
+        float mine[FR] = {0.f, 0.f, 0.f, 0.f};
+        for (int o0 = 0; o0 < P; o0 += 4) {  // P <= 64: lane o keeps output o
+            float acc[FR][4];
+#pragma unroll
+            for (int r = 0; r < FR; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[r][u] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = o0 + u < P ? o0 + u : P - 1;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int c = i * 64 + lane;
+                    if (c < d4) {
+                        const f32x4 wv = WLDS ? reinterpret_cast<const f32x4*>(wsm + (size_t)o * d)[c]
+                                              : reinterpret_cast<const f32x4*>(dec_w + (size_t)o * d)[c];
+#pragma unroll
+                        for (int r = 0; r < FR; ++r)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[r][u] = __fmaf_rn(v[r][i][k], wv[k], acc[r][u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1)
+#pragma unroll
+                for (int r = 0; r < FR; ++r)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[r][u] += __shfl_xor(acc[r][u], m, 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (o0 + u < P && lane == o0 + u) {
+#pragma unroll
+                    for (int r = 0; r < FR; ++r) mine[r] = acc[r][u] + dec_b[o0 + u];
+                }
         }
         if (lane < P) {
             const int intra = lane / C, ch = lane % C;
-            const int hh = th * ps + intra / ps, ww = tw * ps + intra % ps;
-            const size_t gi = ((size_t)b_idx * C + ch) * HW + (size_t)hh * W + ww;
-            float r = mine;
-            if (c_skip) {
-                const float cs = c_skip[(size_t)b_idx * coef_stride], co = c_out[(size_t)b_idx * coef_stride];
-                r = __fmaf_rn(co, mine, __fmul_rn(cs, mu[gi]));
+#pragma unroll
+            for (int r = 0; r < FR; ++r) {
+                const int row = row0 + r;
+                if (row >= Mtok) break;
+                const int b_idx = row / tokens, tok = row % tokens;
+                const int th = tok / nw, tw = tok % nw;
+                const int hh = th * ps + intra / ps, ww = tw * ps + intra % ps;
+                const size_t gi = ((size_t)b_idx * C + ch) * HW + (size_t)hh * W + ww;
+                float rr = mine[r];
+                if (c_skip) {
+                    const float cs = c_skip[(size_t)b_idx * coef_stride], co = c_out[(size_t)b_idx * coef_stride];
+                    rr = __fmaf_rn(co, mine[r], __fmul_rn(cs, mu[gi]));
+                }
+                out[gi] = rr;
             }
-            out[gi] = r;
         }
     }
 }
@@ -415,10 +464,11 @@ int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln
         bsi_set_error("bsi_dit_final: decoder P=%d unsupported (needs patch*patch*C <= 64)", P);
         return BSI_EINVAL;
     }
-    const bool wlds = lds <= 128 * 1024;
+    const bool wlds = lds <= 128 * 1024;  // (reading the weights from L2 instead measures the same: 26 vs 27 ms per 129 launches)
     if (!wlds) lds = 0;
     const int wpb = TPB / 64;
-    int grid = (Mtok + wpb * 8 - 1) / (wpb * 8);  // ~8 tokens per wave amortise the LDS fill
+    // one trip = 4 tokens per wave (2048 workgroups measured faster than 512 longer-lived ones: occupancy beats the amortised LDS fill)
+    int grid = (Mtok + wpb * 4 - 1) / (wpb * 4);
     if (grid < 1) grid = 1;
     if (grid > 2048) grid = 2048;
 #define LAUNCH_FINAL(V)                                                                                              \

@@ -1,0 +1,18 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/pmc_all; mkdir -p $O
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/a -- python3 bench.py --k 2 --steps 1 --warmup 0 --train-steps 1 --train-batch 64 --no-cpu-baseline > /dev/null 2>&1
+WHICH=unet,unet_train K=2 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/b -- python3 tools/secondary_bench.py > /dev/null 2>&1
+python - <<'PY'
+import csv, glob, collections
+for d in ("gpurun_out/pmc_all/a", "gpurun_out/pmc_all/b"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"][:90]][r["Counter_Name"]] += float(r["Counter_Value"])
+    print(d)
+    for k, cs in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_LDS_BANK_CONFLICT", 0)):
+        c, a = cs.get("SQ_LDS_BANK_CONFLICT", 0), cs.get("SQ_LDS_IDX_ACTIVE", 0)
+        if a > 0:
+            print(f"  {100 * c / a:5.1f} % conflict cycles  ({a:.3g} LDS cycles)  {k}")
+PY
+rm -rf $O

@@ -366,7 +366,10 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     // The buffer base is the slab's first row, so a lane's offset never changes; rows past the end of the tensor fall outside
     // num_records (zeros), rows before its start (first tile only) are sent out of range explicitly.
     const int srow = lane >> 2, spos = lane & 3;
-    const int achunk = (spos ^ ((-(srow >> 2)) & 3)) * 16;
+    // slab rows are swizzled with key (row >> 1) & 3: measured conflict free for fragments starting at ANY row
+    // (tools/experiments/lds_shift_conflicts.hip: 7.2 cycles per ds_read_b128 for shifts 0..15; the aligned kernels' key
+    // (-(row >> 2)) & 3 costs 9.3 cycles when the first row is not a multiple of 8, i.e. for the dx = +-1 taps)
+    const int achunk = (spos ^ ((srow >> 1) & 3)) * 16;
     const int rowb = p.Cin * 2;
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* Wb = reinterpret_cast<const char*>(p.W);
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                     for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + woff + i * 4 * C_RB);
                     int row = xrow0 + dy * p.Wd + dx;
                     asm volatile("" : "+v"(row));  // recompute per phase: hoisting the 9 taps' addresses out of the chunk loop costs 20+ VGPRs
-                    const int xaddr = row * C_RB + ((qd ^ ((-(row >> 2)) & 3)) << 4);
+                    const int xaddr = row * C_RB + ((qd ^ ((row >> 1) & 3)) << 4);
                     const unsigned zall = dy < 0 ? ytop : dy > 0 ? ybot : 0u;
                     const unsigned zlane = dx < 0 ? xl : dx > 0 ? xr : 0u;
                     if ((zall | zlane) == 0) {  // no fragment of this wave touches a border under this tap

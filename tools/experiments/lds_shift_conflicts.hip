@@ -10,17 +10,21 @@ __global__ __launch_bounds__(256) void k(int shift, int mode, int iters, unsigne
     for (int i = threadIdx.x; i < 40960 / 4; i += 256) ((float*)lds)[i] = (float)i;
     __syncthreads();
     const int row = 64 + rho + shift;
-    int key;
-    if (mode == 0) key = (-(row >> 2)) & 3;              // the kernels' swizzle: chunk ^= (-(row >> 2)) & 3
-    else if (mode == 1) key = (row >> 2) & 3;            // plain (row >> 2) & 3
-    else key = ((row >> 2) ^ (row >> 4)) & 3;            // folded
+    // mode = a | b << 4 | neg << 8 | add << 9: key = +-((row >> a) (^ or +) (row >> b)) & 3   (b = 15: single term)
+    const int a = mode & 15, b = (mode >> 4) & 15, neg = (mode >> 8) & 1, add = (mode >> 9) & 1;
+    int key = row >> a;
+    if (b != 15) key = add ? key + (row >> b) : key ^ (row >> b);
+    key = (neg ? -key : key) & 3;
     const int addr = row * 64 + ((qd ^ key) << 4);
     f32x4 acc = {0, 0, 0, 0};
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
         f32x4 v[8];
+        // volatile asm: the addresses are loop invariant and the compiler would hoist plain loads out of the loop
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(lds + addr + j * 1024);  // 8 reads in flight
+        for (int j = 0; j < 8; ++j)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(lds + addr + j * 1024)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += v[j];
     }
@@ -33,13 +37,25 @@ int main() {
     unsigned long long* d; float* s;
     hipMalloc(&d, 8); hipMalloc(&s, 1024);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    const int iters = 2000;
-    for (int mode = 0; mode < 3; ++mode)
-        for (int shift : {0, 1, 2, 3, 4, 5, 8, 15, 16, 31, 32, 33, -1, -33}) {
-            hipLaunchKernelGGL(k, dim3(1), dim3(256), 65536, 0, shift, mode, 10, d, s);
-            hipLaunchKernelGGL(k, dim3(1), dim3(256), 65536, 0, shift, mode, iters, d, s);
-            unsigned long long c; hipMemcpy(&c, d, 8, hipMemcpyDeviceToHost);
-            printf("swizzle %d shift %4d: %6.1f cycles per ds_read_b128 (4 waves, one per SIMD; 8 = conflict free)\n", mode, shift, (double)c / (iters * 8 * 4));
-        }
+    const int iters = 500;
+    for (int neg = 0; neg < 2; ++neg)
+        for (int add = 0; add < 2; ++add)
+            for (int a = 0; a < 4; ++a)
+                for (int b : {15, 1, 2, 3, 4}) {
+                    if (b != 15 && b <= a) continue;
+                    if (b == 15 && add) continue;
+                    const int mode = a | b << 4 | neg << 8 | add << 9;
+                    double worst = 0, best = 1e9;
+                    for (int shift = 0; shift < 16; ++shift) {
+                        hipLaunchKernelGGL(k, dim3(1), dim3(256), 65536, 0, shift, mode, 10, d, s);
+                        hipLaunchKernelGGL(k, dim3(1), dim3(256), 65536, 0, shift, mode, iters, d, s);
+                        unsigned long long c; hipMemcpy(&c, d, 8, hipMemcpyDeviceToHost);
+                        const double cyc = (double)c / (iters * 8 * 4);
+                        worst = cyc > worst ? cyc : worst; best = cyc < best ? cyc : best;
+                    }
+                    printf("key = %s((row >> %d)%s) & 3: best %.1f worst %.1f cycles per read over shifts 0..15\n", neg ? "-" : "", a,
+                           b == 15 ? "" : (add ? (b == 1 ? " + (row >> 1)" : b == 2 ? " + (row >> 2)" : b == 3 ? " + (row >> 3)" : " + (row >> 4)")
+                                              : (b == 1 ? " ^ (row >> 1)" : b == 2 ? " ^ (row >> 2)" : b == 3 ? " ^ (row >> 3)" : " ^ (row >> 4)")), best, worst);
+                }
     return 0;
 }

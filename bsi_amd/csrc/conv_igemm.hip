@@ -674,9 +674,12 @@ int launch_conv(ConvParams p, hipStream_t s) {
         // stores get five phases to drain instead of two), 256 -> 128 channels bf16 93 / 336 against 94 / 341, 128 -> 128 bf16
         // 57 / 214 against 50 / 189 (longer load phase: tap address arithmetic); UNet sampling at 256 images: 510 images/s (k=16)
         // with the slab kernel wherever possible, 505 with it for fp32 outputs only, 497 without it.  Ablation flag 256 = never.
+        // (Numbers from before the slab's LDS swizzle fix; after it: 256 -> 128 bf16 312 vs 361 us, 384 -> 128 448 vs 535 us at 512 images.)
         const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0 &&
                          (EPI != CEPI_FILM_SILU_BF16 || (p.H * p.Wd) % 128 == 0);  // FiLM: a wave's 128 rows within one image
-        const bool want = !(g_conv_abl & 256);
+        // plain bf16 epilogue with at most 128 input channels: the ring kernel is 3-5 % faster there (4 chunks x 9 taps give the
+        // slab little to amortise); 512 forces the slab kernel wherever the shape allows
+        const bool want = !(g_conv_abl & 256) && (EPI != CEPI_BIAS_BF16 || p.Cin > 128 || (g_conv_abl & 512));
         if (can && want) return launch_conv_slab<EPI>(p, grid, s);
     }
     const size_t lds = (size_t)C_R * C_SLOT;

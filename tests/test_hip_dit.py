@@ -596,3 +596,27 @@ def test_dp_trainer_exchange_path_on_one_rank():
         dist.destroy_process_group()
         if os.path.exists(store.name):
             os.unlink(store.name)
+
+
+@pytest.mark.gpu
+def test_sample_graph_replay_matches_eager():
+    """BSI.sample(graph=True): the whole chain captured as one HIP graph returns the eager path's samples bit for bit (same
+    generator draws), also on a second replay with a new generator state."""
+    import torch
+    from bsi_amd import BSI, Discretization
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    model = DenoisingDiT((3, 16, 16), 2, 128, 2, 2, dropout=0.0, fourier_features=FourierFeatures(n_min=6, n_max=7)).to(dev).eval()
+    with torch.no_grad():
+        for blk in model.dit.blocks:
+            blk.adaLN_modulation[-1].weight.normal_(0, 0.02)
+    bsi = BSI(model, data_shape=(3, 16, 16), lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=6, preconditioning="edm",
+              discretization=Discretization.image_8bit()).to(dev)
+    with torch.no_grad():
+        for seed in (5, 6):
+            a = bsi.sample(3, torch.Generator(dev).manual_seed(seed))
+            b = bsi.sample(3, torch.Generator(dev).manual_seed(seed), graph=True)
+            assert torch.equal(a, b)
+        assert not torch.equal(a, bsi.sample(3, torch.Generator(dev).manual_seed(7), graph=True))

@@ -1502,7 +1502,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* src = ihalf ? Wb + koff + gW[q] : Ab + koff + gA[q];
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
+            // laboratory: cache-policy bits of the LDS-DMA loads (ABL 2048 / 4096: nt on the A / W half-stages, 8192 / 16384: sc1)
+            if constexpr ((ABL & (2048 | 4096 | 8192 | 16384)) != 0) {
+                if (ihalf) {
+                    if constexpr (ABL & 4096) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 2);
+                    else if constexpr (ABL & 16384) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 16);
+                    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
+                } else {
+                    if constexpr (ABL & 2048) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 2);
+                    else if constexpr (ABL & 8192) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 16);
+                    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
+                }
+            } else {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
+            }
         }
         islot = islot == 4 ? 0 : islot + 1;
         if (ihalf) {

@@ -201,6 +201,12 @@ int main() {
             rep("v6 no epi, no glds", time_pring<E, 5>(p, 20));
             rep("v12 full", time_k64r<E, 0>(p, 20));
             rep("v12 gelu full", time_k64r<G, 0>(p, 20));
+            rep("v12 A loads nt", time_k64r<E, 2048>(p, 20));
+            rep("v12 W loads nt", time_k64r<E, 4096>(p, 20));
+            rep("v12 A and W loads nt", time_k64r<E, 2048 | 4096>(p, 20));
+            rep("v12 A loads sc1", time_k64r<E, 8192>(p, 20));
+            rep("v12 W loads sc1", time_k64r<E, 16384>(p, 20));
+            rep("v12 full (again)", time_k64r<E, 0>(p, 20));
             rep("v12 epilogue w/o global stores", time_k64r<E, 128>(p, 20));
             rep("v12 gelu w/o global stores", time_k64r<G, 128>(p, 20));
             rep("v12 ordinary (wb) stores", time_k64r<E, 32>(p, 20));

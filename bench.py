@@ -208,7 +208,7 @@ def main():
         avg_ms = tot_ms / max(cnt, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         line = {
-            "metric": "images/sec BSI.sample k=128 (DiT, 3x32x32)",
+            "metric": f"images/sec BSI.sample k={a.k} (DiT, 3x32x32)",
             "value": value, "unit": "images/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

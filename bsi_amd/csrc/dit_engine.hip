@@ -43,6 +43,8 @@ struct Workspace {
     float* x;   // fp32 [M, dim]
     char* xn;   // bf16 [M, dim]
     char* big;  // bf16 [M, 4*dim]
+    char* splitk;  // fp32 partial sums of the split-K latency path (a few images per call), 0 bytes for large batches
+    size_t splitk_bytes;
     size_t total;
 };
 
@@ -56,6 +58,14 @@ inline Workspace carve(const bsi_dit_config* c, int B, void* base) {
     w.x = reinterpret_cast<float*>(p + off); off += align_up(M * c->dim * 4, 256);
     w.xn = p + off; off += align_up(M * c->dim * 2, 256);
     w.big = p + off; off += align_up(M * 4 * (size_t)c->dim * 2, 256);
+    {
+        const int Mi = (int)M, dm = c->dim;
+        size_t sk = bsi_gemm_splitk_workspace_bytes(Mi, 3 * dm, dm);
+        const size_t c2 = bsi_gemm_splitk_workspace_bytes(Mi, dm, dm), c3 = bsi_gemm_splitk_workspace_bytes(Mi, 4 * dm, dm),
+                     c4 = bsi_gemm_splitk_workspace_bytes(Mi, dm, 4 * dm);
+        sk = sk > c2 ? sk : c2; sk = sk > c3 ? sk : c3; sk = sk > c4 ? sk : c4;
+        w.splitk = p + off; w.splitk_bytes = sk; off += align_up(sk, 256);
+    }
     w.total = off;
     return w;
 }
@@ -152,7 +162,7 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         g.epilogue = BSI_EPI_BIAS_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_QKV, s);
-            if (int rc = bsi_gemm_bf16(&g, stream)) return rc;
+            if (int rc = bsi_gemm_bf16_ws(&g, ws.splitk, ws.splitk_bytes, stream)) return rc;
         }
         {
             ProfScope prof(BSI_PROF_ATTN, s);
@@ -166,7 +176,7 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         go.epilogue = BSI_EPI_BIAS_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_OUT, s);
-            if (int rc = bsi_gemm_bf16(&go, stream)) return rc;
+            if (int rc = bsi_gemm_bf16_ws(&go, ws.splitk, ws.splitk_bytes, stream)) return rc;
         }
         {   // x += gate_msa * delta; xn = LN(x) * (1 + scale_mlp) + shift_mlp
             ProfScope prof(BSI_PROF_LN, s);
@@ -180,7 +190,7 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         g1.epilogue = BSI_EPI_BIAS_GELU_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_FC1, s);
-            if (int rc = bsi_gemm_bf16(&g1, stream)) return rc;
+            if (int rc = bsi_gemm_bf16_ws(&g1, ws.splitk, ws.splitk_bytes, stream)) return rc;
         }
         bsi_gemm_args g2{};  // MLP output -> delta (in the now dead xn buffer)
         g2.A = ws.big; g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = ws.xn;
@@ -188,7 +198,7 @@ extern "C" int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights*
         g2.epilogue = BSI_EPI_BIAS_BF16;
         {
             ProfScope prof(BSI_PROF_GEMM_FC2, s);
-            if (int rc = bsi_gemm_bf16(&g2, stream)) return rc;
+            if (int rc = bsi_gemm_bf16_ws(&g2, ws.splitk, ws.splitk_bytes, stream)) return rc;
         }
         pend_delta = ws.xn;
         pend_gate = ml + 5 * dim;

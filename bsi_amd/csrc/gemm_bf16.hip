@@ -44,6 +44,10 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
+    // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
+    // split s multiplies the K range [s*kslice, (s+1)*kslice) and writes its partial sums to out + s*slab_stride floats
+    int splits, kslice;
+    size_t slab_stride;
 };
 
 // tile index (n-fastest order when gm == 1) -> (tm, tn).  Inside an XCD 32 consecutive tiles run together; with
@@ -1088,7 +1092,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     const int wm = wave >> 2, wn = wave & 3;
     char* scratch = lds + R * SLOT_BYTES + wave * 4096;
 
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int nwg = p.splits > 1 ? tiles_mn * p.splits : tiles_mn;
     const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
     const int wpx = (gridDim.x + 7 - xcd) >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
@@ -1105,6 +1110,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     const int srow = lane >> 2, spos = lane & 3;
     const char* gsrc[4];
     auto set_sources = [&](int t) {
+        size_t kbytes = 0;  // split-K: byte offset of this split's K range in a row of A / W
+        if (p.splits > 1) {
+            const int sp = t / tiles_mn;
+            t -= sp * tiles_mn;
+            kbytes = (size_t)sp * p.kslice * 2;
+        }
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
         const int m0 = tm_ * BM, n0 = tn_ * BN;
@@ -1116,13 +1127,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                 const int c = spos ^ ((-(r >> 2)) & 3);
                 int m = m0 + r;
                 m = m < p.M ? m : p.M - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
+                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16 + kbytes;
             } else {
                 const int rw = (slot - 16) * 16 + srow;
                 const int c = spos ^ ((-(rw >> 4)) & 3);
                 int n = n0 + rw;
                 n = n < p.N ? n : p.N - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
+                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16 + kbytes;
             }
         }
     };
@@ -1151,11 +1162,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
 
     auto epilogue = [&](int t) {
         int tm_, tn_;
+        if (p.splits > 1) {  // partial sums of split sp go to its slab
+            const int sp = t / tiles_mn;
+            tile_coords(p, t - sp * tiles_mn, tm_, tn_);
+            GemmParams q = p;
+            q.out = reinterpret_cast<float*>(p.out) + (size_t)sp * p.slab_stride;
+            wave_tile_epilogue<EPI, ABL>(q, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
+            return;
+        }
         tile_coords(p, t, tm_, tn_);
         wave_tile_epilogue<EPI, ABL>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
     };
 
-    const int nk = p.K / 32;  // launcher guarantees nk >= D
+    const int nk = (p.splits > 1 ? p.kslice : p.K) / 32;  // launcher guarantees nk >= D
     set_sources(tile);
 #pragma unroll
     for (int d = 0; d < D; ++d) stage(d, d);
@@ -1272,7 +1291,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
         {   // the store allowance of the next phases is valid only if every store of the epilogue was issued (no M / N tail)
             int tm_, tn_;
-            tile_coords(p, tile, tm_, tn_);
+            tile_coords(p, p.splits > 1 ? tile % tiles_mn : tile, tm_, tn_);
             after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 2 : 0;
         }
         if (!has_next) break;
@@ -2071,6 +2090,82 @@ int launch_epi(const GemmParams& p, hipStream_t s) {
     return launch_cfg<4, 2, 4, EPI>(p, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split-K for small M (a few images per call: 16..64 tiles on 256 CUs, each walking its whole K loop alone -- 28..75 us per GEMM
+// of pure latency).  The K range is cut into `splits` slices; tile (split, m, n) runs the K = 32 ring kernel with the fp32
+// epilogue into slab `split` of the caller's workspace, and splitk_finish_kernel sums the slabs in fixed order (deterministic),
+// adds the bias, applies the activation and rounds to bf16.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits,
+                                                            const float* __restrict__ bias, int M, int N, int ldo,
+                                                            __bf16* __restrict__ out) {
+    const int n4 = N >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), c = (int)(i % n4) * 4;
+        f32x4 a = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < splits; ++sp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)sp * slab_stride + (size_t)m * N + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+        if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = gelu_tanh_f(a[e]);
+        } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = silu_f(a[e]);
+        }
+        u32x2 w;
+        w[0] = pack_bf16x2(a[0], a[1]);
+        w[1] = pack_bf16x2(a[2], a[3]);
+        *reinterpret_cast<u32x2*>(out + (size_t)m * ldo + c) = w;
+    }
+}
+
+// number of K slices for this problem (1 = do not split): only for few tiles, K long enough, slices of whole 128-column blocks
+int splitk_plan(int M, int N, int K) {
+    if (M <= 128 || M > 2048 || K < 512 || K % 128 != 0 || N % 4 != 0) return 1;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    int best = 1;
+    for (int sp = 2; sp <= 8; sp *= 2)
+        if (K % (sp * 128) == 0 && K / sp >= 256 && tiles * sp <= num_cus()) best = sp;
+    return best;
+}
+
+template <int EPI>
+int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t s) {
+    GemmParams p = p0;
+    p.bias = nullptr;
+    p.out = workspace;
+    p.ldo = p.N;
+    p.splits = splits;
+    p.kslice = p.K / splits;
+    p.slab_stride = (size_t)p.M * p.N;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n * splits;
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const size_t lds = 4 * (size_t)512 * 64 + 32768;
+    auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32, 0, false, 4, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16_ws");
+    const size_t total = (size_t)p.M * (p.N / 4);
+    size_t g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel<EPI>, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), p.slab_stride,
+                       splits, p0.bias, p.M, p.N, p0.ldo, reinterpret_cast<__bf16*>(p0.out));
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16_ws(finish)");
+    return BSI_OK;
+}
+
 }  // namespace
 
 extern "C" int bsi_gemm_set_variant(int v) {
@@ -2125,3 +2220,34 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
             return BSI_EINVAL;
     }
 }
+
+extern "C" size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K) {
+    const int sp = splitk_plan(M, N, K);
+    return sp > 1 ? (size_t)sp * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int bsi_gemm_bf16_ws(const bsi_gemm_args* a, void* workspace, size_t workspace_bytes, bsi_stream_t stream) {
+    // small-M latency path: split-K through the caller's workspace when the shape qualifies, the epilogue is a plain bf16 one
+    // and the workspace is large enough; otherwise exactly bsi_gemm_bf16
+    if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 &&
+        a->lda >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && a->ldo >= a->N &&
+        (a->epilogue == BSI_EPI_BIAS_BF16 || a->epilogue == BSI_EPI_BIAS_GELU_BF16 || a->epilogue == BSI_EPI_BIAS_SILU_BF16)) {
+        const int sp = splitk_plan(a->M, a->N, a->K);
+        if (sp > 1 && workspace_bytes >= (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float)) {
+            GemmParams p{};
+            p.A = reinterpret_cast<const __bf16*>(a->A);
+            p.W = reinterpret_cast<const __bf16*>(a->W);
+            p.bias = a->bias;
+            p.out = a->out;
+            p.M = a->M; p.N = a->N; p.K = a->K;
+            p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
+            p.tokens = 1;
+            hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+            if (a->epilogue == BSI_EPI_BIAS_BF16) return launch_splitk<BSI_EPI_BIAS_BF16>(p, sp, workspace, s);
+            if (a->epilogue == BSI_EPI_BIAS_GELU_BF16) return launch_splitk<BSI_EPI_BIAS_GELU_BF16>(p, sp, workspace, s);
+            return launch_splitk<BSI_EPI_BIAS_SILU_BF16>(p, sp, workspace, s);
+        }
+    }
+    return bsi_gemm_bf16(a, stream);
+}
+

@@ -303,6 +303,38 @@ def test_gemm_persistent_tile_handover_full_size(N, epi_name):
     assert rel_linf(o12[rows.to(DEV)].cpu(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("M,Nn,K", [(256, 1024, 1024), (300, 3072, 1024), (1024, 1024, 4096), (2048, 4096, 1024), (512, 768, 512)])
+def test_gemm_split_k_small_m(N, M, Nn, K):
+    """bsi_gemm_bf16_ws: the split-K latency path for a few images per call against fp64 and against bsi_gemm_bf16, all three plain
+    bf16 epilogues; with too small a workspace it must fall back to the ordinary kernel (same result as bsi_gemm_bf16)."""
+    gen = torch.Generator().manual_seed(M + Nn + K)
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Nn, generator=gen)
+    ref = A.double() @ W.double().t() + bias.double()
+    dA, dW, db = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias)
+    lib = N.lib()
+    need = lib.bsi_gemm_splitk_workspace_bytes(M, Nn, K)
+    assert need > 0, "these shapes are meant to split"
+    ws = empty(need, dtype=torch.uint8)
+    for epi, fn in ((N.EPI_BIAS_BF16, lambda r: r), (N.EPI_BIAS_GELU_BF16, do.gelu_tanh), (N.EPI_BIAS_SILU_BF16, do.silu)):
+        outs = []
+        for mode in ("split", "small_ws", "plain"):
+            out = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+            a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K, ldo=Nn,
+                           epilogue=epi)
+            if mode == "split":
+                N.check(lib.bsi_gemm_bf16_ws(C.byref(a), N.ptr(ws), need, N.stream()))
+            elif mode == "small_ws":
+                N.check(lib.bsi_gemm_bf16_ws(C.byref(a), N.ptr(ws), need // 2 - 1, N.stream()))
+            else:
+                N.check(lib.bsi_gemm_bf16(C.byref(a), N.stream()))
+            outs.append(out.cpu().float())
+        assert rel_linf(outs[0], fn(ref)) < 5e-3
+        assert torch.equal(outs[1], outs[2])                                              # fallback = the ordinary kernel
+        assert float(((outs[0] - outs[2]).abs() / (outs[2].abs() + 0.05)).max()) < 1.6e-2  # split vs ordinary: a bf16 ulp
+
+
 def test_gemm_rejects_bad_shapes(N):
     a = N.GemmArgs(A=1, W=1, out=1, M=4, N=24, K=64, lda=64, ldw=64, ldo=24, epilogue=0)
     assert N.lib().bsi_gemm_bf16(C.byref(a), None) == -1

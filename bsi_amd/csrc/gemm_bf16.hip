@@ -2125,7 +2125,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 
 // number of K slices for this problem (1 = do not split): only for few tiles, K long enough, slices of whole 128-column blocks
 int splitk_plan(int M, int N, int K) {
-    if (M <= 128 || M > 2048 || K < 512 || K % 128 != 0 || N % 4 != 0) return 1;
+    // K >= 2048 only: measured (tools/experiments/splitk_time.py) fc2 (K = 4096) 72 -> 28..40 us, but the K = 1024 GEMMs get slower
+    // (22 -> 26..37 us): their K loop is already short and the fp32 slab round trip + finishing launch cost more than they save
+    if (M <= 128 || M > 2048 || K < 2048 || K % 128 != 0 || N % 4 != 0) return 1;
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
     int best = 1;
     for (int sp = 2; sp <= 8; sp *= 2)

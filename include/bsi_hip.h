@@ -203,7 +203,7 @@ typedef struct bsi_gemm_args {
     void* out2;       /* bf16 [M, ldo] (BIAS_GELU_DUAL) */
 } bsi_gemm_args;
 int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
-/* Small-M latency path: same contract, plus a caller-owned scratch buffer.  When M <= 2048, K >= 512 and the epilogue is a plain
+/* Small-M latency path: same contract, plus a caller-owned scratch buffer.  When M <= 2048, K >= 2048 and the epilogue is a plain
  * bf16 one, the K range is split over workgroups (fp32 partial sums in `workspace`, summed in fixed order) so that a GEMM of a few
  * tiles does not walk its whole K loop on a handful of CUs; otherwise (or with too small a workspace) it is bsi_gemm_bf16.
  * bsi_gemm_splitk_workspace_bytes returns the bytes that make the split possible for a shape (0 = never split). */

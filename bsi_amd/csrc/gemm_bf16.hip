@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
 //   1 = no global_load_lds in the loop, 2 = no ds_read in the loop, 4 = no epilogue, 8 = no barriers in the loop.
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
-    constexpr int TM = 8, WN = 4, NW = 8;
+    constexpr int TM = 8, NW = 8;
     constexpr int BM = 256, BN = 256;
     constexpr int ROWS = BM + BN;
     constexpr int BUF_BYTES = ROWS * ROW_BYTES;

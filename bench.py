@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Headline benchmark: images/s of BSI.sample (k=128, DiT-L/2, 3x32x32) on N MI355X GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Launched WITHOUT torchrun and with --gpus N > 1, the parent process starts N children of itself
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before it has made any GPU call, relays rank 0's JSON line and exits with
+the worst child status; it refuses (non-zero) when fewer than N devices are visible instead of measuring one GPU.
 
 One "step" = one full `BSI.sample` call (k measure/refine steps = k+1 denoiser evaluations) of `--batch`
 images per GPU, synthetic inputs (Gaussian noise from the device generator), random-init weights of the
@@ -50,9 +54,12 @@ def parse():
     ap.add_argument("--k", type=int, default=128, help="sampling steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")
-    ap.add_argument("--train-steps", type=int, default=2, help="timed optimizer steps of the train benchmark (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the train benchmark (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=512, help="GLOBAL batch of the train benchmark (split over ranks)")
     ap.add_argument("--train-timeout", type=int, default=300, help="seconds before the train benchmark is abandoned")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (UNet, DiT-L/4, ELBO)")
+    ap.add_argument("--secondary-budget", type=float, default=150.0,
+                    help="seconds the secondary block may use; entries that would not fit are reported as skipped")
     return ap.parse_args()
 
 
@@ -87,10 +94,21 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(k):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(k, reps=3):
     """CPU oracle (a port of the reference's algorithm, oracle/) on the host cores: 2 complete sampling steps
-    (denoiser evaluation + measure/refine update) + the final prediction at B=4, extrapolated to k+1
-    evaluations per image.  Bounded: 3 DiT-L/2 evaluations of 4 images (about 2 TFLOP of fp32 work)."""
+    (denoiser evaluation + measure/refine update) + the final prediction at B=4, extrapolated to k+1 evaluations per
+    image.  Protocol of BASELINE.md §4: 1 warm-up run + `reps` timed repetitions, the MEDIAN is reported, with the CPU
+    model and the thread count.  Bounded: (1 + reps) x 3 DiT-L/2 evaluations of 4 images (about 2 TFLOP of fp32 each)."""
     from oracle import bsi_oracle as bo
     from oracle import dit_oracle as do
 
@@ -104,14 +122,22 @@ def cpu_baseline(k):
     tt = torch.linspace(0, 1, k + 1)[[0, k // 2, k]]  # 2 steps taken from the k-step schedule
     eps0 = torch.randn((B, *shape), generator=g)
     eps = torch.randn((2, B, *shape), generator=g)
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        o.sample_history(eps0, eps, t=tt)          # 2 steps + final prediction = 3 evaluations
-        dt = time.perf_counter() - t0
-    per_eval = dt / 3.0
-    return {"value": B / (per_eval * (k + 1)), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32, {threads} threads) DiT-L/2, B={B}: 3 denoiser evaluations + 2 refine "
-                      f"steps in {dt:.1f} s, extrapolated to k+1={k + 1} evaluations per image"}
+        for i in range(1 + reps):
+            t0 = time.perf_counter()
+            o.sample_history(eps0, eps, t=tt)          # 2 steps + final prediction = 3 evaluations
+            dt = time.perf_counter() - t0
+            if i > 0:                                  # run 0 is the warm-up
+                times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    per_eval = med / 3.0
+    return {"value": B / (per_eval * (k + 1)), "unit": "images/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "repetitions": reps, "run_seconds": [round(t, 3) for t in times],
+            "sample": f"oracle (torch-CPU fp32, {threads} threads, {cpu_model()}) DiT-L/2, B={B}: 3 denoiser evaluations + 2 "
+                      f"refine steps, 1 warm-up + {reps} timed runs, median {med:.2f} s, extrapolated to k+1={k + 1} "
+                      "evaluations per image"}
 
 
 def train_bench(a, bsi, model, dev, world, rank, barrier):
@@ -149,17 +175,150 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
             "loss": float(loss)}
 
 
+def secondary_bench(a, bsi, dev, budget_s):
+    """Secondary workloads of SURVEY §8(d) on rank 0 at N = 1, so that they are in the driver-visible record: VDM-UNet
+    (config 2) sampling and training, DiT-L/4 64x64 k = 256 sampling (config 5) and ELBO evaluation.  `frac` = model
+    TFLOP/s / 2500 (dense bf16 peak).  Bounded by `budget_s`: an entry is skipped (and says so) once the budget is spent."""
+    from bsi_amd import BSI, Discretization
+    from bsi_amd.dp import DPTrainer
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+
+    t_start = time.perf_counter()
+    out = {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+
+    def mk(model, shape, k):
+        return BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=k, preconditioning="edm",
+                   discretization=Discretization.image_8bit()).to(dev)
+
+    def timed(fn, warm, reps=1):
+        warm()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
+
+    def entry(name, need_s, fn):
+        if left() < need_s:
+            out[name] = {"skipped": f"secondary budget ({budget_s:.0f} s) spent"}
+            return
+        try:
+            out[name] = fn()
+        except Exception as e:  # a secondary failure must not take the headline line with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    g = torch.Generator(dev).manual_seed(7)
+    t4 = lambda b_: torch.linspace(0, 1, 5, device=dev)  # noqa: E731  (4-step schedule for warm-up calls)
+
+    def elbo():
+        b = 512
+        x = (torch.randint(0, 256, (b, 3, 32, 32), device=dev).float() / 255) * 2 - 1
+        with torch.no_grad():
+            dt, (_, bpd, _) = timed(lambda: bsi.elbo(x, 1, 1, g), lambda: bsi.elbo(x[:64], 1, 1, g), reps=3)
+        assert torch.isfinite(bpd).all()
+        tf = b / dt * 2 * FWD_GFLOP_PER_IMG / 1e3
+        return {"workload": "DiT-L/2 32x32 BSI.elbo(n_recon=1, n_measure=1), 2 denoiser evaluations per image",
+                "images_per_call": b, "value": b / dt, "unit": "images/s", "model_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS}
+
+    def unet():
+        shape = (3, 32, 32)
+        torch.manual_seed(0)
+        m = DenoisingVDMUNet(shape, NyquistPositionalEmbedding(32, 100), "silu", 128, 32, 4, n_attention_heads=1,
+                             dropout=0.1, fourier_features=FourierFeatures(n_min=6, n_max=8)).to(dev).eval()
+        ub = mk(m, shape, 128)
+        b = 256
+        with torch.no_grad():
+            dt, s = timed(lambda: ub.sample(b, g), lambda: ub.sample(b, g, t=t4(b)))
+        assert torch.isfinite(s).all()
+        tf = b / dt * 129 * 53.47 / 1e3
+        res = {"sample": {"workload": "CIFAR10 VDM-UNet (dim 128, 32 levels, 1 head) BSI.sample k=128", "images_per_call": b,
+                          "value": b / dt, "unit": "images/s", "model_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS}}
+        m.train()
+        tr = DPTrainer(ub, lr=2e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+        gb = 128
+        x = (torch.randint(0, 256, (gb, *shape), device=dev).float() / 255) * 2 - 1
+        dt, loss = timed(lambda: tr.train_step(x, g), lambda: tr.train_step(x, g), reps=10)
+        assert torch.isfinite(loss)
+        tf = gb / dt * 3 * 53.47 / 1e3
+        res["train"] = {"workload": "CIFAR10 VDM-UNet train step (fwd+bwd+clip+AdamW+EMA, dropout 0.1), global batch 128",
+                        "value": 1 / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt, "model_tflops": tf,
+                        "frac": tf / PEAK_BF16_TFLOPS, "loss": float(loss)}
+        return res
+
+    def dit64():
+        shape = (3, 64, 64)
+        torch.manual_seed(0)
+        m = DenoisingDiT(shape, 4, 1024, 24, 16, dropout=0.05, fourier_features=FourierFeatures(n_min=6, n_max=8))
+        with torch.no_grad():
+            for blk in m.dit.blocks:
+                blk.adaLN_modulation[-1].weight.normal_(0, 0.02)
+        db = mk(m.to(dev).eval(), shape, 256)
+        b = 64
+        with torch.no_grad():
+            dt, s = timed(lambda: db.sample(b, g), lambda: db.sample(b, g, t=t4(b)))
+        assert torch.isfinite(s).all()
+        tf = b / dt * 257 * 161.61 / 1e3
+        return {"workload": "ImageNet64 DiT-L/4 (3x64x64) BSI.sample k=256", "images_per_call": b, "value": b / dt,
+                "unit": "images/s", "model_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS}
+
+    entry("dit_l2_elbo", 10, elbo)
+    entry("vdm_unet", 25, unet)
+    entry("dit_l4_64x64_k256", 40, dit64)
+    out["seconds"] = time.perf_counter() - t_start
+    return out
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without torchrun: start the N rank processes (one per GPU) as children of this
+    process, which itself makes NO GPU call (device_count() does not initialise the runtime on this image).  Rank 0's
+    stdout (the JSON line) is relayed; the exit status is the worst child status."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} requested but only {n_dev} GPU(s) are visible; refusing to measure fewer ranks "
+              "than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1):
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == max(a.gpus, 1) or world == 1, f"launched with WORLD_SIZE={world} but --gpus {a.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -217,9 +376,10 @@ def main():
                                    "random-init weights",
                        "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}"},
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
+            "model_frac_of_peak": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.batch),
-                         "kernel": "gemm_bf16_k64r_kernel<BSI_EPI_BIAS_GELU_BF16=2, 0> (fc1)",
+                         "kernel": N.fc1_kernel_name(),
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }
 
@@ -236,15 +396,15 @@ def main():
 
     train = None
     if a.train_steps > 0:
-        # The train measurement is secondary: if it fails or hangs (e.g. a collective mismatch on an untested topology)
-        # the sampling line is still emitted by the watchdog and the process exits.
+        # The train measurement is the second half of the metric.  If it hangs (e.g. a collective deadlock) the watchdog
+        # still emits the sampling line, marked with the error, and the process exits NON-ZERO (never a silent success).
         import threading
 
         def give_up():
             if line is not None:
                 line["train"] = {"error": "train benchmark did not finish within %d s" % a.train_timeout}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(a.train_timeout, give_up)
         dog.daemon = True
@@ -255,16 +415,22 @@ def main():
             train = {"error": f"{type(e).__name__}: {e}"}
             model.eval()
         dog.cancel()
+        torch.cuda.empty_cache()
 
+    rc = 0
     if rank == 0:
         if train is not None:
             line["train"] = train
+            rc = 4 if "error" in train else 0
+        if world == 1 and not a.no_secondary:
+            line["secondary"] = secondary_bench(a, bsi, dev, a.secondary_budget)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.k)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

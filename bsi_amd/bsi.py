@@ -324,14 +324,22 @@ class BSI(nn.Module):
         k = t.numel() - 1
         shape = (n, *self.data_shape)
         cache = self.__dict__.setdefault("_graph_cache", {})
-        key = (n, k, t.data_ptr(), t._version, native._weights_key())
+        # The captured graph bakes in raw device pointers of the bf16 weight shadows (the "pack") and of the engine
+        # workspace.  The entry OWNS both (they stay alive as long as the graph does) and the key names the pack object:
+        # a raw-kernel weight update (DPTrainer invalidates the pack without touching parameter versions) or a pack rebuilt
+        # for any other reason gives a new object -> a new capture, never a replay over freed or stale memory.
+        pack = native.native_pack()
+        key = (n, k, t.data_ptr(), t._version, native._weights_key(), id(pack))
         entry = cache.get(key)
         if entry is None:
+            cache.clear()  # one graph at a time: its private memory pool holds every intermediate of the chain
             eps0 = torch.empty(shape, **self.tensor_args)
             eps_steps = torch.empty((k, *shape), **self.tensor_args)
             eps0.normal_()
             eps_steps.normal_()
             t_static = t.detach().clone()
+            shared_ws = native._ws
+            native._ws = None  # the chain allocates a workspace of its own, which the entry keeps
             # warm-up on a side stream (lazy initialisation, function attributes, allocator pools), then capture
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -339,11 +347,14 @@ class BSI(nn.Module):
                 self._run_chain(n, None, t_static, history=False, noise=(eps0, eps_steps))
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            ws = native._ws
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 out = self._run_chain(n, None, t_static, history=False, noise=(eps0, eps_steps))
-            cache.clear()  # one graph at a time: its private memory pool holds every intermediate of the chain
-            entry = cache[key] = (g, eps0, eps_steps, out, t_static)
+            assert native._ws is ws and native.native_pack() is pack
+            if shared_ws is not None and shared_ws.numel() >= ws.numel():
+                native._ws = shared_ws  # eager calls go back to the shared workspace
+            entry = cache[key] = (g, eps0, eps_steps, out, (t_static, pack, ws))
         g, eps0, eps_steps, out, _ = entry
         torch.randn(shape, **self.tensor_args, generator=generator, out=eps0)  # the eager path's draws, in the same order
         for i in range(k):

@@ -51,10 +51,58 @@ def ema_weight(call_index: int, *, beta: float = 0.9999, update_after_step: int 
     return 1.0 - decay
 
 
-def allreduce_sum_buckets(buckets, group=None, async_op=False):
-    """Sum-all-reduce every tensor of `buckets` (device agnostic: RCCL on GPUs, gloo in the CPU tests)."""
-    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for b in buckets]
-    return works
+class GradExchange:
+    """Gradient exchange of one optimizer step over the flat gradient buffer — the ONE code path `DPTrainer.train_step`
+    runs when world > 1, written device-agnostically (RCCL on GPUs, gloo in the CPU tests).
+
+    `plan` is the ordered list of buckets `(begin, end, gate)`: the buckets are sum-all-reduced in this order; `gate` is the
+    index of the backward event the bucket has to wait for (block l of the DiT: its gradients are complete when the backward
+    has enqueued block l), or None for buckets that need the whole backward (patch encoder, decoder, or the single bucket
+    of a model without per-block events).  Replaces DDP's bucketed reducer for this path (bsi/tasks/bsi.py:163-166:
+    `DistributedDataParallel(model, static_graph=True)`); the 1/world of DDP's average is applied by the fused optimizer
+    kernel (`bsi_clip_adamw_ema`, grad_scale), not here."""
+
+    def __init__(self, plan, group=None):
+        self.plan = [(int(b), int(e), g) for b, e, g in plan if e > b]
+        self.group = group
+
+    @classmethod
+    def for_params(cls, fp, block_prefixes, group=None):
+        """Plan for a `FlatParams` layout: one bucket per prefix of `block_prefixes` (in forward order; reduced LAST block
+        first, as the backward completes them, gate = block index), then everything before the first block and everything
+        after the last one as two ungated buckets.  With no block prefixes: one ungated bucket over the whole buffer."""
+        n = fp.flat.numel()
+        if not block_prefixes:
+            return cls([(0, n, None)], group)
+        spans = [fp.span(pre) for pre in block_prefixes]
+        for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
+            assert e0 == b1, "block parameter spans must be adjacent in the flat buffer"
+        plan = [(b, e, l) for l, (b, e) in reversed(list(enumerate(spans)))]
+        plan += [(0, spans[0][0], None), (spans[-1][1], n, None)]
+        return cls(plan, group)
+
+    def covers(self, n):
+        """True when the buckets tile [0, n) exactly once."""
+        pos = 0
+        for b, e, _ in sorted(self.plan):
+            if b != pos:
+                return False
+            pos = e
+        return pos == n
+
+    def run(self, flat_g, wait_gate=None, wait_all=None):
+        """All-reduce (sum) every bucket of `flat_g` in plan order.  `wait_gate(l)` is called before the first bucket gated
+        on event l, `wait_all()` once before the first ungated bucket (on GPUs: stream waits; in a synchronous backward they
+        may be None)."""
+        waited_all = False
+        for b, e, gate in self.plan:
+            if gate is None:
+                if not waited_all and wait_all is not None:
+                    wait_all()
+                waited_all = True
+            elif wait_gate is not None:
+                wait_gate(gate)
+            dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
 
 
 class FlatParams:
@@ -108,16 +156,23 @@ class DPTrainer:
         self.fp = FlatParams(self.model)
         self.ema_fp = FlatParams(self.ema_model) if ema else None
         dev = self.fp.flat.device
+        self._setup_update_state(dev)
+        self.bucketed = hasattr(self.model, "dit")
+        depth = len(self.model.dit.blocks) if self.bucketed else 0
+        self.xchg = GradExchange.for_params(self.fp, [f"dit.blocks.{i}." for i in range(depth)], process_group)
+        assert self.xchg.covers(self.fp.flat.numel())
+        self.last_grad_norm = None
+        self._setup_exchange_state(dev, depth)
+
+    # -- stages of a step: each is one method so that the host logic (order of stages, bucket plan, gates, 1/world) is
+    #    testable with world-size-2 gloo processes that substitute the two device stages (tests/test_dp_host.py)
+    def _setup_update_state(self, dev):
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sq_ws = torch.empty(N.lib().bsi_sqnorm_workspace_bytes(), dtype=torch.uint8, device=dev)
-        self.bucketed = hasattr(self.model, "dit")
-        depth = len(self.model.dit.blocks) if self.bucketed else 0
-        self.block_spans = [self.fp.span(f"dit.blocks.{i}.") for i in range(depth)]
-        if self.bucketed:
-            self.head_span = (0, self.block_spans[0][0])                     # patch encoder
-            self.tail_span = (self.block_spans[-1][1], self.fp.flat.numel())  # decoder
+
+    def _setup_exchange_state(self, dev, depth):
         self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
         self.events = None
         if self.exchange and self.bucketed:
@@ -125,15 +180,10 @@ class DPTrainer:
             for e in self.events:
                 e.record()  # instantiate the underlying hipEvent_t
             self._ev_arr = (C.c_void_p * depth)(*[C.c_void_p(e.cuda_event) for e in self.events])
-        self.last_grad_norm = None
 
-    # ------------------------------------------------------------------------------------------------
-    def _invalidate(self, model):
-        model._pack = None
-        model._pack_t = None
-
-    def train_step(self, x: torch.Tensor, generator=None) -> torch.Tensor:
-        """One optimizer step on this rank's shard `x`; returns the (local) mean loss (detached)."""
+    def _backward(self, x, generator):
+        """BSI.train_loss + the HIP backward on this rank's shard: (mean loss, flat fp32 gradient in FlatParams order).
+        With the exchange on, the backward records event l when block l's gradients are enqueued."""
         lib = N.lib()
         for p in self.model.parameters():
             p.grad = None
@@ -142,39 +192,54 @@ class DPTrainer:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
         loss = self.bsi.train_loss(x, generator).mean()
         loss.backward()
+        if self.exchange and self.bucketed:
+            N.check(lib.bsi_dit_backward_set_events(None, 0))
         flat_g = self.model._last_flat_grad
         assert flat_g is not None, "the HIP training engine did not run (model is not a native denoiser?)"
-        if self.exchange and not self.bucketed:
-            cur = torch.cuda.current_stream()
-            self.comm_stream.wait_stream(cur)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            cur.wait_stream(self.comm_stream)
-        elif self.exchange:
-            N.check(lib.bsi_dit_backward_set_events(None, 0))
-            cur = torch.cuda.current_stream()
-            with torch.cuda.stream(self.comm_stream):
-                # blocks finish last-to-first; each bucket starts when its event fires, overlapping the backward
-                for l in reversed(range(len(self.events))):
-                    self.comm_stream.wait_event(self.events[l])
-                    b, e = self.block_spans[l]
-                    dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
-                self.comm_stream.wait_stream(cur)  # encoder/decoder gradients are complete when the backward is
-                for b, e in (self.head_span, self.tail_span):
-                    if e > b:
-                        dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
-            cur.wait_stream(self.comm_stream)
+        return loss, flat_g
+
+    def _gate_wait(self, l):
+        self.comm_stream.wait_event(self.events[l])
+
+    def _exchange(self, flat_g):
+        """Sum the gradient over the ranks, bucket by bucket (GradExchange.plan).  On GPUs the collectives run on a side
+        stream: blocks finish last-to-first and each bucket starts when its event fires, overlapping the rest of the
+        backward; encoder / decoder gradients (and the UNet's single bucket) wait for the whole backward."""
+        if not flat_g.is_cuda:
+            self.xchg.run(flat_g, wait_gate=self._gate_wait, wait_all=None)
+            return
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.comm_stream):
+            self.xchg.run(flat_g, wait_gate=self._gate_wait, wait_all=lambda: self.comm_stream.wait_stream(cur))
+        cur.wait_stream(self.comm_stream)
+
+    def _update(self, flat_g, lr, ema_w):
+        """Global-norm clip + AdamW + EMA on the flat buffers; `flat_g` holds the SUM over ranks, the 1/world of the
+        average is folded into the kernel's gradient scale."""
+        lib = N.lib()
         n = flat_g.numel()
-        lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
         N.check(lib.bsi_grad_sqnorm(N.ptr(flat_g), n, N.ptr(self.sq), N.ptr(self.sq_ws), N.stream()))
-        w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
-        self.step_count += 1
         N.check(lib.bsi_clip_adamw_ema(N.ptr(self.fp.flat), N.ptr(flat_g), N.ptr(self.m), N.ptr(self.v),
                                        N.ptr(self.ema_fp.flat) if self.ema_fp else None, n, N.ptr(self.sq),
                                        float(self.max_grad_norm or 0.0), 1.0 / self.world, lr, self.betas[0],
-                                       self.betas[1], self.eps, self.weight_decay, self.step_count, w, N.stream()))
+                                       self.betas[1], self.eps, self.weight_decay, self.step_count, ema_w, N.stream()))
+        self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
+
+    # ------------------------------------------------------------------------------------------------
+    def _invalidate(self, model):
+        model._pack = None
+        model._pack_t = None
+
+    def train_step(self, x: torch.Tensor, generator=None) -> torch.Tensor:
+        """One optimizer step on this rank's shard `x`; returns the (local) mean loss (detached)."""
+        loss, flat_g = self._backward(x, generator)
+        if self.exchange:
+            self._exchange(flat_g)
+        lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
+        w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
+        self.step_count += 1
+        self._update(flat_g, lr, w)
         self._invalidate(self.model)
         if self.ema_model is not None:
             self._invalidate(self.ema_model)
-        self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
         return loss.detach()

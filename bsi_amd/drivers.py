@@ -182,7 +182,8 @@ def to_lightning_state_dict(model, ema_model=None, *, ema_step: int | None = Non
     """The `state_dict` a reference task would save for these weights (keys of SURVEY Appendix C)."""
     out = {MODEL_PREFIX + k: v.detach().cpu() for k, v in model.state_dict().items()}
     if ema_model is not None:
-        out.update({EMA_PREFIX + k: v.detach().cpu() for k, v in ema_model.state_dict().items()})
         if ema_step is not None:
-            out[EMA_EXTRA] = {"initted": ema_step > 0, "step": int(ema_step)}  # EMA.get_extra_state (ema_pytorch.py:196-197)
+            # EMA.get_extra_state (ema_pytorch.py:196-197); a module's extra state precedes its children's entries
+            out[EMA_EXTRA] = {"initted": ema_step > 0, "step": int(ema_step)}
+        out.update({EMA_PREFIX + k: v.detach().cpu() for k, v in ema_model.state_dict().items()})
     return out

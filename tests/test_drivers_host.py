@@ -133,3 +133,94 @@ def test_lightning_checkpoint_keys_round_trip():
         raise AssertionError("missing EMA weights accepted")
     except KeyError:
         pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Reference-derived fixtures (tests/golden/g12_drivers.npz, tools/gen_golden_drivers.py: the reference's own statements
+# executed in the build container)
+# ----------------------------------------------------------------------------------------------------------------------
+def _g12():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_drivers.npz"))
+    return z
+
+
+def test_schedules_vs_reference_generate_samples():
+    """scripts/generate_samples.py:117-152 executed by the generator for linear / cosine / edm / edm7 at k in {8, 128}."""
+    z = _g12()
+    b = _FakeBSI()
+    for k in (8, 128):
+        for name in D.SCHEDULES:
+            ref = z[f"sched_{name}_{k}"]
+            got = D.sampling_schedule(b, name, k).numpy()
+            assert got.dtype == ref.dtype == np.float32 and got.shape == ref.shape
+            # same fp32 operation sequence; LogUniformOracle.cdf follows bsi.py:80-81
+            assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= 2e-7, (name, k)
+
+
+class _Recorded:
+    def __init__(self, z, sizes):
+        self.z, self.pos, self.sizes, self.calls = z, {}, sizes, []
+
+    def _next(self, key, x):
+        i = self.pos.get(key, 0)
+        self.pos[key] = i + 1
+        bpd, var = torch.from_numpy(self.z[f"elbo_rec_{key}_{i}_bpd"]), torch.from_numpy(self.z[f"elbo_rec_{key}_{i}_var"])
+        assert len(bpd) == len(x)
+        return -bpd, bpd, {"bpd_var": var}
+
+    lambda_0 = torch.tensor(1e-2)
+
+    def elbo(self, x, r, m, generator=None, *, estimate_var=False):
+        self.calls.append(["inf", len(x), r, m, bool(estimate_var)])
+        return self._next("inf", x)
+
+    def finite_elbo(self, x, r, m, generator=None, *, t=None, estimate_var=False):
+        self.calls.append([len(t) - 1, len(x), r, m, bool(estimate_var), [float(t[0]), float(t[-1])]])
+        return self._next(len(t) - 1, x)
+
+
+def test_elbo_bookkeeping_vs_reference_eval_elbo():
+    """scripts/eval_elbo.py:119-173 (loop + results dictionary) executed by the generator on recorded per-sample arrays:
+    same call sequence, same means, same variance of the mean, same JSON."""
+    z = _g12()
+    sizes = [int(n) for n in z["elbo_batch_sizes"]]
+    ks = ["inf", 8, 32]
+    fake = _Recorded(z, sizes)
+    batches = [(torch.zeros(n, 3, 4, 4), torch.zeros(n)) for n in sizes]
+    acc = D.evaluate_elbo(fake, batches, 2, 3, ks)
+    assert fake.calls == json.loads(str(z["elbo_calls_json"]))
+    for k in ks:
+        assert abs(acc[k].mean() - float(z[f"elbo_mean_{k}"])) <= 1e-15 * abs(float(z[f"elbo_mean_{k}"])) + 1e-15
+        assert abs(acc[k].mean_var() - float(z[f"elbo_mean_var_{k}"])) <= 1e-12 * float(z[f"elbo_mean_var_{k}"])
+    res = D.elbo_results(acc, ckpt="run/last.ckpt", split="test", r_samples=2, m_samples=3, ks=ks, overrides=["a=b"])
+    ref = json.loads(str(z["elbo_results_json"]))
+    got = json.loads(json.dumps(res))
+    assert got["ckpt"] == ref["ckpt"] and got["config"] == ref["config"]
+    assert set(got) == set(ref) and set(got["bpd_means"]) == set(ref["bpd_means"]) == {"inf", "8", "32"}
+    for sect in ("bpd_means", "bpd_mean_vars"):
+        for k in ref[sect]:
+            assert abs(got[sect][k] - ref[sect][k]) <= 1e-12 * abs(ref[sect][k])
+
+
+def test_checkpoint_keys_vs_reference_ema_state_dict():
+    """Key list, shapes and `_extra_state` of a reference task-shaped module {model, ema_model = create_ema(model)}
+    (bsi/tasks/bsi.py:73-81, ema_pytorch.py:196-201) against `to_lightning_state_dict` / `load_lightning_checkpoint`."""
+    z = _g12()
+    from bsi_amd.models.dit import DenoisingDiT
+    from bsi_amd.nn import FourierFeatures
+    mk = lambda: DenoisingDiT((3, 16, 16), 2, 128, 2, 2, dropout=None, fourier_features=FourierFeatures(n_min=6, n_max=8))  # noqa: E731
+    torch.manual_seed(1)
+    m, e = mk(), mk()
+    sd = D.to_lightning_state_dict(m, e, ema_step=5)
+    ref_keys = json.loads(str(z["ckpt_keys_json"]))
+    assert list(sd.keys()) == ref_keys                       # same keys in the same order
+    shapes = json.loads(str(z["ckpt_shapes_json"]))
+    assert {k: list(v.shape) for k, v in sd.items() if hasattr(v, "shape")} == shapes
+    assert sd["ema_model._extra_state"] == json.loads(str(z["ckpt_extra_state_5_json"]))
+    assert D.to_lightning_state_dict(m, e, ema_step=0)["ema_model._extra_state"] == json.loads(str(z["ckpt_extra_state_0_json"]))
+    m2, e2 = mk(), mk()
+    extra = D.load_lightning_checkpoint({"state_dict": sd}, m2, e2)
+    assert extra == {"initted": True, "step": 5}
+    for (n1, p1), (_, p2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(p1, p2), n1

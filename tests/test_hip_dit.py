@@ -620,3 +620,35 @@ def test_sample_graph_replay_matches_eager():
             b = bsi.sample(3, torch.Generator(dev).manual_seed(seed), graph=True)
             assert torch.equal(a, b)
         assert not torch.equal(a, bsi.sample(3, torch.Generator(dev).manual_seed(7), graph=True))
+
+
+def test_sample_graph_survives_weight_update_and_workspace_growth():
+    """the captured graph holds raw pointers to the bf16 weight shadows and the workspace.  After a DPTrainer step
+    (weights change through a raw kernel: no parameter version bump) and after an eager call with a larger batch (workspace
+    reallocated) a graphed sample must still equal the eager one bit for bit."""
+    from bsi_amd.dp import DPTrainer
+    g = golden("g4_train_dit")
+    model = make_model("dit_ff", True)
+    bsi = make_bsi(model, k=6)
+    dev = torch.device(DEV, 0)
+
+    def pair(seed):
+        with torch.no_grad():
+            a = bsi.sample(3, torch.Generator(dev).manual_seed(seed))
+            b = bsi.sample(3, torch.Generator(dev).manual_seed(seed), graph=True)
+        return a, b
+
+    a0, b0 = pair(5)
+    assert torch.equal(a0, b0)
+    with torch.no_grad():
+        bsi.sample(16, torch.Generator(dev).manual_seed(1))          # larger batch: the shared workspace is reallocated
+    a1, b1 = pair(5)
+    assert torch.equal(a1, b1) and torch.equal(a1, a0)
+    model.train()
+    tr = DPTrainer(bsi, lr=5e-2, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        tr.train_step(g["x"].to(DEV))
+    model.eval()
+    a2, b2 = pair(5)
+    assert torch.equal(a2, b2)
+    assert not torch.equal(a2, a0)                                   # the weights did change

@@ -35,3 +35,36 @@ def rel_l2(a, b):
 def max_rel(a, b, floor=0.0):
     a, b = a.double().cpu(), b.double().cpu()
     return float(((a - b).abs() / b.abs().clamp_min(floor if floor > 0 else 1e-30)).max())
+
+
+CALIB = dict(shape=(3, 32, 32), patch_size=4, dim=128, depth=4, heads=2, ff=(6, 8), seed=11, B=64)
+
+
+def calib_weights():
+    """Weights of the SURVEY Appendix F calibration model (g11_calib_dit): a seeded torch-CPU stream from
+    oracle.dit_oracle.dit_random_weights, checked against the fingerprint the golden generator stored."""
+    from oracle import dit_oracle as do
+    c = CALIB
+    W = do.dit_random_weights(c["shape"], c["patch_size"], c["dim"], c["depth"], ff=c["ff"], seed=c["seed"])
+    fp = torch.stack([torch.stack((v.double().sum(), v.double().abs().sum(), v.flatten()[0].double(),
+                                   v.flatten()[-1].double())) for _, v in sorted(W.items())])
+    ref = golden("g11_calib_dit")["weight_fingerprint"]
+    assert torch.allclose(fp, ref, rtol=1e-12, atol=0), "seeded weight stream differs from the one the golden was made with"
+    return W
+
+
+def report(name, **values):
+    """Record achieved parity errors: printed (visible with -rA / -s) and appended to gpurun_out/parity_report.jsonl so
+    that the numbers behind a green assertion are on file (copied to profiles/ per round)."""
+    import json
+    rec = {"test": name, **{k: (float(v) if not isinstance(v, (str, int, list, dict)) else v) for k, v in values.items()}}
+    line = json.dumps(rec)
+    print("PARITY " + line)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return rec

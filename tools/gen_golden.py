@@ -379,6 +379,56 @@ def g8_optimizer():
     save("g8_optimizer", ema_steps=np.array(steps), ema_decays=np.array(decays), lr_schedule=np.array(lrs), **rec)
 
 
+def g11_calibration():
+    """SURVEY Appendix F calibration point: DiT dim 128, depth 4, heads 2, patch 4 on 3x32x32, adaLN un-zeroed, B = 64.
+    The weights are NOT stored: they are `oracle.dit_oracle.dit_random_weights(..., seed=11)` (a seeded torch-CPU
+    stream), loaded into the reference class here; the fixture holds a fingerprint of them so that a drifting RNG is
+    noticed.  Expected values: the reference's fp32 `train_loss` (per sample), the same in fp64, the gradient norm
+    per parameter tensor, and teacher-forced `_predict_x` at 8 times (fp32 and fp64)."""
+    import copy
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import dit_oracle as do
+    shape, ps, dim, depth, heads, B = (3, 32, 32), 4, 128, 4, 2, 64
+    W = do.dit_random_weights(shape, ps, dim, depth, ff=(6, 8), seed=11)
+    model = ref.dit.DenoisingDiT(shape, ps, dim, depth, heads, dropout=None,
+                                 fourier_features=ref.nn.FourierFeatures(n_min=6, n_max=8))
+    model.load_state_dict(W)
+    model.eval()
+    b = make_bsi(model, shape, k=128)
+    x = data(B, shape, 110)
+    g = torch.Generator().manual_seed(111)
+    loss = b.train_loss(x, g)
+    model.zero_grad()
+    loss.mean().backward()
+    gnorms = {"GN." + k: p.grad.double().norm() for k, p in model.named_parameters()}
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))
+    g = torch.Generator().manual_seed(111)
+    off = torch.rand((), generator=g)
+    perm = torch.randperm(B, generator=g)
+    eps = torch.randn((B, *shape), generator=g)
+    m64 = copy.deepcopy(model).double()
+    b64 = make_bsi(m64, shape, k=128, dtype=torch.float64)
+    lam64 = b64.p_lambda.icdf(torch.remainder(perm.double() / (1 + B) + off.double(), 1))
+    mu64 = torch.addcmul(((lam64 - b64.lambda_0) / lam64).view(-1, 1, 1, 1) * x.double(),
+                         torch.rsqrt(lam64).view(-1, 1, 1, 1), eps.double())
+    with torch.no_grad():
+        xh64 = b64._predict_x(mu64, b64.p_lambda.cdf(lam64))
+        loss64 = b64.p_lambda.reciprocal_pdf(lam64) * (x.double() - xh64).square().flatten(1).mean(1)
+        # teacher-forced one-step predictions
+        gt = torch.Generator().manual_seed(112)
+        tt = torch.tensor([0.0, 0.05, 0.2, 0.4, 0.6, 0.8, 0.95, 1.0])
+        lam_t = b.p_lambda.icdf(tt)
+        xs = data(len(tt), shape, 113)
+        mu_t = torch.addcmul(((lam_t - b.lambda_0) / lam_t).view(-1, 1, 1, 1) * xs, torch.rsqrt(lam_t).view(-1, 1, 1, 1),
+                             torch.randn((len(tt), *shape), generator=gt))
+        xh_t = b._predict_x(mu_t, tt)
+        xh_t64 = b64._predict_x(mu_t.double(), tt.double())
+    fp = torch.stack([torch.stack((v.double().sum(), v.double().abs().sum(), v.flatten()[0].double(),
+                                   v.flatten()[-1].double())) for _, v in sorted(W.items())])
+    save("g11_calib_dit", x=x, offset=off, perm=perm, eps=eps, loss=loss, loss_mean=loss.mean(), loss_fp64=loss64,
+         grad_norm=gn, weight_fingerprint=fp, tf_t=tt, tf_mu=mu_t, tf_xhat=xh_t, tf_xhat64=xh_t64, **gnorms)
+
+
 def kat_reference_tests():
     """Inputs/expected values of the reference's own four known-answer tests
     (tests/test_bsi.py:7-34, tests/models/components/test_fourier_features.py:9-28) evaluated
@@ -401,6 +451,10 @@ def kat_reference_tests():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:  # regenerate only the named sets, e.g. `python tools/gen_golden.py g11_calibration`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     g1_tables()
     g2_g3_lambda_and_q()
     g4_train_loss()
@@ -408,4 +462,5 @@ if __name__ == "__main__":
     g6_elbo()
     g7_components()
     g8_optimizer()
+    g11_calibration()
     kat_reference_tests()

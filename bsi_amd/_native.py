@@ -163,6 +163,7 @@ _PROTOS = {
     "bsi_attention_bwd_long": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "bsi_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "bsi_ln_mod_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "bsi_ln_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "bsi_silu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bsi_cast_transpose_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "bsi_cast_rows_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),

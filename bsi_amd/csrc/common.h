@@ -58,6 +58,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Wave-wide sums on the DPP / lane-swap path (no LDS traffic, ~10x shorter than the __shfl_xor chain): quad permutes and
+// row mirrors sum each 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950) combine the four rows.  Every lane ends
+// with the total.  The association differs from wave_sum, so results agree with it to fp32 rounding, not bit for bit.
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_xadd<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_xadd<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_xadd<0x141>(v);  // row_half_mirror
+    v = dpp_xadd<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float rows_sum(float v) {  // sum over the four 16-lane rows of values that are uniform per row
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float wave_sum_fast(float v) { return rows_sum(row16_sum(v)); }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

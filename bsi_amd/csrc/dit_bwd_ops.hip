@@ -210,6 +210,174 @@ __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* _
     }
 }
 
+// Fused residual-path backward of one LayerNorm-modulate and the gated residual add below it (dit.py:50-55,93-102), for the
+// training tape that keeps the LayerNorm INPUT x (fp32) and its (mean, rstd) per row.  One pass over a row:
+//   LN part   (dxn != null):  n = (x - mean) * rstd;  g = dropout(dxn);  dshift[b] += sum_t g;  dscale[b] += sum_t g*n;
+//                             dn = g * (1 + scale);   dX += rstd * (dn - mean(dn) - n * mean(dn * n))
+//   gate part (delta != null, x_below = x - gate*delta is not needed: the tape holds every LayerNorm input):
+//                             ddelta = bf16(gate * dX);  dgate[b] += sum_t dX * delta
+// Bytes per element: dxn 2 + x 4 + dX 4 + delta 2 read, dX 4 + ddelta 2 written = 18 (the separate kernels moved 30 and
+// rewound x in place).  One wave per row, 16 rows per wave, 64 rows per workgroup; all loads of a row are issued before the
+// first use; the two row reductions run on the DPP / lane-swap path; the per-sample column sums are kept in registers over
+// the wave's rows, reduced through LDS and added with one fp32 atomic per element per 64-row slab.
+constexpr int FRW = 16;         // rows per wave
+constexpr int FRB = 4 * FRW;    // rows per workgroup
+
+template <int VPL, bool HAS_LN, bool HAS_GATE>
+__global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
+    const __bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats,
+    const float* __restrict__ scale, int mod_stride, float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride,
+    float* dX, const __bf16* __restrict__ delta, const float* __restrict__ gate, int gate_stride, float* __restrict__ dgate,
+    int dgate_stride, __bf16* __restrict__ ddelta, int M, int d, int tokens, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][nacc][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * FRB;
+    const int b = row0 / tokens;
+    const int d4 = d >> 2;
+    const float inv_d = 1.0f / (float)d;
+    f32x4 sc1[VPL], gt[VPL], ash[VPL], asc[VPL], agt[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        sc1[i] = z; gt[i] = z; ash[i] = z; asc[i] = z; agt[i] = z;
+        if (c < d4) {
+            if constexpr (HAS_LN) {
+                const f32x4 s = reinterpret_cast<const f32x4*>(scale + (size_t)b * mod_stride)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sc1[i][k] = s[k] + 1.0f;
+            }
+            if constexpr (HAS_GATE) gt[i] = reinterpret_cast<const f32x4*>(gate + (size_t)b * gate_stride)[c];
+        }
+    }
+    for (int r = 0; r < FRW; ++r) {
+        const int row = row0 + wave * FRW + r;
+        if (row >= M) break;
+        f32x4 xv[VPL], gv[VPL], dxv[VPL], dlv[VPL];
+        float mean = 0.f, rstd = 0.f;
+        if constexpr (HAS_LN) {
+            mean = stats[2 * (size_t)row];
+            rstd = stats[2 * (size_t)row + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            xv[i] = z; gv[i] = z; dxv[i] = z; dlv[i] = z;
+            if (c < d4) {
+                dxv[i] = reinterpret_cast<const f32x4*>(dX + (size_t)row * d)[c];
+                if constexpr (HAS_LN) {
+                    xv[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
+                    gv[i] = bf16x4_to_f32(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d) + c));
+                }
+                if constexpr (HAS_GATE)
+                    dlv[i] = bf16x4_to_f32(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)row * d) + c));
+            }
+        }
+        if constexpr (HAS_LN) {
+            float s1 = 0.f, s2 = 0.f;
+            const unsigned rh = dc.thr ? drop_row(dc, (unsigned)row) : 0u;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float g = gv[i][k];
+                        if (dc.thr) g = drop_keep_rc(dc, rh, (unsigned)c * 4 + k) ? g * dc.scale : 0.0f;  // forward's mask
+                        const float n = (xv[i][k] - mean) * rstd;
+                        ash[i][k] += g;
+                        asc[i][k] = __fmaf_rn(g, n, asc[i][k]);
+                        const float dn = g * sc1[i][k];
+                        xv[i][k] = n;
+                        gv[i][k] = dn;
+                        s1 += dn;
+                        s2 = __fmaf_rn(dn, n, s2);
+                    }
+                }
+            }
+            s1 = row16_sum(s1);
+            s2 = row16_sum(s2);
+            const float m1 = rows_sum(s1) * inv_d, m2 = rows_sum(s2) * inv_d;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dxv[i][k] += rstd * (gv[i][k] - m1 - xv[i][k] * m2);
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                if constexpr (HAS_LN) reinterpret_cast<f32x4*>(dX + (size_t)row * d)[c] = dxv[i];
+                if constexpr (HAS_GATE) {
+                    f32x4 dd;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dd[k] = gt[i][k] * dxv[i][k];
+                        agt[i][k] = __fmaf_rn(dxv[i][k], dlv[i][k], agt[i][k]);
+                    }
+                    __builtin_nontemporal_store(f32x4_to_bf16(dd), reinterpret_cast<u32x2*>(ddelta + (size_t)row * d) + c);
+                }
+            }
+        }
+    }
+    // per-sample column sums: waves 1..3 -> LDS -> wave 0 -> one atomic per element
+    constexpr int NACC = (HAS_LN ? 2 : 0) + (HAS_GATE ? 1 : 0);
+    if (wave > 0) {
+        float* my = red + (size_t)(wave - 1) * NACC * d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                int a = 0;
+                if constexpr (HAS_LN) {
+                    reinterpret_cast<f32x4*>(my)[c] = ash[i];
+                    reinterpret_cast<f32x4*>(my + d)[c] = asc[i];
+                    a = 2;
+                }
+                if constexpr (HAS_GATE) reinterpret_cast<f32x4*>(my + (size_t)a * d)[c] = agt[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 t0 = ash[i], t1 = asc[i], t2 = agt[i];
+                for (int w = 0; w < 3; ++w) {
+                    const float* o = red + (size_t)w * NACC * d;
+                    int a = 0;
+                    if constexpr (HAS_LN) {
+                        const f32x4 o0 = reinterpret_cast<const f32x4*>(o)[c];
+                        const f32x4 o1 = reinterpret_cast<const f32x4*>(o + d)[c];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { t0[k] += o0[k]; t1[k] += o1[k]; }
+                        a = 2;
+                    }
+                    if constexpr (HAS_GATE) {
+                        const f32x4 o2 = reinterpret_cast<const f32x4*>(o + (size_t)a * d)[c];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t2[k] += o2[k];
+                    }
+                }
+                if constexpr (HAS_LN) {
+                    float* d0 = dshift + (size_t)b * dmod_stride + c * 4;
+                    float* d1 = dscale + (size_t)b * dmod_stride + c * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { atomicAdd(d0 + k, t0[k]); atomicAdd(d1 + k, t1[k]); }
+                }
+                if constexpr (HAS_GATE) {
+                    float* d2 = dgate + (size_t)b * dgate_stride + c * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(d2 + k, t2[k]);
+                }
+            }
+        }
+    }
+}
+
 // Backward of dit.py:163-172,181 + bsi.py:382-386: given g_xhat [B,C,H,W] (gradient of x_hat = c_skip*mu + c_out*f):
 //   dY[token, o] = c_out[b] * g_xhat[b, ch, hh, ww]  (patchify order), y = LN_affine(x) (fp32)
 //   dy = sum_o dY[o] * Wdec[o,:],  dlnw += dy * n, dlnb += dy,  dbdec[o] += dY[o],
@@ -417,6 +585,47 @@ extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scal
                               float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps,
                               bsi_stream_t stream) {
     return bsi_ln_mod_bwd_drop(dxn, x, scale, mod_stride, dshift, dscale, dmod_stride, dX, M, d, tokens, eps, DropCfg{}, stream);
+}
+
+// Fused LayerNorm-modulate backward + gated-residual backward (see ln_gate_bwd_kernel).  Either part may be absent:
+// dxn == NULL: gate part only (top of the network); delta == NULL: LayerNorm part only (bottom of the network).
+int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
+                         float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
+                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream) {
+    const bool ln = dxn != nullptr, gt = delta != nullptr;
+    BSI_CHECK_ARG(dX && (ln || gt), "bsi_ln_gate_bwd: nothing to do");
+    BSI_CHECK_ARG(!ln || (x && stats && scale && dshift && dscale), "bsi_ln_gate_bwd: LayerNorm part needs x, stats, scale, dshift, dscale");
+    BSI_CHECK_ARG(!gt || (gate && dgate && ddelta), "bsi_ln_gate_bwd: gate part needs gate, dgate, ddelta");
+    BSI_CHECK_ARG(M > 0 && d % 4 == 0 && d <= 1024 && tokens % FRB == 0 && M % tokens == 0,
+                  "bsi_ln_gate_bwd: M=%d d=%d (<= 1024) tokens=%d (tokens must be a multiple of %d)", M, d, tokens, FRB);
+    dim3 grid(M / FRB);
+    const __bf16* g = reinterpret_cast<const __bf16*>(dxn);
+    const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
+    __bf16* dd = reinterpret_cast<__bf16*>(ddelta);
+    const size_t lds = (size_t)3 * ((ln ? 2 : 0) + (gt ? 1 : 0)) * d * sizeof(float);
+#define LGB(V, L, G)                                                                                                         \
+    hipLaunchKernelGGL((ln_gate_bwd_kernel<V, L, G>), grid, dim3(TPB), lds, S(stream), g, x, stats, scale, mod_stride, dshift,   \
+                       dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc)
+#define LGB_V(L, G)                   \
+    do {                              \
+        if (d <= 256) LGB(1, L, G);   \
+        else LGB(4, L, G);            \
+    } while (0)
+    if (ln && gt) LGB_V(true, true);
+    else if (ln) LGB_V(true, false);
+    else LGB_V(false, true);
+#undef LGB_V
+#undef LGB
+    BSI_CHECK_LAUNCH("bsi_ln_gate_bwd");
+    return BSI_OK;
+}
+
+extern "C" int bsi_ln_gate_bwd(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride,
+                               float* dshift, float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate,
+                               int gate_stride, float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens,
+                               bsi_stream_t stream) {
+    return bsi_ln_gate_bwd_drop(dxn, x, stats, scale, mod_stride, dshift, dscale, dmod_stride, dX, delta, gate, gate_stride, dgate,
+                                dgate_stride, ddelta, M, d, tokens, DropCfg{}, stream);
 }
 
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,

@@ -58,11 +58,13 @@ template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
 __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
                                    const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                   const __bf16* delta, const float* __restrict__ gate, __bf16* out, DropCfg dc) {
+                                   const __bf16* delta, const float* __restrict__ gate, __bf16* out, DropCfg dc,
+                                   float* x_out, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    float* xr = x + (size_t)row * d;
+    const float* xr = x + (size_t)row * d;
+    float* xw = (x_out ? x_out : x) + (size_t)row * d;  // training tape: the updated row goes to its own slot
     const int d4 = d >> 2;
     const int mrow = (shift || gate) ? (row / tokens) % mod_rows : 0;
     f32x4 v[VPL];
@@ -78,7 +80,7 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
             v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
             v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
             v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
-            reinterpret_cast<f32x4*>(xr)[c] = v[i];
+            reinterpret_cast<f32x4*>(xw)[c] = v[i];
         }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
@@ -97,6 +99,10 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    if (stats && lane == 0) {  // kept for the backward (bsi_ln_gate_bwd)
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = rstd;
+    }
     const float* sh = shift ? shift + (size_t)mrow * mod_stride : nullptr;
     const float* sc = scale ? scale + (size_t)mrow * mod_stride : nullptr;
     __bf16* orow = out + (size_t)row * d;
@@ -386,7 +392,8 @@ extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, c
 
 int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
                                const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
-                               const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream) {
+                               const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream,
+                               float* x_out, float* stats) {
     BSI_CHECK_ARG(x && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_resid_ln_modulate: bad args M=%d d=%d", M, d);
     BSI_CHECK_ARG(out_bf16 || delta, "bsi_resid_ln_modulate: nothing to do");
     BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_resid_ln_modulate: shift and scale go together");
@@ -400,13 +407,13 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
     const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
     else if (d <= 1024)
         hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
     else
         hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
     BSI_CHECK_LAUNCH("bsi_resid_ln_modulate");
     return BSI_OK;
 }

@@ -3,8 +3,10 @@
 // bsi/tasks/bsi.py:187-194).  Host-side sequencing only; no allocation, no synchronisation.
 //
 // Tape per block and token row (bf16 unless noted): xn1 [d], qkv [3d], lse (fp32 per head), ao [d], d1 [d], xn2 [d],
-// hp [4d] (pre-GELU), h [4d], d2 [d]  = 16 d elements = 32 KB per token at d = 1024 (8 MB per image per block).
-// Only the FINAL residual stream is kept in fp32: the backward rewinds it block by block (x1 = x2 - gate*d2, ...).
+// hp [4d] (pre-GELU), h [4d], d2 [d], and the two LayerNorm inputs xa, xb (fp32 [d]) with their (mean, rstd)
+// = 16 d bf16 + 2 d fp32 = 40 KB per token at d = 1024 (10 MB per image per block, 240 MB per image for DiT-L: sized for the
+// 288 GB of HBM3E).  Keeping every LayerNorm input lets the backward fuse LayerNorm-backward with the gated-residual
+// backward in one 18-B-per-element pass (bsi_ln_gate_bwd) instead of rewinding the stream (two passes, 30 B).
 #include "common.h"
 #include "dit_ops.h"
 #include "prof.h"
@@ -39,11 +41,13 @@ inline Dims dims_of(const bsi_dit_config* c, int B) {
 struct BlockTape {
     char *xn1, *qkv, *ao, *d1, *xn2, *hp, *h, *d2;
     float* lse;
+    float *xa, *xb;    // fp32 [M, dim]: inputs of LayerNorm 1 / 2 (xa of block 0 is written by the patch encoder)
+    float *sa, *sb;    // fp32 [M, 2]: (mean, rstd) of those rows
 };
 
 struct Tape {
     char* a0;       // bf16 [M, kpad]
-    float* x;       // fp32 [M, dim]  final residual stream
+    float* x;       // fp32 [M, dim]  final residual stream (input of the decoder's LayerNorm)
     float* mod;     // fp32 [B, depth, 6 dim]
     char* emb;      // bf16 [B, dim]
     float* ada_pre; // fp32 [depth, B, dim]
@@ -64,7 +68,8 @@ inline Tape carve_tape(const Dims& d, int B, void* base) {
     t.ada_pre = reinterpret_cast<float*>(p + off); off += au((size_t)d.depth * B * dim * 4);
     t.ada_s = p + off; off += au((size_t)d.depth * B * dim * 2);
     t.blocks = p + off;
-    t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4);
+    t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4) +
+                    au(M * dim * 4) * 2 + au(M * 2 * 4) * 2;
     off += t.block_bytes * d.depth;
     t.total = off;
     return t;
@@ -83,7 +88,11 @@ inline BlockTape block_tape(const Tape& t, const Dims& d, int B, int l) {
     b.hp = p + off; off += au(M * 4 * dim * 2);
     b.h = p + off; off += au(M * 4 * dim * 2);
     b.d2 = p + off; off += au(M * dim * 2);
-    b.lse = reinterpret_cast<float*>(p + off);
+    b.lse = reinterpret_cast<float*>(p + off); off += au((size_t)B * d.heads * d.tokens * 4);
+    b.xa = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
+    b.xb = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
+    b.sa = reinterpret_cast<float*>(p + off); off += au(M * 2 * 4);
+    b.sb = reinterpret_cast<float*>(p + off);
     return b;
 }
 
@@ -168,8 +177,8 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
                   "bsi_dit_train_forward: c_in/c_skip/c_out must be given together");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Dims d = dims_of(cfg, B);
-    BSI_CHECK_ARG(d.tokens % 64 == 0 && d.dim % 64 == 0 && d.dim / d.heads == 64 && d.tokens <= 256,
-                  "bsi_dit_train_forward: unsupported geometry (tokens %d, head dim %d)", d.tokens, d.dim / d.heads);
+    BSI_CHECK_ARG(d.tokens % 64 == 0 && d.dim % 64 == 0 && d.dim / d.heads == 64 && d.tokens <= 256 && d.dim <= 1024,
+                  "bsi_dit_train_forward: unsupported geometry (tokens %d, dim %d, head dim %d)", d.tokens, d.dim, d.dim / d.heads);
     const int dim = d.dim, M = (int)d.M;
     const int mod_stride = d.depth * 6 * dim;
     Tape tp = carve_tape(d, B, tape_mem);
@@ -186,30 +195,34 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
                  nullptr, nullptr, nullptr, 0, stream));
     }
     TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin, d.nfreq, d.kpad, tp.a0, s));
-    TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, tp.x, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32, nullptr, nullptr,
-             w->pos, d.tokens, stream));
+    TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, block_tape(tp, d, B, 0).xa, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32,
+             nullptr, nullptr, w->pos, d.tokens, stream));
     const void* pend_delta = nullptr;
     const float* pend_gate = nullptr;
+    float* x_prev = nullptr;  // residual stream before the pending branch is added
     for (int l = 0; l < d.depth; ++l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
         BlockTape bt = block_tape(tp, d, B, l);
         const float* ml = tp.mod + (size_t)l * 6 * dim;
-        TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, B, mod_stride, d.tokens, nullptr,
-                                  nullptr, bt.xn1, stream));
+        // xa = x_prev + gate * d2 of the block below (block 0: the encoder wrote xa), xn1 = LN(xa) * (1 + scale) + shift
+        TRY(bsi_resid_ln_modulate_drop(l == 0 ? bt.xa : x_prev, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, B, mod_stride,
+                                       d.tokens, nullptr, nullptr, bt.xn1, DropCfg{}, stream, bt.xa, bt.sa));
         TRY(gemm(bt.xn1, dim, bw.qkv_w, dim, bw.qkv_b, bt.qkv, 3 * dim, M, 3 * dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_attention_fwd_train(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse,
                                     make_drop(dropout_p, seed, 2 * l), stream));
         TRY(gemm(bt.ao, dim, bw.out_w, dim, bw.out_b, bt.d1, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_resid_ln_modulate_drop(tp.x, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride,
-                                       d.tokens, nullptr, nullptr, bt.xn2, make_drop(dropout_p, seed, 2 * l + 1), stream));
+        TRY(bsi_resid_ln_modulate_drop(bt.xa, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride,
+                                       d.tokens, nullptr, nullptr, bt.xn2, make_drop(dropout_p, seed, 2 * l + 1), stream, bt.xb,
+                                       bt.sb));
         TRY(gemm(bt.xn2, dim, bw.fc1_w, dim, bw.fc1_b, bt.h, 4 * dim, M, 4 * dim, dim, BSI_EPI_BIAS_GELU_DUAL, nullptr, bt.hp, nullptr, 0, stream));
         TRY(gemm(bt.h, 4 * dim, bw.fc2_w, 4 * dim, bw.fc2_b, bt.d2, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         pend_delta = bt.d2;
         pend_gate = ml + 5 * dim;
+        x_prev = bt.xb;
     }
-    // materialise the final residual stream (kept for the backward), then the decoder
-    TRY(bsi_resid_ln_modulate(tp.x, M, dim, 1e-5f, pend_delta, pend_gate, nullptr, nullptr, B, mod_stride, d.tokens, nullptr,
-                              nullptr, nullptr, stream));
+    // materialise the final residual stream (kept for the decoder's backward), then the decoder
+    TRY(bsi_resid_ln_modulate_drop(x_prev, M, dim, 1e-5f, pend_delta, pend_gate, nullptr, nullptr, B, mod_stride, d.tokens, nullptr,
+                                   nullptr, nullptr, DropCfg{}, stream, tp.x, nullptr));
     return bsi_dit_final_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, w->dec_b, cfg->C, cfg->H, cfg->W,
                                 cfg->patch, mu, c_skip, c_out, 1, nullptr, nullptr, 1, 0, out, s);
 }
@@ -247,6 +260,13 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         }
     }
 
+    {   // top of the stack: x_final = xb + g_m * d2 of the last block
+        const int l = d.depth - 1;
+        BlockTape bt = block_tape(tp, d, B, l);
+        TRY(bsi_ln_gate_bwd_drop(nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, ws.dX, bt.d2,
+                                 tp.mod + (size_t)l * 6 * dim + 5 * dim, mod_stride, ws.dmod + (size_t)l * 6 * dim + 5 * dim,
+                                 mod_stride, ws.dd, M, dim, d.tokens, DropCfg{}, stream));
+    }
     for (int l = d.depth - 1; l >= 0; --l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
         const bsi_dit_block_weights_t& bT = wT->blocks[l];
@@ -255,25 +275,34 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         const float* ml = tp.mod + (size_t)l * 6 * dim;
         float* dml = ws.dmod + (size_t)l * 6 * dim;
         (void)bw;
-        // ---- MLP branch: x2 = x1 + g_m * d2
-        TRY(bsi_gate_bwd(ws.dX, bt.d2, tp.x, ml + 5 * dim, mod_stride, dml + 5 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
-        // dh = dd2 . W2, times gelu'(hp)  -> dhp
+        // ---- MLP branch: x2 = xb + g_m * d2.  ws.dd = g_m * dX was produced by the fused kernel of the block above (or by the
+        //      gate-only launch in front of the loop).  dh = dd2 . W2, times gelu'(hp)  -> dhp
         TRY(gemm(ws.dd, dim, bT.fc2_wT, dim, nullptr, ws.dbig, 4 * dim, M, 4 * dim, dim, BSI_EPI_MUL_GELUGRAD_BF16, bt.hp, nullptr, nullptr, 0, stream));
         TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, bg.fc2_b, 0, ws.tn, stream));
         // dxn2 = dhp . W1
         TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, bg.fc1_b, 0, ws.tn, stream));
-        TRY(bsi_ln_mod_bwd_drop(ws.dsmall, tp.x, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX, M,
-                                dim, d.tokens, 1e-5f, make_drop(dropout_p, seed, 2 * l + 1), stream));
-        // ---- attention branch: x1 = x0 + g_a * d1
-        TRY(bsi_gate_bwd(ws.dX, bt.d1, tp.x, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, M, dim, d.tokens, ws.dd, stream));
+        // LayerNorm 2 backward (dX becomes dL/dxb) + attention branch xb = xa + g_a * d1: dd = g_a * dX, dg_a
+        TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xb, bt.sb, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX,
+                                 bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, ws.dd, M, dim, d.tokens,
+                                 make_drop(dropout_p, seed, 2 * l + 1), stream));
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
         TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
                                    make_drop(dropout_p, seed, 2 * l), stream));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
         TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
-        TRY(bsi_ln_mod_bwd(ws.dsmall, tp.x, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, M, dim, d.tokens, 1e-5f, stream));
+        // LayerNorm 1 backward (dX becomes dL/dxa) + the MLP branch of the block below: xa = xb' + g_m' * d2'
+        if (l > 0) {
+            BlockTape below = block_tape(tp, d, B, l - 1);
+            const float* mlb = tp.mod + (size_t)(l - 1) * 6 * dim;
+            float* dmlb = ws.dmod + (size_t)(l - 1) * 6 * dim;
+            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, below.d2,
+                                     mlb + 5 * dim, mod_stride, dmlb + 5 * dim, mod_stride, ws.dd, M, dim, d.tokens, DropCfg{}, stream));
+        } else {
+            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, nullptr, nullptr,
+                                     0, nullptr, 0, nullptr, M, dim, d.tokens, DropCfg{}, stream));
+        }
         {   // adaLN MLP of this block (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2, rows = samples
             const float* pre = tp.ada_pre + (size_t)l * B * dim;
             const char* sl = tp.ada_s + (size_t)l * B * dim * 2;

@@ -1586,6 +1586,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
     };
 
+    // start stagger: workgroups begin (and so reach their epilogues) spread over `stagger` * 16 * 64 clocks, so that the output
+    // tiles of all CUs do not hit the memory system in one burst
+    if (p.stagger > 0) {
+        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase
     set_sources(tile);
     issue_next();
@@ -1976,6 +1982,7 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 5 * (size_t)256 * 128;
+    p.stagger = g_stagger;
     auto kern = gemm_bf16_k64r_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {

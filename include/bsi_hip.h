@@ -272,6 +272,13 @@ int bsi_gate_bwd(const float* dX, const void* delta, float* x, const float* gate
                  int dgate_stride, int M, int d, int tokens, void* ddelta, bsi_stream_t stream);
 int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift, float* dscale,
                    int dmod_stride, float* dX, int M, int d, int tokens, float eps, bsi_stream_t stream);
+/* Fused form used by the training engine, whose tape keeps every LayerNorm input x (fp32) and its per-row (mean, rstd)
+ * `stats` [M][2]: LayerNorm-modulate backward (as bsi_ln_mod_bwd, statistics read instead of recomputed) followed, on the
+ * same row, by the gated-residual backward of the branch below it (ddelta = bf16(gate*dX), dgate[b] += sum dX*delta; no
+ * rewinding of x).  dxn == NULL: gate part only; delta == NULL: LayerNorm part only.  d <= 1024, tokens % 64 == 0. */
+int bsi_ln_gate_bwd(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
+                    float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
+                    float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, bsi_stream_t stream);
 /* out_bf16[i] = ds[i] * silu'(pre[i]) (pre == NULL: plain cast); fp32 [rows,cols] -> bf16 [cols, ld] transposed. */
 int bsi_silu_bwd_bf16(const float* ds, const float* pre, size_t n, void* out, bsi_stream_t stream);
 int bsi_cast_transpose_bf16(const float* in, int rows, int cols, void* out, int ld_out, bsi_stream_t stream);

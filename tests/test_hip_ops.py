@@ -506,6 +506,58 @@ def test_gate_and_ln_backward(N, Bs, tokens, d):
     assert rel_linf(dmod2.cpu()[:, 4 * d:5 * d], sc.grad) < 1e-5
 
 
+@pytest.mark.parametrize("Bs,tokens,d", [(3, 64, 128), (2, 256, 1024), (1, 128, 256)])
+def test_fused_ln_gate_backward(N, Bs, tokens, d):
+    """bsi_ln_gate_bwd (LayerNorm-modulate backward with saved statistics + gated-residual backward in one pass) against
+    fp64 autograd of  xn = LN(x) * (1 + scale) + shift,  x = x_below + gate * delta  (dit.py:50-55,93-102)."""
+    gen = torch.Generator().manual_seed(7 * Bs + tokens + d)
+    M = Bs * tokens
+    rows = torch.arange(M) // tokens
+    x_below = torch.randn((M, d), generator=gen) * 2 + 0.5
+    delta = bf16r(torch.randn((M, d), generator=gen))
+    mod = torch.randn((Bs, 6 * d), generator=gen) * 0.3
+    dX_in = torch.randn((M, d), generator=gen)
+    dxn = bf16r(torch.randn((M, d), generator=gen))
+    xb = x_below.double().requires_grad_(True)
+    dl = delta.double().requires_grad_(True)
+    gate = mod[:, 2 * d:3 * d].double().requires_grad_(True)
+    sh = mod[:, 3 * d:4 * d].double().requires_grad_(True)
+    sc = mod[:, 4 * d:5 * d].double().requires_grad_(True)
+    x = torch.addcmul(xb, gate[rows], dl)
+    x.retain_grad()
+    xn = do.layer_norm(x) * (1 + sc[rows]) + sh[rows]
+    ((xn * dxn.double()).sum() + (x * dX_in.double()).sum()).backward()
+    # statistics exactly as the forward kernel writes them
+    x32 = x.detach().float()
+    mean = x32.mean(dim=1)
+    rstd = 1.0 / torch.sqrt(((x32 - mean[:, None]) ** 2).mean(dim=1) + 1e-5)
+    stats = torch.stack((mean, rstd), dim=1).contiguous()
+    dmod_in = dev(mod)
+    for mode in ("both", "ln", "gate"):
+        dXacc = dev(dX_in.clone())
+        dmod = dev(torch.zeros_like(mod))
+        dd = empty(M, d, dtype=torch.bfloat16)
+        dd.zero_()
+        ln, gt = mode != "gate", mode != "ln"
+        N.check(N.lib().bsi_ln_gate_bwd(
+            N.ptr(dev(dxn.to(torch.bfloat16))) if ln else None, N.ptr(dev(x32)) if ln else None, N.ptr(dev(stats)) if ln else None,
+            dmod_in.data_ptr() + 16 * d if ln else None, 6 * d, dmod.data_ptr() + 12 * d if ln else None,
+            dmod.data_ptr() + 16 * d if ln else None, 6 * d, N.ptr(dXacc),
+            N.ptr(dev(delta.to(torch.bfloat16))) if gt else None, dmod_in.data_ptr() + 8 * d if gt else None, 6 * d,
+            dmod.data_ptr() + 8 * d if gt else None, 6 * d, N.ptr(dd) if gt else None, M, d, tokens, N.stream()))
+        want_dx = x.grad if ln else dX_in.double()            # dL/dx: the residual-path gradient plus the LayerNorm's
+        assert rel_linf(dXacc, want_dx) < 2e-5, (mode, rel_linf(dXacc, want_dx))
+        if ln:
+            assert rel_linf(dmod.cpu()[:, 3 * d:4 * d], sh.grad) < 1e-5 and rel_linf(dmod.cpu()[:, 4 * d:5 * d], sc.grad) < 1e-5
+        if gt:
+            assert rel_linf(dd.cpu().float(), gate.detach()[rows] * want_dx) < 4e-3, mode
+            ref_dg = torch.zeros(Bs, d, dtype=torch.float64).index_add_(0, rows, want_dx * delta.double())
+            assert rel_linf(dmod.cpu()[:, 2 * d:3 * d], ref_dg) < 1e-5, mode
+        else:
+            assert float(dmod.cpu()[:, 2 * d:3 * d].abs().max()) == 0.0
+    assert rel_linf(gate.grad, torch.zeros(Bs, d, dtype=torch.float64).index_add_(0, rows, x.grad * delta.double())) < 1e-12
+
+
 def test_cast_transpose_and_silu_bwd(N):
     gen = torch.Generator().manual_seed(9)
     w = torch.randn((300, 84), generator=gen)

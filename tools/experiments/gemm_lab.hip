@@ -127,10 +127,10 @@ static void dma_bench() {
 }
 
 template <int EPI, int ABL>
-float time_k64r(GemmParams p, int iters) {
+float time_k64r(GemmParams p, int iters, int gm = 4) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
-    p.gm = 4;
+    p.gm = gm;
     const size_t lds = 5 * 256 * 128;
     auto kern = gemm_bf16_k64r_kernel<EPI, ABL>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -149,7 +149,7 @@ float time_k64r(GemmParams p, int iters) {
 int main() {
     if (getenv("LAB_DMA")) { dma_bench(); return 0; }
     const int M = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 65536;
-    struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 3072, 1024}, {"fc2", 1024, 4096}};
+    struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 3072, 1024}, {"fc2", 1024, 4096}, {"fc1", 4096, 1024}, {"out", 1024, 1024}};
     for (auto sh : shapes) {
         size_t na = (size_t)M * sh.K, nw = (size_t)sh.N * sh.K, no = (size_t)M * sh.N;
         std::vector<unsigned short> ha(na), hw(nw);
@@ -191,6 +191,15 @@ int main() {
                     printf("%s %-14s %8.3f ms %8.0f TF   shader clock %.0f MHz\n", sh.name, pass ? "randn data" : "lab data", ms,
                            fl / ms / 1e9, 100.0 * hc[0] / hc[1]);
                 }
+            }
+            continue;
+        }
+        if (getenv("LAB_GM")) {  // band height x cache policy of the operand streams (variant 12)
+            for (int gm : {1, 2, 4, 8, 16, 32}) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "v12 gm %2d default", gm); rep(nm, time_k64r<E, 0>(p, 20, gm));
+                snprintf(nm, sizeof nm, "v12 gm %2d A nt", gm); rep(nm, time_k64r<E, 2048>(p, 20, gm));
+                snprintf(nm, sizeof nm, "v12 gm %2d W nt", gm); rep(nm, time_k64r<E, 4096>(p, 20, gm));
             }
             continue;
         }

@@ -44,7 +44,12 @@ __device__ __forceinline__ float lane_group_sum(float v) {
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
-template <int DH, int KC, bool DROP>
+// ALL: the whole K and V of the (batch, head) are staged ONCE (tokens * DH * 4 bytes of LDS: 64 KB for the DiT's 256 tokens x 64),
+// the chunk loop then runs without barriers or global loads; two such workgroups share a CU, so one's staging round trip is
+// covered by the other's chunk loop.  Without ALL (long sequences: the UNet's 1024 positions x 128) every chunk is staged.
+// ABL (laboratory, tools/experiments/attn_lab.hip): 1 = no exp2 (plain copy of the argument), 2 = no global stores, 4 = no P.V
+// products / V reads, 8 = no K.Q^T products / K reads, 16 = no K/V global loads (LDS holds garbage), 32 = no Q loads.
+template <int DH, int KC, bool DROP, bool ALL, int ABL = 0>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int tokens,
                                                             int heads, __bf16* __restrict__ out, int ld_out,
                                                             float scale_log2e, float* __restrict__ lse, DropCfg dc) {
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
     constexpr int CPR = DH / 8;       // 16-B chunks per row
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Kl = lds;
-    char* Vl = lds + KC * RB;
+    char* Vl = lds + KC * RB;  // (ALL: set below to lds + tokens * RB)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
@@ -74,8 +79,10 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qf[jq][ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)(q0 + 16 * jq + c16) * ld_qkv + 32 * ks + 8 * g);
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (ABL & 32) { for (int e = 0; e < 8; ++e) qf[jq][ks][e] = (__bf16)(0.01f * (float)(lane + e)); }
+                else qf[jq][ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)(q0 + 16 * jq + c16) * ld_qkv + 32 * ks + 8 * g);
+            }
     }
 
     f32x4 o[DT][2];
@@ -91,17 +98,32 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
         for (int jq = 0; jq < 2; ++jq) rowh[jq] = drop_row(dc, (unsigned)bh * tokens + q0 + 16 * jq + c16);
     }
 
-    for (int kc0 = 0; kc0 < tokens; kc0 += KC) {
-        __syncthreads();  // previous chunk fully consumed
-        // ---- stage K and V chunk: KC rows x CPR chunks each, 512 threads ---------------------------
-        for (int idx = tid; idx < KC * CPR; idx += 512) {
+    if constexpr (ALL) {
+        Vl = lds + tokens * RB;
+        for (int idx = tid; idx < ((ABL & 16) ? 0 : tokens * CPR); idx += 512) {
             const int r = idx / CPR, c = idx % CPR;
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kg + (size_t)(kc0 + r) * ld_qkv + c * 8);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vg + (size_t)(kc0 + r) * ld_qkv + c * 8);
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kg + (size_t)r * ld_qkv + c * 8);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vg + (size_t)r * ld_qkv + c * 8);
             *reinterpret_cast<u32x4*>(Kl + r * RB + k_chunk_swz<DH>(r, c) * 16) = kv;
             *reinterpret_cast<u32x4*>(Vl + r * RB + (v_block_swz<DH>(r, c >> 1) * 2 + (c & 1)) * 16) = vv;
         }
         __syncthreads();
+    }
+    for (int kc0 = 0; kc0 < tokens; kc0 += KC) {
+        if constexpr (!ALL) {
+            __syncthreads();  // previous chunk fully consumed
+            // ---- stage K and V chunk: KC rows x CPR chunks each, 512 threads ---------------------------
+            for (int idx = tid; idx < KC * CPR; idx += 512) {
+                const int r = idx / CPR, c = idx % CPR;
+                const u32x4 kv = *reinterpret_cast<const u32x4*>(Kg + (size_t)(kc0 + r) * ld_qkv + c * 8);
+                const u32x4 vv = *reinterpret_cast<const u32x4*>(Vg + (size_t)(kc0 + r) * ld_qkv + c * 8);
+                *reinterpret_cast<u32x4*>(Kl + r * RB + k_chunk_swz<DH>(r, c) * 16) = kv;
+                *reinterpret_cast<u32x4*>(Vl + r * RB + (v_block_swz<DH>(r, c >> 1) * 2 + (c & 1)) * 16) = vv;
+            }
+            __syncthreads();
+        }
+        const char* Kc = ALL ? Kl + kc0 * RB : Kl;   // this chunk's rows (the swizzle keys depend on row & 15 only)
+        const char* Vc = ALL ? Vl + kc0 * RB : Vl;
         if (!active) continue;
 
         // ---- S^T = K . Q^T : rows = keys, cols = queries --------------------------------------------
@@ -113,7 +135,12 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
             const int row = 16 * kt + c16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + row * RB + k_chunk_swz<DH>(row, 4 * ks + g) * 16);
+                if constexpr (ABL & 8) {
+                    s[kt][0][ks] += (float)qf[0][ks][kt & 7];
+                    s[kt][1][ks + 2] += (float)qf[1][ks][kt & 7];
+                    continue;
+                }
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kc + row * RB + k_chunk_swz<DH>(row, 4 * ks + g) * 16);
                 s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
                 s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
             }
@@ -141,6 +168,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
                     const f32x2 arg = __builtin_elementwise_fma(f32x2{s[kt][jq][r], s[kt][jq][r + 1]}, f32x2{scale_log2e, scale_log2e},
                                                                 f32x2{-mb, -mb});
                     f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                    if constexpr (ABL & 1) pv = arg * arg;
                     ps2 += pv;  // the normaliser uses the undropped probabilities
                     if constexpr (DROP) {  // dropout on the attention weights (dit.py:43-44 dropout_p), training only:
                         // element (row = (b, h, query), column = key)
@@ -175,6 +203,11 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
             const int rowB = rowA + 16;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                if constexpr (ABL & 4) {
+                    o[dt][0][kb & 3] += (float)pf[0][dt];
+                    o[dt][1][kb & 3] += (float)pf[1][dt + 4];
+                    continue;
+                }
                 const int blk = dt >> 1;                      // 32-B block holding columns 16dt..16dt+15
                 const int inblk = (dt & 1) * 32 + pp * 8;     // byte offset inside the 64-B block pair... see below
                 // a 32-B block holds 16 bf16 columns: block index = dt (16 cols * 2 B = 32 B)
@@ -182,9 +215,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
                 const int offA = rowA * RB + v_block_swz<DH>(rowA, dt) * 32 + pp * 8;
                 const int offB = rowB * RB + v_block_swz<DH>(rowB, dt) * 32 + pp * 8;
                 const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vl + offA));
+                    (__attribute__((address_space(3))) s16x4*)(Vc + offA));
                 const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vl + offB));
+                    (__attribute__((address_space(3))) s16x4*)(Vc + offB));
                 union { bf16x8 v; s16x4 h[2]; } vf;
                 vf.h[0] = va;
                 vf.h[1] = vb;
@@ -194,6 +227,41 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
         }
     }
 
+    if constexpr (ALL && DH == 64) {
+        // Output through LDS: the wave's 32 x 64 tile (4 KB) is written into its slice of the K region (free once every wave has
+        // left the chunk loop) with the 16-B chunk index XOR-ed by row & 7, read back by rows and stored as whole 128-B lines
+        // (8 lanes x 16 B per row, 8 rows per instruction): 4 store instructions per wave instead of 8 that each touch 16 rows
+        // with 32 B (partial-line writes: measured as the kernel's bound, TA busy 84 %).
+        __syncthreads();
+        char* scr = lds + wave * 4096;
+        if (active) {
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                float l = l_run[jq];
+                l = lane_group_sum(l);
+                const float inv = 1.0f / l;
+                if (lse && g == 0) lse[(size_t)bh * tokens + q0 + 16 * jq + c16] = (m_run[jq] * scale_log2e + __log2f(l)) * 0.6931471805599453f;
+                const int row = 16 * jq + c16;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(o[dt][jq][0] * inv, o[dt][jq][1] * inv);
+                    w[1] = pack_bf16x2(o[dt][jq][2] * inv, o[dt][jq][3] * inv);
+                    *reinterpret_cast<u32x2*>(scr + row * 128 + (((2 * dt + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = w;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((ch ^ (row & 7)) << 4));
+                if constexpr (ABL & 2) { if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) out[lane] = (__bf16)1.0f; continue; }
+                *reinterpret_cast<u32x4*>(out + ((size_t)b * tokens + q0 + row) * ld_out + h * DH + ch * 8) = v;
+            }
+        }
+        return;
+    }
     if (!active) return;
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
@@ -213,17 +281,21 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const __bf16* __rest
     }
 }
 
-template <int DH, int KC>
+template <int DH, int KC, bool ALL = false>
 int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __bf16* out, int ld_out, float* lse,
                 DropCfg dc, hipStream_t s) {
-    const size_t lds = 2 * (size_t)KC * DH * 2;
-    auto kern = attention_fwd_kernel<DH, KC, false>;
-    auto kern_d = attention_fwd_kernel<DH, KC, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    const size_t lds = 2 * (size_t)(ALL ? tokens : KC) * DH * 2;
+    auto kern = attention_fwd_kernel<DH, KC, false, ALL>;
+    auto kern_d = attention_fwd_kernel<DH, KC, true, ALL>;
+    // per device: the attribute belongs to the function ON a device (a process may drive several GPUs)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        const int max_lds = ALL ? 2 * 256 * DH * 2 : (int)lds;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_d), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        attr_set[dev] = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((tokens + 255) / 256, B * heads);
@@ -235,22 +307,28 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
 
 }  // namespace
 
+int bsi_attention_fwd_persistent(const void* qkv, int ld_qkv, int B, int heads, void* out, int ld_out, float* lse, DropCfg dc,
+                                 hipStream_t s);
+
 static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
                               float* lse, DropCfg dc, bsi_stream_t stream) {
     BSI_CHECK_ARG(qkv && out && B > 0 && heads > 0, "bsi_attention_fwd: bad args");
     BSI_CHECK_ARG(dh == 64 || dh == 128, "bsi_attention_fwd: head dim %d unsupported (64 or 128)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0, "bsi_attention_fwd: tokens=%d must be a multiple of 64", tokens);
-    BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_qkv >= 3 * heads * dh && ld_out % 4 == 0 && ld_out >= heads * dh,
+    BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_qkv >= 3 * heads * dh && ld_out % 8 == 0 && ld_out >= heads * dh,
                   "bsi_attention_fwd: bad leading dimensions");
     const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
     __bf16* o = reinterpret_cast<__bf16*>(out);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dh == 64) {
-        // with dropout the 256-key variant exceeds the register file: use 64-key chunks (online softmax)
-        // 64-key chunks (online softmax): 117 VGPRs -> two workgroups per CU, whose load and compute phases overlap; measured
-        // 76.5 us against 88.6 us for the single-chunk 256-key variant (246 VGPRs, one workgroup per CU) at 128 x 16 heads.
-        static const bool kc256 = getenv("BSI_ATTN_KC256") != nullptr;  // A/B switch for experiments
-        if (tokens % 256 == 0 && !dc.thr && kc256) return launch_attn<64, 256>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
+        // 64-key chunks with online softmax: 117 VGPRs, so two workgroups share a CU.  Up to 256 tokens the whole K and V of the
+        // (batch, head) are staged once (64 KB) and the chunk loop has no barrier; longer sequences stage chunk by chunk.
+        static const bool chunked = getenv("BSI_ATTN_CHUNKED") != nullptr;  // A/B switches for experiments
+        static const bool no_persist = getenv("BSI_ATTN_NO_PERSIST") != nullptr;
+        // the DiT geometry proper (256 tokens): persistent kernel, next pair's traffic under this pair's arithmetic
+        if (tokens == 256 && !no_persist && !chunked && (size_t)tokens * ld_qkv * 2 < (1ull << 32))
+            return bsi_attention_fwd_persistent(qkv, ld_qkv, B, heads, out, ld_out, lse, dc, s);
+        if (tokens <= 256 && !chunked) return launch_attn<64, 64, true>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
         return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
     }
     if (tokens % 128 == 0) return launch_attn<128, 128>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);

@@ -344,7 +344,7 @@ def test_gemm_rejects_bad_shapes(N):
 
 
 @pytest.mark.parametrize("B,tokens,heads,dh", [(2, 64, 2, 64), (3, 256, 4, 64), (2, 256, 16, 64), (1, 1024, 1, 128),
-                                                (2, 64, 1, 128), (1, 512, 2, 64)])
+                                                (2, 64, 1, 128), (1, 512, 2, 64), (41, 256, 16, 64)])
 def test_attention(N, B, tokens, heads, dh):
     gen = torch.Generator().manual_seed(B + tokens + heads)
     d = heads * dh
@@ -358,6 +358,13 @@ def test_attention(N, B, tokens, heads, dh):
     # P is rounded to bf16 before the PV product (2^-9 relative per term, averaged) and O is stored as bf16
     assert rel_linf(out.cpu().float(), ref) < 1e-2, rel_linf(out.cpu().float(), ref)
     assert float((out.cpu().double() - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    if dh == 64:  # the variant that also saves the log-sum-exp (training forward); 41 x 16 pairs: 2-3 pairs per persistent workgroup
+        out2, lse = empty(B, tokens, d, dtype=torch.bfloat16), empty(B, heads, tokens)
+        N.check(N.lib().bsi_attention_fwd_lse(N.ptr(dev(qkv.to(torch.bfloat16))), 3 * d, B, tokens, heads, dh, N.ptr(out2), d,
+                                              N.ptr(lse), N.stream()))
+        assert torch.equal(out2, out)
+        ref_lse = torch.logsumexp(q @ k.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+        assert float((lse.cpu().double() - ref_lse).abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("M,d,tokens,mod_rows", [(128, 128, 64, 2), (512, 1024, 256, 1), (512, 1024, 256, 2),

@@ -301,7 +301,8 @@ class BSI(nn.Module):
         return _SqErr.apply(x, x_hat, rpdf, 1.0, True)
 
     # -- sampling (bsi.py:312-373) -------------------------------------------------------------------
-    def sample(self, n_samples: int, generator=None, *, t: Tensor | None = None, graph: bool = False) -> Tensor:
+    def sample(self, n_samples: int, generator=None, *, t: Tensor | None = None, graph: bool = False,
+               device_noise: bool = False) -> Tensor:
         """Draw `n_samples` samples (Algorithm 3): k+1 denoiser evaluations.
 
         `graph=True` replays the whole chain as ONE captured HIP graph (captured on first use for this (n_samples, schedule)):
@@ -309,7 +310,16 @@ class BSI(nn.Module):
         path, so both paths return bit-identical samples for the same generator state.  Measured on MI355X: no gain at any batch
         size (1..16 images: 4.5 ms per denoiser step either way) -- the small-batch step is bound by the latency of its ~320
         dependent kernels themselves (a 256 x 256 GEMM tile walks its K loop in ~10 us however small M is), not by launch
-        overhead; large batches keep the GPU busy anyway."""
+        overhead; large batches keep the GPU busy anyway.
+
+        `device_noise=True` (opt-in): the Gaussian noise of mu_0 and of every measurement is generated inside the HIP kernels
+        (Philox4x32-10 + Box-Muller, bsi_refine_step_philox) from ONE 64-bit seed drawn from `generator` -- no eps tensors, no
+        k+1 generator calls.  It is a different random stream from the reference's `torch.randn` calls (bsi.py:325,332-334),
+        which is why it is not the default; samples are reproducible for a given generator state."""
+        if device_noise:
+            if graph:
+                raise RuntimeError("BSI.sample: device_noise and graph cannot be combined")
+            return self._run_chain(n_samples, generator, t, history=False, device_noise=True)
         if graph:
             return self._run_chain_graphed(n_samples, generator, t)
         return self._run_chain(n_samples, generator, t, history=False)
@@ -366,7 +376,7 @@ class BSI(nn.Module):
         """As `sample`, returning (mus[k+1], x_hats[k+1], ys[k])."""
         return self._run_chain(n_samples, generator, t, history=True)
 
-    def _run_chain(self, n, generator, t, history, noise=None):
+    def _run_chain(self, n, generator, t, history, noise=None, device_noise=False):
         self._require_fp32()
         if t is None:
             t = self.default_schedule
@@ -383,7 +393,14 @@ class BSI(nn.Module):
         native = self._native_model() if self.preconditioning == "edm" else None
         mod = native.adaln_table(t_eval) if native is not None else None
 
-        eps = noise[0] if noise is not None else torch.randn(shape, **self.tensor_args, generator=generator)
+        seed = None
+        if device_noise:
+            assert not history and noise is None
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev, generator=generator)  # stays on the device
+            eps = torch.empty(shape, **self.tensor_args)
+            N.check(lib.bsi_philox_normal(N.ptr(seed), 0xFFFFFFFF, eps.numel(), N.ptr(eps), N.stream()))
+        else:
+            eps = noise[0] if noise is not None else torch.randn(shape, **self.tensor_args, generator=generator)
         if history:
             mus = torch.empty((k + 1, *shape), **self.tensor_args)
             x_hats = torch.zeros((k + 1, *shape), **self.tensor_args)
@@ -410,14 +427,19 @@ class BSI(nn.Module):
 
         for i in range(k):
             f, is_xhat = predict(mu, i)
-            eps = noise[1][i] if noise is not None else torch.randn(shape, **self.tensor_args, generator=generator)
             if history:
                 out_mu, xh_o, y_o = mus[i + 1], x_hats[i], ys[i]
             else:
                 out_mu, xh_o, y_o = mu_next, None, None
-            N.check(lib.bsi_refine_step(N.ptr(mu), N.ptr(f), N.ptr(eps), N.ptr(lam), N.ptr(alpha), N.ptr(c_skip),
-                                        N.ptr(c_out), i, is_xhat, n, D, N.ptr(xh_o), N.ptr(y_o), N.ptr(out_mu),
-                                        N.stream()))
+            if device_noise:
+                N.check(lib.bsi_refine_step_philox(N.ptr(mu), N.ptr(f), N.ptr(seed), N.ptr(lam), N.ptr(alpha), N.ptr(c_skip),
+                                                   N.ptr(c_out), i, is_xhat, n, D, N.ptr(xh_o), N.ptr(y_o), N.ptr(out_mu),
+                                                   N.stream()))
+            else:
+                eps = noise[1][i] if noise is not None else torch.randn(shape, **self.tensor_args, generator=generator)
+                N.check(lib.bsi_refine_step(N.ptr(mu), N.ptr(f), N.ptr(eps), N.ptr(lam), N.ptr(alpha), N.ptr(c_skip),
+                                            N.ptr(c_out), i, is_xhat, n, D, N.ptr(xh_o), N.ptr(y_o), N.ptr(out_mu),
+                                            N.stream()))
             if history:
                 mu = mus[i + 1]
             else:

@@ -287,16 +287,9 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
     const size_t lds = 2 * (size_t)(ALL ? tokens : KC) * DH * 2;
     auto kern = attention_fwd_kernel<DH, KC, false, ALL>;
     auto kern_d = attention_fwd_kernel<DH, KC, true, ALL>;
-    // per device: the attribute belongs to the function ON a device (a process may drive several GPUs)
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        const int max_lds = ALL ? 2 * 256 * DH * 2 : (int)lds;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_d), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        attr_set[dev] = true;
-    }
+    const int max_lds = ALL ? 2 * 256 * DH * 2 : (int)lds;
+    set_max_lds(reinterpret_cast<const void*>(kern), max_lds);
+    set_max_lds(reinterpret_cast<const void*>(kern_d), max_lds);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid((tokens + 255) / 256, B * heads);
     if (dc.thr) hipLaunchKernelGGL(kern_d, grid, dim3(512), lds, s, qkv, ld_qkv, tokens, heads, out, ld_out, scale_log2e, lse, dc);

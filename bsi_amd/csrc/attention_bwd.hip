@@ -270,12 +270,7 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
     BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 4 == 0, "bsi_attention_bwd: bad leading dimensions");
     const size_t lds = (size_t)4 * tokens * RB + 3 * tokens * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * 256 * RB + 3 * 256 * 4);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(attention_bwd_kernel), 4 * 256 * RB + 3 * 256 * 4);
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(512), lds, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const __bf16*>(qkv), ld_qkv, reinterpret_cast<const __bf16*>(out),
                        reinterpret_cast<const __bf16*>(dout), ld_o, lse, tokens, heads, reinterpret_cast<__bf16*>(dqkv),

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int PT = 256, PDH = 64, PRB = 128, PKC = 64;
+constexpr int PT = 256, PDH = 64, PRB = 128;
 constexpr int P_BUF = 2 * PT * PRB;          // K + V of one pair: 64 KB
 constexpr int P_SCR = 2 * P_BUF;             // output scratch: 16 waves x 2 KB
 
@@ -250,19 +250,9 @@ template <bool DROP, bool LSE>
 int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int ld_out, float* lse, DropCfg dc, hipStream_t s) {
     auto kern = attention_fwd_p_kernel<DROP, LSE>;
     constexpr int lds = P_SCR + 16 * 2048;  // 160 KB
-    static bool attr_set[64] = {};
-    static int cus[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipDeviceProp_t prop;
-        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        attr_set[dev] = true;
-    }
-    const int pairs = B * heads;
-    const int grid = pairs < cus[dev] ? pairs : cus[dev];
+    set_max_lds(reinterpret_cast<const void*>(kern), lds);
+    const int pairs = B * heads, ncu = device_cus();
+    const int grid = pairs < ncu ? pairs : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, qkv, ld_qkv, pairs, heads, out, ld_out,
                        1.4426950408889634f / sqrtf((float)PDH), lse, dc);
     BSI_CHECK_LAUNCH("bsi_attention_fwd(persistent)");

@@ -165,19 +165,63 @@ __global__ void predict_combine_bwd_kernel(const float* __restrict__ g, const fl
     }
 }
 
-// bsi.py:331-335: the fused measure/refine step.  Algorithmic traffic: read mu, f, eps + write mu' = 16 B/elt.
+// Counter-based Gaussian noise for the measurement step y = x_hat + eps / sqrt(alpha) (bsi.py:331-333) generated IN the kernel:
+// Philox4x32-10 keyed by a 64-bit seed that lives in device memory (drawn once per chain from the caller's torch.Generator, so
+// no host synchronisation), counter = (index of the group of four elements, noise stream), Box-Muller on 24-bit uniforms.
+// This is an opt-in (BSI.sample(device_noise=True)): the default path draws eps with the caller's generator exactly as the
+// reference does (bsi.py:332-334), because a different generator is a different random stream.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned long long group, unsigned stream_id) {
+    unsigned x[4];
+    philox4x32_10((unsigned)group, (unsigned)(group >> 32), stream_id, 0x42534931u, (unsigned)seed, (unsigned)(seed >> 32), x);
+    f32x4 n;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = (float)((x[2 * h] >> 8) + 1u) * 5.9604644775390625e-08f;   // (0, 1]
+        const float u2 = (float)(x[2 * h + 1] >> 8) * 5.9604644775390625e-08f;      // [0, 1): v_sin / v_cos take revolutions
+        const float r = sqrtf(-2.0f * __logf(u1));
+        n[2 * h] = r * __builtin_amdgcn_cosf(u2);
+        n[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
+    }
+    return n;
+}
+
+__global__ void philox_normal_kernel(const unsigned long long* __restrict__ seed, unsigned stream_id, size_t n4,
+                                     float* __restrict__ out) {
+    const unsigned long long sd = seed[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = philox_normal4(sd, i, stream_id);
+}
+
+// bsi.py:331-335: the fused measure/refine step.  Algorithmic traffic: read mu, f, eps + write mu' = 16 B/elt (12 with PHILOX).
+template <bool PHILOX>
 __global__ void refine_step_kernel(const float* __restrict__ mu, const float* __restrict__ f,
-                                   const float* __restrict__ eps, const float* __restrict__ lam,
+                                   const float* __restrict__ eps, const unsigned long long* __restrict__ seed,
+                                   const float* __restrict__ lam,
                                    const float* __restrict__ alpha, const float* __restrict__ cs,
                                    const float* __restrict__ co, int step, int f_is_xhat, size_t n4,
                                    float* __restrict__ xh_out, float* __restrict__ y_out, float* __restrict__ mu_next) {
     const float a = alpha[step], l0 = lam[step], l1 = lam[step + 1];
     const float ra = rsqrt_rn(a);
     const float c_skip = f_is_xhat ? 0.f : cs[step], c_out = f_is_xhat ? 1.f : co[step];
+    unsigned long long sd = 0;
+    if constexpr (PHILOX) sd = seed[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 m = reinterpret_cast<const f32x4*>(mu)[i];
         const f32x4 fv = reinterpret_cast<const f32x4*>(f)[i];
-        const f32x4 e = reinterpret_cast<const f32x4*>(eps)[i];
+        f32x4 e;
+        if constexpr (PHILOX) e = philox_normal4(sd, i, (unsigned)step);
+        else e = reinterpret_cast<const f32x4*>(eps)[i];
         f32x4 xh, y, mn;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -392,9 +436,33 @@ extern "C" int bsi_refine_step(const float* mu, const float* f, const float* eps
     const size_t n4 = (size_t)rows * D / 4;
     int grid = blocks_for(n4);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(refine_step_kernel, dim3(grid), dim3(TPB), 0, S(stream), mu, f, eps, lam, alpha, c_skip, c_out, i,
-                       f_is_xhat, n4, x_hat_out, y_out, mu_next);
+    hipLaunchKernelGGL(refine_step_kernel<false>, dim3(grid), dim3(TPB), 0, S(stream), mu, f, eps, nullptr, lam, alpha, c_skip,
+                       c_out, i, f_is_xhat, n4, x_hat_out, y_out, mu_next);
     BSI_CHECK_LAUNCH("bsi_refine_step");
+    return BSI_OK;
+}
+
+extern "C" int bsi_refine_step_philox(const float* mu, const float* f, const unsigned long long* seed, const float* lam,
+                                      const float* alpha, const float* c_skip, const float* c_out, int i, int f_is_xhat, int rows,
+                                      int D, float* x_hat_out, float* y_out, float* mu_next, bsi_stream_t stream) {
+    BSI_CHECK_ARG(mu && f && seed && lam && alpha && mu_next, "bsi_refine_step_philox: null pointer");
+    BSI_CHECK_ARG(f_is_xhat || (c_skip && c_out), "bsi_refine_step_philox: coefficients missing");
+    BSI_CHECK_ARG(rows > 0 && D > 0 && ((size_t)rows * D) % 4 == 0 && i >= 0, "bsi_refine_step_philox: bad sizes");
+    const size_t n4 = (size_t)rows * D / 4;
+    int grid = blocks_for(n4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(refine_step_kernel<true>, dim3(grid), dim3(TPB), 0, S(stream), mu, f, nullptr, seed, lam, alpha, c_skip,
+                       c_out, i, f_is_xhat, n4, x_hat_out, y_out, mu_next);
+    BSI_CHECK_LAUNCH("bsi_refine_step_philox");
+    return BSI_OK;
+}
+
+extern "C" int bsi_philox_normal(const unsigned long long* seed, unsigned stream_id, size_t n, float* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(seed && out && n > 0 && n % 4 == 0, "bsi_philox_normal: bad args (n must be a multiple of 4)");
+    int grid = blocks_for(n / 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(TPB), 0, S(stream), seed, stream_id, n / 4, out);
+    BSI_CHECK_LAUNCH("bsi_philox_normal");
     return BSI_OK;
 }
 

@@ -38,6 +38,36 @@ void bsi_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, device): remember the pairs already set (round 1 kept one
+// flag per process, which left the kernels of a second device without the attribute).  A lost race only repeats the call.
+inline void set_max_lds(const void* kern, int bytes) {
+    struct Seen { const void* k; int dev; };
+    static Seen seen[512];
+    static int n_seen = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const int n = n_seen;
+    for (int i = 0; i < n; ++i)
+        if (seen[i].k == kern && seen[i].dev == dev) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (n < 512) {
+        seen[n] = Seen{kern, dev};
+        n_seen = n + 1;
+    }
+}
+
+// Compute units of the CURRENT device (persistent kernels launch one workgroup per CU).
+inline int device_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }

@@ -651,11 +651,7 @@ int conv_cus() {
 template <int EPI>
 int launch_conv_slab(const ConvParams& p, int grid, hipStream_t s) {
     auto kern = conv_slab_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)S_LDS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_LDS, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_nhwc_bf16");
     return BSI_OK;
@@ -684,11 +680,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
     }
     const size_t lds = (size_t)C_R * C_SLOT;
     auto kern = conv_ring_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_nhwc_bf16");
     return BSI_OK;

@@ -330,12 +330,8 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     plan(p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     p.colsum = dbias ? p.out + (size_t)p.splits * p.slab_stride : nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<4>), 160 * 1024);
+    set_max_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), 160 * 1024);
     const dim3 grid(8 * ((p.tiles_n * p.tiles_u * p.splits + 7) / 8));  // whole rounds of the 8 XCDs (the kernel drops the excess)
     if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);

@@ -21,6 +21,8 @@
 //     full 128-B lines per row per wave (no LDS transpose, no scattered 2-byte stores);
 //   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles with n
 //     fastest: the A panel of an m-tile is fetched from HBM once and re-used from that XCD's L2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -311,611 +313,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Ping-pong schedule (variant 1).  The 8 waves form two groups (waves 0-3: upper half of the M tile, waves 4-7:
-// lower half); waves w and w+4 share a SIMD.  Every wave runs the phase sequence
-//     L0(kt): ds_read fragments of k-step 0 (+ issue the global_load_lds of tile kt+1)
-//     C0(kt): 32 MFMA            L1(kt): ds_read fragments of k-step 1, wait for its own tile-(kt+1) loads
-//     C1(kt): 32 MFMA
-// with one s_barrier between phases, and group B runs ONE phase behind group A.  So in every phase exactly one
-// wave per SIMD issues MFMAs while its partner reads LDS / issues DMA: the matrix pipe never waits for LDS
-// latency or the barrier.  Hazards (two LDS buffers, tile kt in buffer kt&1):
-//   RAW  tile kt+1 is read first by group A in its L0(kt+1); every wave drained its own loads of tile kt+1
-//        (vmcnt(0)) in its L1(kt), which for both groups ends at least one barrier earlier;
-//   WAR  loads of tile kt+2 are issued in L0(kt+1) of each wave into the buffer of tile kt, whose last reads
-//        (group B's L1(kt)) completed (lgkmcnt(0)) one barrier earlier.
-// ABL: compile-time ablation bits used only by tools/experiments/gemm_lab.hip (0 in the product):
-//   1 = no global_load_lds in the loop, 2 = no ds_read in the loop, 4 = no epilogue, 8 = no barriers in the loop.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
-    constexpr int TM = 8, NW = 8;
-    constexpr int BM = 256, BN = 256;
-    constexpr int ROWS = BM + BN;
-    constexpr int BUF_BYTES = ROWS * ROW_BYTES;
-    constexpr int STAGE_INSTR = 8;
-
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int srow = lane >> 3, schunk = lane & 7;
-    const char* gsrc[STAGE_INSTR];
-#pragma unroll
-    for (int q = 0; q < STAGE_INSTR; ++q) {
-        const int r = (q * NW + wave) * 8 + srow;
-        if (r < BM) {
-            const int c = schunk ^ ((r >> 1) & 7);
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
-            gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
-        } else {
-            const int rw = r - BM;
-            const int c = schunk ^ (((rw >> 1) & 1) | (((rw >> 4) & 3) << 1));
-            int n = n0 + rw;
-            n = n < p.N ? n : p.N - 1;
-            gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
-        }
-    }
-    auto stage = [&](int kt, int buf) {
-        char* base = lds + buf * BUF_BYTES;
-#pragma unroll
-        for (int q = 0; q < STAGE_INSTR; ++q) {
-            char* dst = base + (q * NW + wave) * 8 * ROW_BYTES;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kt * ROW_BYTES), LDS_PTR(dst), 16, 0, 0);
-        }
-    };
-
-    const int fx = (lane >> 1) & 7;
-    const int xoff = (wm * TM * 16 + (lane & 15)) * ROW_BYTES;
-    const int woff = (BM + wn * 64 + 16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
-    const int c0 = (((lane >> 4)) ^ fx) << 4;
-    const int c1 = (((lane >> 4) + 4) ^ fx) << 4;
-
-    f32x4 acc[4][TM];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 wf[4], xf[TM];
-    auto load_frags = [&](const char* b, int cc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * ROW_BYTES + cc);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * ROW_BYTES + cc);
-    };
-    auto compute = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define PHASE_BARRIER()                          \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __builtin_amdgcn_s_barrier();            \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-
-    const int nk = p.K / BK;
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_BARRIER();
-    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
-
-    if constexpr (ABL & 2) load_frags(lds, c0);
-    // experiment (ABL & 16): touch the 128-B lines of K step kt+PF so that they are L2-resident when the DMA asks
-    constexpr int PF = 3;
-    const char* pfrow;
-    {
-        const int r = tid;  // one LDS row (= one 128-B line per K step) per thread
-        if (r < BM) { int m = m0 + r; m = m < p.M ? m : p.M - 1; pfrow = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda); }
-        else { int n = n0 + r - BM; n = n < p.N ? n : p.N - 1; pfrow = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw); }
-    }
-    unsigned pfdummy = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* b = lds + (kt & 1) * BUF_BYTES;
-        // L0
-        if constexpr (!(ABL & 2)) load_frags(b, c0);
-        if constexpr (!(ABL & 1)) {
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        }
-        bool pf_issued = false;
-        if constexpr (ABL & 16) {
-            if (kt + PF < nk) {
-                const char* a = pfrow + (size_t)(kt + PF) * ROW_BYTES;
-                asm volatile("global_load_dword %0, %1, off" : "+v"(pfdummy) : "v"(a) : "memory");
-                pf_issued = true;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 8)) PHASE_BARRIER();
-        // C0
-        compute();
-        if constexpr (!(ABL & 8)) PHASE_BARRIER();
-        // L1
-        if constexpr (!(ABL & 2)) load_frags(b, c1);
-        if (pf_issued) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 8)) PHASE_BARRIER();
-        // C1
-        compute();
-        if constexpr (!(ABL & 8)) PHASE_BARRIER();
-    }
-    if (wm == 0) PHASE_BARRIER();  // balance the barrier count of the two groups
-#undef PHASE_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfdummy)::"memory");
-
-    if constexpr (ABL & 4) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-    } else {
-        gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane, lds + wave * 16384);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 2: two workgroups per CU.  Workgroup = 4 waves (one per SIMD), tile 128(M) x 256(N), K step 32,
-// three-slot LDS ring (72 KB, so two workgroups share a CU's 160 KB and 2 waves sit on every SIMD).
-// Per K step: counted vmcnt (the newest stage stays in flight) -> one barrier -> issue the DMA of stage kt+3
-// into the slot just freed -> ds_read the fragments of step kt+1 into the alternate register set -> 32 MFMA on
-// the current set.  Loads run three K steps ahead of the math; the LDS->register reads of the next step and the
-// DMA issue hide behind this wave's own MFMAs, barrier waits and the whole epilogue hide behind the co-resident
-// workgroup, which is at an unrelated phase (no chip-wide lock step of store bursts).
-// LDS rows are 64 B (4 chunks of 16 B): chunk' = chunk ^ ((-(rowgroup)) & 3) with rowgroup = (row>>2)&3 for
-// activation rows and (row>>4)&3 for the permuted weight rows makes every ds_read_b128 conflict free.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_w4_kernel(const GemmParams p) {
-    constexpr int TM = 8;
-    constexpr int BM = 128, BN = 256, BKS = 32;
-    constexpr int RB = 64;                        // bytes per LDS row
-    constexpr int SLOT_BYTES = (BM + BN) * RB;    // 24 KB
-    constexpr int A_BYTES = BM * RB;              // 8 KB
-    constexpr int NSLOT = 3;
-
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = wn
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- staging: 24 wave-instructions of 16 rows x 64 B per stage; wave w issues instruction slots q*4 + w
-    const int srow = lane >> 2, spos = lane & 3;
-    unsigned goff[6];  // byte offsets from p.A (q < 2) / p.W (q >= 2); the launcher guarantees they fit 32 bits
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int slot = q * 4 + wave;
-        if (q < 2) {  // activation rows 0..127
-            const int r = slot * 16 + srow;
-            const int c = spos ^ ((-(r >> 2)) & 3);
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
-            goff[q] = (unsigned)m * (unsigned)(p.lda * 2) + c * 16;
-        } else {  // weight rows 0..255
-            const int rw = (slot - 8) * 16 + srow;
-            const int c = spos ^ ((-(rw >> 4)) & 3);
-            int n = n0 + rw;
-            n = n < p.N ? n : p.N - 1;
-            goff[q] = (unsigned)n * (unsigned)(p.ldw * 2) + c * 16;
-        }
-    }
-    const char* Ab = reinterpret_cast<const char*>(p.A);
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-    auto stage = [&](int kt, int slot) {
-        char* base = lds + slot * SLOT_BYTES;
-        const char* ak = Ab + (size_t)kt * (BKS * 2);  // wave-uniform bases -> saddr + 32-bit voffset addressing
-        const char* wk = Wb + (size_t)kt * (BKS * 2);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            char* dst = base + (q * 4 + wave) * 1024;  // instruction slot s covers LDS rows [16s, 16s+16)
-            __builtin_amdgcn_global_load_lds(GLB_PTR((q < 2 ? ak : wk) + goff[q]), LDS_PTR(dst), 16, 0, 0);
-        }
-    };
-
-    // ---- fragment addresses
-    const int rho = lane & 15, qd = lane >> 4;
-    const int cc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
-    const int xoff = rho * RB + cc;
-    const int woff = A_BYTES + (wave * 64 + 16 * (rho >> 2) + (rho & 3)) * RB + cc;
-
-    f32x4 acc[4][TM];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 wf0[4], xf0[TM], wf1[4], xf1[TM];
-#define LOAD_FRAGS(WF, XF, SLOT)                                                                       \
-    do {                                                                                               \
-        const char* b_ = lds + (SLOT) * SLOT_BYTES;                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
-            WF[i] = *reinterpret_cast<const bf16x8*>(b_ + woff + i * 4 * RB);                          \
-        _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                 \
-            XF[j] = *reinterpret_cast<const bf16x8*>(b_ + xoff + j * 16 * RB);                         \
-    } while (0)
-#define COMPUTE(WF, XF)                                                                                \
-    do {                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); \
-    } while (0)
-    // one K step: frags of step kt are in (WFc, XFc); prefetch step kt+1 into (WFn, XFn)
-#define KSTEP(kt, WFc, XFc, WFn, XFn)                                                                  \
-    do {                                                                                               \
-        if ((kt) + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        __builtin_amdgcn_s_barrier();                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        if constexpr (!(ABL & 1)) {                                                                    \
-            if ((kt) + 3 < nk) stage((kt) + 3, slot_c);                                                \
-        }                                                                                              \
-        if ((kt) + 1 < nk) LOAD_FRAGS(WFn, XFn, slot_n);                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        COMPUTE(WFc, XFc);                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        slot_c = slot_n;                                                                               \
-        slot_n = (slot_n == NSLOT - 1) ? 0 : slot_n + 1;                                               \
-    } while (0)
-
-    const int nk = p.K / BKS;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 2) stage(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    LOAD_FRAGS(wf0, xf0, 0);
-    int slot_c = 0, slot_n = 1;
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        KSTEP(kt, wf0, xf0, wf1, xf1);
-        KSTEP(kt + 1, wf1, xf1, wf0, xf0);
-    }
-    if (kt < nk) KSTEP(kt, wf0, xf0, wf1, xf1);
-#undef KSTEP
-#undef COMPUTE
-#undef LOAD_FRAGS
-
-    if constexpr (ABL & 4) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-    } else {
-        gemm_epilogue<TM, EPI>(p, acc, m0, n0 + wave * 64, lane);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 3 (default): PERSISTENT ping-pong.  One workgroup per CU walks its share of the output tiles; the
-// phase sequence of variant 1 simply continues across tile boundaries:
-//     ... L1 C1 | E(tile T) | L0 C0 L1 C1 ... (tile T+1)
-// The DMA of the next tile's first K step is issued in the last L0 of the current tile (the LDS buffer parity
-// keeps alternating), so no tile starts with a cold prologue, and because group B runs one phase behind group
-// A, A's epilogue overlaps B's last MFMA phase and B's epilogue overlaps A's first loads: per tile the matrix
-// pipe idles for about one epilogue instead of prologue + epilogue + store drain.  Epilogue stores are
-// fire-and-forget; they retire (in vmcnt order) before the next L1's vmcnt(0), two phases later.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_ppp_kernel(const GemmParams p) {
-    constexpr int TM = 8, NW = 8;
-    constexpr int BM = 256, BN = 256;
-    constexpr int ROWS = BM + BN;
-    constexpr int BUF_BYTES = ROWS * ROW_BYTES;
-    constexpr int STAGE_INSTR = 8;
-
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    // tiles of this workgroup: XCD x = blockIdx % 8 owns the contiguous chunk [lo, hi) of the n-fastest tile order;
-    // its workgroups take tiles lo + (blockIdx / 8), stepping by the number of workgroups on that XCD.
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
-    const int wpx = (gridDim.x + 7 - xcd) >> 3;  // workgroups living on this XCD
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
-    int tile = lo + wl;
-    if (tile >= hi) return;  // fewer tiles than workgroups on this XCD (whole workgroup leaves together)
-
-    const int srow = lane >> 3, schunk = lane & 7;
-    const char* gsrc[STAGE_INSTR];
-    auto set_sources = [&](int t) {
-        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
-#pragma unroll
-        for (int q = 0; q < STAGE_INSTR; ++q) {
-            const int r = (q * NW + wave) * 8 + srow;
-            if (r < BM) {
-                const int c = schunk ^ ((r >> 1) & 7);
-                int m = m0 + r;
-                m = m < p.M ? m : p.M - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
-            } else {
-                const int rw = r - BM;
-                const int c = schunk ^ (((rw >> 1) & 1) | (((rw >> 4) & 3) << 1));
-                int n = n0 + rw;
-                n = n < p.N ? n : p.N - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
-            }
-        }
-    };
-    auto stage = [&](int kt, int buf) {
-        char* base = lds + buf * BUF_BYTES;
-#pragma unroll
-        for (int q = 0; q < STAGE_INSTR; ++q) {
-            char* dst = base + (q * NW + wave) * 8 * ROW_BYTES;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kt * ROW_BYTES), LDS_PTR(dst), 16, 0, 0);
-        }
-    };
-
-    const int fx = (lane >> 1) & 7;
-    const int xoff = (wm * TM * 16 + (lane & 15)) * ROW_BYTES;
-    const int woff = (BM + wn * 64 + 16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
-    const int c0 = (((lane >> 4)) ^ fx) << 4;
-    const int c1 = (((lane >> 4) + 4) ^ fx) << 4;
-
-    f32x4 acc[4][TM];
-    bf16x8 wf[4], xf[TM];
-    auto load_frags = [&](const char* b, int cc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * ROW_BYTES + cc);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * ROW_BYTES + cc);
-    };
-    auto compute = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define PHASE_BARRIER()                          \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __builtin_amdgcn_s_barrier();            \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-
-    const int nk = p.K / BK;
-    if (p.stagger > 0) {
-        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    set_sources(tile);
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_BARRIER();
-    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
-
-    int v = 0;  // running K-step count: LDS buffer parity continues across tiles
-    while (true) {
-        const int next = tile + wpx;
-        const bool has_next = next < hi;
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt, ++v) {
-            const char* b = lds + (v & 1) * BUF_BYTES;
-            // L0
-            load_frags(b, c0);
-            if (kt + 1 < nk) {
-                stage(kt + 1, (v + 1) & 1);
-            } else if (has_next) {
-                set_sources(next);
-                stage(0, (v + 1) & 1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PHASE_BARRIER();
-            compute();  // C0
-            PHASE_BARRIER();
-            load_frags(b, c1);  // L1
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            PHASE_BARRIER();
-            compute();  // C1
-            PHASE_BARRIER();
-        }
-        // E
-        if constexpr (ABL & 4) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-        } else {
-            gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
-        }
-        PHASE_BARRIER();
-        if (!has_next) break;
-        tile = next;
-    }
-    if (wm == 0) PHASE_BARRIER();  // balance the barrier count of the two groups
-#undef PHASE_BARRIER
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 4: ping-pong wave groups over a DEEP LDS ring.  Tile 256 x 256, K step 32, ring of R slots of 32 KB
-// (R = 5 uses all 160 KB of the CU).  The L2->LDS DMA path moves at most ~70 GB/s per CU, i.e. a 64-KB K=64
-// stage needs ~0.9 us of transfer on top of its latency, more than the ~1.1 us one such stage of MFMA work lasts:
-// with two 64-KB buffers the DMA queue runs dry every step.  Here R-1 stages (up to 128 KB) are in flight,
-// issued 4 per wave per phase with a counted vmcnt, so the DMA path streams continuously while the two wave
-// groups alternate L (12 ds_read_b128 + 4 DMA issues) and C (32 MFMA) phases one barrier apart.
-//   RAW: stage v+1 is waited for (vmcnt(4*(D-1))) by every wave at the end of its L(v); group A reads it two
-//        barriers later at the earliest.   WAR: stage v+D overwrites the slot of tile v-1, whose last reads
-//        (group B's L(v-1)) finished one barrier before group A issues it.   D = R-1.
-template <int EPI, int R, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p) {
-    constexpr int TM = 8, NW = 8;
-    constexpr int BM = 256, BN = 256;
-    constexpr int RB = 64;                       // bytes per LDS row (K step 32)
-    constexpr int SLOT_BYTES = (BM + BN) * RB;   // 32 KB
-    constexpr int A_BYTES = BM * RB;
-    constexpr int D = R - 1;
-    constexpr int KSB = 64;                      // global bytes per K step
-
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // staging: 32 wave-instructions (16 rows x 64 B) per stage, wave w issues instruction slots q*8 + w, q < 4
-    const int srow = lane >> 2, spos = lane & 3;
-    const char* gsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int slot = q * NW + wave;  // 0..15 activation rows, 16..31 weight rows
-        if (q < 2) {
-            const int r = slot * 16 + srow;
-            const int c = spos ^ ((-(r >> 2)) & 3);
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
-            gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16;
-        } else {
-            const int rw = (slot - 16) * 16 + srow;
-            const int c = spos ^ ((-(rw >> 4)) & 3);
-            int n = n0 + rw;
-            n = n < p.N ? n : p.N - 1;
-            gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16;
-        }
-    }
-    auto stage = [&](int v, int slot) {
-        char* base = lds + slot * SLOT_BYTES;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            char* dst = base + (q * NW + wave) * 1024;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)v * KSB), LDS_PTR(dst), 16, 0, 0);
-        }
-    };
-
-    const int rho = lane & 15, qd = lane >> 4;
-    const int cc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
-    const int xoff = (wm * TM * 16 + rho) * RB + cc;
-    const int woff = A_BYTES + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB + cc;
-
-    f32x4 acc[4][TM];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 wf[4], xf[TM];
-    auto load_frags = [&](const char* b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
-    };
-#define PHASE_BARRIER()                          \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __builtin_amdgcn_s_barrier();            \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-
-    const int nk = p.K / 32;
-    // prologue: stages 0..D-1 in flight, stage 0 landed
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) stage(d, d);
-    if (nk >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_BARRIER();
-    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
-
-    int slot = 0, pslot = D;  // slot of tile v, slot receiving tile v+D
-    for (int v = 0; v < nk; ++v) {
-        // L(v)
-        load_frags(lds + slot * SLOT_BYTES);
-        if constexpr (!(ABL & 1)) {
-            if (v + D < nk) stage(v + D, pslot);
-        }
-        // stage v+1 must have landed (own part): allow the D-1 younger stages to stay in flight
-        if (v + D < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PHASE_BARRIER();
-        // C(v)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_BARRIER();
-        slot = (slot == R - 1) ? 0 : slot + 1;
-        pslot = (pslot == R - 1) ? 0 : pslot + 1;
-    }
-    if (wm == 0) PHASE_BARRIER();
-#undef PHASE_BARRIER
-
-    if constexpr (ABL & 4) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-    } else {
-        gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane, lds + wave * 16384);
-    }
-}
-
-
-// Epilogue of one wave's 128 x 64 accumulator block (shared by the K = 32 ring kernel and the K = 64 kernel): bias /
-// activation, bf16 outputs transposed through the wave's 4 KB LDS scratch so that every store instruction writes whole
-// 128-B lines, non-temporal stores.
-// SCRATCH = false: no LDS at all.  Lanes rho and rho^1 (rows m and m+1 of the same 16-column group) swap one half of their
-// 16 columns with a DPP quad permute, after which every lane holds 8 columns of ONE row per store and the 8 lanes of a row
-// pair write a complete 128-B line per store instruction (even rows, then odd rows).
-// BIAS_IN_ACC: the accumulators were initialised with the bias (free: a register move instead of a zero), no add here.
 template <int EPI, int ABL, bool SCRATCH = true, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane, char* scratch) {
     constexpr int TM = 8;
@@ -1312,158 +709,6 @@ extern int g_gm;
 int num_cus();
 
 // ---------------------------------------------------------------------------------------------------------
-// Variant 10: the persistent ping-pong schedule of variant 6 on K = 64 STAGES (128-B tile rows).
-// Why: the L2 -> LDS DMA moves whole 128-B cache lines; with 64-B rows (K step 32) every line is fetched in two halves by
-// two different stages and the fill rate is 37 B/clk/CU instead of 60 (tools/experiments/gemm_lab.hip, LAB_DMA), which at
-// 32 B/clk/CU of demand made the fill stream the bottleneck of variant 6.
-//   * two 64 KB stage buffers (A rows 0..255, W rows 256..511, 128 B each) + 32 KB epilogue scratch = 160 KB;
-//   * a stage is consumed in two k halves, each with its own load (L) and MFMA (C) phase as in variant 6;
-//   * the whole stage v+1 (8 DMA instructions per wave) is issued in L(v, 0), right after the other buffer's last readers
-//     passed; it must have landed at the barrier that ends C(v, 1): two k halves (~2200 clocks) of latency cover, the same as
-//     a 3-slot K = 32 ring, which costs nothing (a 2-slot ring loses 35 %);
-//   * the DMA stream continues across tile boundaries (the stage issued in the last L(., 0) belongs to the next tile).
-// LDS chunk swizzles for 128-B rows: activation rows by (row >> 1) & 7, weight rows by ((row >> 1) & 1) | (((row >> 4) & 3) << 1).
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_k64_kernel(const GemmParams p) {
-    constexpr int TM = 8, NW = 8;
-    constexpr int BM = 256, BN = 256, RB = 128;
-    constexpr int STAGE = (BM + BN) * RB, A_BYTES = BM * RB;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    char* scratch = lds + 2 * STAGE + wave * 4096;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
-    const int wpx = (gridDim.x + 7 - xcd) >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
-    int tile = lo + wl;
-    if (tile >= hi) return;
-
-    // staging: a wave-instruction covers 8 rows x 128 B; wave w issues slots q*8 + w, q < 8 (slots 0..31 A rows, 32..63 W rows)
-    const int srow = lane >> 3, spos = lane & 7;
-    unsigned goff[8];  // byte offsets of this lane's source chunk from p.A (q < 4) / p.W (q >= 4)
-    const char* Ab = reinterpret_cast<const char*>(p.A);
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-    auto set_sources = [&](int t) {
-        int tm_, tn_;
-        tile_coords(p, t, tm_, tn_);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int slot = q * NW + wave;
-            if (q < 4) {
-                const int r = slot * 8 + srow;
-                const int c = spos ^ ((r >> 1) & 7);
-                int m = tm_ * BM + r;
-                m = m < p.M ? m : p.M - 1;
-                goff[q] = (unsigned)m * (unsigned)(p.lda * 2) + c * 16;
-            } else {
-                const int r = (slot - 32) * 8 + srow;
-                const int c = spos ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1));
-                int n = tn_ * BN + r;
-                n = n < p.N ? n : p.N - 1;
-                goff[q] = (unsigned)n * (unsigned)(p.ldw * 2) + c * 16;
-            }
-        }
-    };
-    auto stage = [&](int kstage, int buf) {
-        char* base = lds + buf * STAGE;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const char* src = (q < 4 ? Ab : Wb) + (size_t)kstage * 128 + goff[q];
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (q * NW + wave) * 1024), 16, 0, 0);
-        }
-    };
-
-    const int rho = lane & 15, qd = lane >> 4;
-    const int xkey = (rho >> 1) & 7, wkey = ((rho >> 1) & 1) | ((rho >> 2) << 1);
-    const int xrow = (wm * TM * 16 + rho) * RB;
-    const int wrow = A_BYTES + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * RB;
-
-    f32x4 acc[4][TM];
-    bf16x8 wf[4], xf[TM];
-#define PHASE_BARRIER()                          \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __builtin_amdgcn_s_barrier();            \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-
-    auto epilogue = [&](int t) {
-        int tm_, tn_;
-        tile_coords(p, t, tm_, tn_);
-        wave_tile_epilogue<EPI, ABL>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
-    };
-
-    const int nk = p.K / 64;  // launcher: K % 64 == 0, nk >= 1
-    set_sources(tile);
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_BARRIER();
-    if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
-
-    int buf = 0;
-    while (true) {
-        const int next = tile + wpx;
-        const bool has_next = next < hi;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int v = 0; v < nk; ++v) {
-            const char* b = lds + buf * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // ---- L(v, ks)
-                {
-                    const int cx = ((ks * 4 + qd) ^ xkey) << 4, cw = ((ks * 4 + qd) ^ wkey) << 4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + wrow + i * 4 * RB + cw);
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xrow + j * 16 * RB + cx);
-                }
-                if (ks == 0) {
-                    if constexpr (!(ABL & 1)) {
-                        if (v + 1 < nk) {
-                            stage(v + 1, buf ^ 1);
-                        } else if (has_next) {
-                            set_sources(next);
-                            stage(0, buf ^ 1);
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PHASE_BARRIER();
-                // ---- C(v, ks)
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                if (ks == 1) {
-                    // stage v+1 (issued two k halves ago) must have landed before the barrier that lets anyone read it
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
-                }
-                PHASE_BARRIER();
-            }
-            buf ^= 1;
-        }
-        if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
-        if (!has_next) break;
-        tile = next;
-    }
-    if (wm == 0) PHASE_BARRIER();
-#undef PHASE_BARRIER
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Variant 12: 128-B tile rows (whole cache lines per DMA row, see variant 10) on a RING OF FIVE HALF-STAGES.
 // A half-stage is the A half (256 rows) or the W half (256 rows) of a K = 64 stage: 32 KB; five slots = all 160 KB of LDS
 // (the epilogue needs no scratch: wave_tile_epilogue<.., false>).  One half-stage (4 DMA instructions per wave) is issued
@@ -1680,223 +925,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
 #undef PHASE_BARRIER
 }
 
-template <int EPI>
-int launch_k64(const GemmParams& p0, hipStream_t s);
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 8: ONE WAVE PER SIMD.  4 waves, each owns a 128 x 128 quadrant of the 256 x 256 tile (64 accumulator tiles =
-// 256 registers per lane), K step 64, two 64 KB LDS stages.  Per stage a wave issues 128 MFMAs (2048 matrix-pipe
-// cycles) and, between them, 32 ds_read_b128 (fragments), 16 global_load_dwordx4 (stage s+2 -> registers) and
-// 16 ds_write_b128 (stage s+1 registers -> LDS): every other instruction is shorter than an MFMA's 16-cycle issue
-// interval, so the matrix pipe can stay busy without a partner wave.  Against the 8-wave schedule: 1/3 fewer LDS bytes
-// per FLOP (128 x 128 instead of 128 x 64 per wave), one barrier per 128 MFMAs, no LDS-DMA issue stalls.
-// LDS rows are 128 B; 16-B chunks are XOR-swizzled (activation rows by (row >> 1) & 7, weight rows by
-// ((row >> 1) & 1) | (((row >> 4) & 3) << 1)), which makes the staging writes and every fragment read conflict free.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256) void gemm_bf16_w1_kernel(const GemmParams p) {
-    constexpr int BM = 256, BN = 256, RBY = 128, KS = 64;
-    constexpr int A_BYTES = BM * RBY, STAGE = (BM + BN) * RBY;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
-    const int wpx = (gridDim.x + 7 - xcd) >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
-
-    // staging: thread -> (row tid >> 3 of a 32-row slab, 16-B chunk tid & 7); slab q = rows 32q .. 32q+31
-    const int srow = tid >> 3, sch = tid & 7;
-    const int a_dst = srow * RBY + ((sch ^ ((srow >> 1) & 7)) << 4);  // + q * 4096
-    // weight rows r = 32q + srow: key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1), (r >> 4) & 3 = (2q + (srow >> 4)) & 3: two values
-    const int w_dst0 = A_BYTES + srow * RBY + ((sch ^ (((srow >> 1) & 1) | (((srow >> 4) & 3) << 1))) << 4);        // even q
-    const int w_dst1 = A_BYTES + srow * RBY + ((sch ^ (((srow >> 1) & 1) | ((((srow >> 4) + 2) & 3) << 1))) << 4);  // odd q
-    // fragments
-    const int rho = lane & 15, qd = lane >> 4;
-    const int xkey = (rho >> 1) & 7, wkey = ((rho >> 1) & 1) | ((rho >> 2) << 1);
-    const int xbase = (wm * 128 + rho) * RBY;                                          // + 16 j rows
-    const int wbase = A_BYTES + (wn * 128 + 16 * (rho >> 2) + (rho & 3)) * RBY;         // + 64 c + 4 i rows
-
-    // two staging register sets (stage parity): global loads run 2.5 stages ahead of their LDS stores
-    u32x4 ra0[8], rw0[8], ra1[8], rw1[8];
-    const char* Ab = reinterpret_cast<const char*>(p.A);
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-    const unsigned a_slab = 32u * (unsigned)(p.lda * 2), w_slab = 32u * (unsigned)(p.ldw * 2);
-    unsigned a_off, w_off, a_offn, w_offn;  // this tile's and the next tile's row offsets (full tiles only)
-    auto offsets = [&](int t, unsigned& ao, unsigned& wo) {
-        int tm_, tn_;
-        tile_coords(p, t, tm_, tn_);
-        ao = (unsigned)(tm_ * BM + srow) * (unsigned)(p.lda * 2) + sch * 16;
-        wo = (unsigned)(tn_ * BN + srow) * (unsigned)(p.ldw * 2) + sch * 16;
-    };
-
-    f32x4 acc[2][4][8];
-    bf16x8 wfa[8], wfb[8], xf[8];  // W fragments of the two 32-wide k halves (double buffer), rolling X fragments
-    const int nk = p.K / KS;      // launcher: even, >= 4
-    const int cx0 = ((qd) ^ xkey) << 4, cx1 = ((4 + qd) ^ xkey) << 4;
-    const int cw0 = ((qd) ^ wkey) << 4, cw1 = ((4 + qd) ^ wkey) << 4;
-    auto rd_w = [&](const char* b, int cw, int idx) {  // idx = 4c + i
-        return *reinterpret_cast<const bf16x8*>(b + wbase + (64 * (idx >> 2) + 4 * (idx & 3)) * RBY + cw);
-    };
-    auto rd_x = [&](const char* b, int cx, int j) { return *reinterpret_cast<const bf16x8*>(b + xbase + 16 * j * RBY + cx); };
-    // accumulators are pinned to AGPRs and updated in place (the builtin lets the register allocator shuttle the 256
-    // accumulator registers between the two halves of the file inside the loop)
-#define W1_GROUP(J, WF)                                                                                              \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[c][i][J]) : "v"(WF[4 * c + i]), "v"(xf[J]))
-    // One stage (K = 64) whose data sits in LDS buffer B:
-    //   k half 0: 8 groups of (2 fragment reads for half 1, 8 MFMAs, [first 4 groups] 4 staging stores of stage s+1 from
-    //             register set RA/RW into the other buffer, whose last readers passed the previous barrier);
-    //   barrier;
-    //   k half 1: 8 groups of (2 fragment reads of stage s+1, 8 MFMAs, 2 global loads of stage s+3 into RA/RW).
-    // X fragment slot j is re-loaded one group after its last use; the reload of slot 7 opens the next half.
-#define W1_STAGE(B, BNX, RA, RW, AK, WK, AO, WO)                                                                     \
-    do {                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
-            if (!(ABL & 2) && j > 0) xf[j - 1] = rd_x(B, cx1, j - 1);                                                \
-            if (!(ABL & 2)) wfb[j] = rd_w(B, cw1, j);                                                                \
-            W1_GROUP(j, wfa);                                                                                        \
-            if (!(ABL & 1) && j < 4) {                                                                               \
-                *reinterpret_cast<u32x4*>(BNX + (2 * j) * 4096 + a_dst) = RA[2 * j];                                 \
-                *reinterpret_cast<u32x4*>(BNX + (2 * j) * 4096 + w_dst0) = RW[2 * j];                                \
-                *reinterpret_cast<u32x4*>(BNX + (2 * j + 1) * 4096 + a_dst) = RA[2 * j + 1];                         \
-                *reinterpret_cast<u32x4*>(BNX + (2 * j + 1) * 4096 + w_dst1) = RW[2 * j + 1];                        \
-            }                                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }                                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
-        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
-            if (!(ABL & 2)) {                                                                                        \
-                if (j == 0) xf[7] = rd_x(B, cx1, 7);                                                                 \
-                else xf[j - 1] = rd_x(BNX, cx0, j - 1);                                                              \
-                wfa[j] = rd_w(BNX, cw0, j);                                                                          \
-            }                                                                                                        \
-            W1_GROUP(j, wfb);                                                                                        \
-            if (!(ABL & 1)) {                                                                                        \
-                RA[j] = *reinterpret_cast<const u32x4*>(AK + (size_t)j * a_slab + AO);                               \
-                RW[j] = *reinterpret_cast<const u32x4*>(WK + (size_t)j * w_slab + WO);                               \
-            }                                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }                                                                                                            \
-        if (!(ABL & 2)) xf[7] = rd_x(BNX, cx0, 7);                                                                   \
-    } while (0)
-
-    char* const buf0 = lds;
-    char* const buf1 = lds + STAGE;
-    int tile = lo + wl;
-    if (tile >= hi) return;
-    // pipeline fill: stage 0 -> LDS buffer 0, stage 1 -> set 1, stage 2 -> set 0
-    offsets(tile, a_off, w_off);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        ra0[q] = *reinterpret_cast<const u32x4*>(Ab + (size_t)q * a_slab + a_off);
-        rw0[q] = *reinterpret_cast<const u32x4*>(Wb + (size_t)q * w_slab + w_off);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        *reinterpret_cast<u32x4*>(buf0 + q * 4096 + a_dst) = ra0[q];
-        *reinterpret_cast<u32x4*>(buf0 + q * 4096 + ((q & 1) ? w_dst1 : w_dst0)) = rw0[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        ra1[q] = *reinterpret_cast<const u32x4*>(Ab + (KS * 2) + (size_t)q * a_slab + a_off);
-        rw1[q] = *reinterpret_cast<const u32x4*>(Wb + (KS * 2) + (size_t)q * w_slab + w_off);
-        ra0[q] = *reinterpret_cast<const u32x4*>(Ab + 2 * (KS * 2) + (size_t)q * a_slab + a_off);
-        rw0[q] = *reinterpret_cast<const u32x4*>(Wb + 2 * (KS * 2) + (size_t)q * w_slab + w_off);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { wfa[j] = rd_w(buf0, cw0, j); xf[j] = rd_x(buf0, cx0, j); }
-
-    while (true) {
-        const int next = tile + wpx;
-        const bool has_next = next < hi;
-        a_offn = a_off; w_offn = w_off;
-        if (has_next) offsets(next, a_offn, w_offn);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nk; s += 2) {
-            // stage s (buffer 0): stores stage s+1 from set 1, loads stage s+3 into set 1
-            {
-                const bool in_tile = s + 3 < nk;
-                const int k3 = in_tile ? s + 3 : s + 3 - nk;
-                const char* ak = Ab + (size_t)k3 * (KS * 2);
-                const char* wk = Wb + (size_t)k3 * (KS * 2);
-                const unsigned ao = in_tile ? a_off : a_offn, wo = in_tile ? w_off : w_offn;
-                W1_STAGE(buf0, buf1, ra1, rw1, ak, wk, ao, wo);
-            }
-            // stage s+1 (buffer 1): stores stage s+2 from set 0, loads stage s+4 into set 0
-            {
-                const bool in_tile = s + 4 < nk;
-                const int k4 = in_tile ? s + 4 : s + 4 - nk;
-                const char* ak = Ab + (size_t)k4 * (KS * 2);
-                const char* wk = Wb + (size_t)k4 * (KS * 2);
-                const unsigned ao = in_tile ? a_off : a_offn, wo = in_tile ? w_off : w_offn;
-                W1_STAGE(buf1, buf0, ra0, rw0, ak, wk, ao, wo);
-            }
-        }
-        // buffer 0 now holds stage 0 of the next tile (its fragments are already on their way); buffer 1 is free once every
-        // wave has left the last stage: it becomes the epilogue scratch (16 KB per wave).
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        int tm_, tn_;
-        tile_coords(p, tile, tm_, tn_);
-        if constexpr (ABL & 4) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sacc += acc[c][i][j][0] + acc[c][i][j][1] + acc[c][i][j][2] + acc[c][i][j][3];
-            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                gemm_epilogue<8, EPI>(p, acc[c], tm_ * BM + wm * 128, tn_ * BN + wn * 128 + 64 * c, lane, buf1 + wave * 16384);
-        }
-        if (!has_next) break;
-        __builtin_amdgcn_s_barrier();  // scratch reads done before the next tile's stage 1 is stored into buffer 1
-        tile = next;
-        a_off = a_offn; w_off = w_offn;
-    }
-#undef W1_STAGE
-#undef W1_GROUP
-}
-
-template <int EPI>
-int launch_w1(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
-    if (p.gm < 1) p.gm = 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < num_cus() ? nwg : num_cus();
-    const size_t lds = 2 * (size_t)512 * 128;
-    auto kern = gemm_bf16_w1_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
-}
-
 template <int TM, int WM, int WN, int EPI>
 int launch_cfg(const GemmParams& p0, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
@@ -1905,71 +933,26 @@ int launch_cfg(const GemmParams& p0, hipStream_t s) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = 2 * (size_t)(BM + BN) * ROW_BYTES;
     auto kern = gemm_bf16_kernel<TM, WM, WN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16");
     return BSI_OK;
 }
 
-int g_variant = 12;  // 0: two-barrier double buffer, 1: ping-pong wave groups, 2: two workgroups per CU,
-                    // 3: persistent ping-pong (default)
-int g_stagger = 0;
+int g_variant = 12;  // 12: production (K = 64 half-stage ring + K = 32 ring), 6: K = 32 ring only
+int g_stagger = 0;   // laboratory: start stagger of the persistent kernels, units of 16 x 64 clocks
 int g_gm = 4;  // band height: 4 m-tiles x 8 n-tiles per XCD round minimises L2 misses (PMC: fc1 605 -> 403 MB per launch)
-int g_num_cus = 0;
+int g_num_cus[64] = {};
 
-int num_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0;
+int num_cus() {  // of the CURRENT device (a process may drive several)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (g_num_cus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus[dev] = prop.multiProcessorCount;
+        if (g_num_cus[dev] <= 0) g_num_cus[dev] = 256;
     }
-    return g_num_cus;
-}
-
-template <int EPI, int R>
-int launch_ring(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    const size_t lds = (size_t)R * 512 * 64;
-    auto kern = gemm_bf16_ring_kernel<EPI, R>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
-}
-
-int num_cus();
-
-template <int EPI>
-int launch_k64(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
-    if (p.gm < 1) p.gm = 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < num_cus() ? nwg : num_cus();
-    const size_t lds = 2 * (size_t)512 * 128 + 32768;
-    auto kern = gemm_bf16_k64_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
+    return g_num_cus[dev];
 }
 
 template <int EPI>
@@ -1984,11 +967,7 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     const size_t lds = 5 * (size_t)256 * 128;
     p.stagger = g_stagger;
     auto kern = gemm_bf16_k64r_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16");
     return BSI_OK;
@@ -2006,92 +985,19 @@ int launch_pring(const GemmParams& p0, hipStream_t s) {
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
     auto kern = gemm_bf16_pring_kernel<EPI, 0, ROLL, 4, CDMA>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
-}
-
-template <int EPI>
-int launch_ppp(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    p.stagger = g_stagger;
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < g_num_cus ? nwg : g_num_cus;
-    const size_t lds = 2 * (size_t)512 * ROW_BYTES;
-    auto kern = gemm_bf16_ppp_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
-}
-
-template <int EPI>
-int launch_w4(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 127) / 128;
-    p.tiles_n = (p.N + 255) / 256;
-    const size_t lds = 3 * (size_t)384 * 64;
-    auto kern = gemm_bf16_w4_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, s, p);
-    BSI_CHECK_LAUNCH("bsi_gemm_bf16");
-    return BSI_OK;
-}
-
-template <int EPI>
-int launch_pp(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    const size_t lds = 2 * (size_t)512 * ROW_BYTES;
-    auto kern = gemm_bf16_pp_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16");
     return BSI_OK;
 }
 
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t s) {
-    if (g_variant == 8 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 256 && p.K % 128 == 0) return launch_w1<EPI>(p, s);
+    // variant 12 (production): bf16-output epilogues with K >= 128 on the K = 64 half-stage ring, everything else large on the
+    // K = 32 ring; variant 6: the K = 32 ring for every epilogue (the A/B partner of the full-size tests)
     if (g_variant == 12 && EpiTraits<EPI>::out_bf16 && p.M > 128 && p.K >= 128 && p.K % 64 == 0) return launch_k64r<EPI>(p, s);
-    if (g_variant == 11 && p.M > 128 && p.K >= 96) return launch_pring<EPI, false, true>(p, s);
-    if (g_variant == 10 && p.M > 128 && p.K >= 64 && p.K % 64 == 0) return launch_k64<EPI>(p, s);
-    if (g_variant == 9 && p.M > 128 && p.K >= 96) return launch_pring<EPI, true>(p, s);
-    if ((g_variant == 6 || g_variant == 8 || g_variant == 10 || g_variant == 12) && p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
-    if (g_variant == 4 && p.M > 128) return launch_ring<EPI, 5>(p, s);
-    if (g_variant == 5 && p.M > 128) return launch_ring<EPI, 4>(p, s);
-    if (g_variant == 3 && p.M > 128) return launch_ppp<EPI>(p, s);
-    const bool off32 = (size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.N * p.ldw * 2 < (1ull << 32);
-    if (g_variant == 2 && p.M > 128 && off32) return launch_w4<EPI>(p, s);
-    if (g_variant == 1 && p.M > 128) return launch_pp<EPI>(p, s);
-    // Large problems: 256x256 tile, 8 waves (2x4), wave tile 128x64.
+    if (p.M > 128 && p.K >= 96) return launch_pring<EPI>(p, s);
+    // Large problems with a short K: 256x256 tile, 8 waves (2x4), wave tile 128x64.
     // Small M (adaLN tables, tiny test models): 64x256 tile, 4 waves (1x4), wave tile 64x64... keeps N coverage.
     if (p.M > 128) return launch_cfg<8, 2, 4, EPI>(p, s);
     return launch_cfg<4, 2, 4, EPI>(p, s);
@@ -2159,11 +1065,7 @@ int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
     auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32, 0, false, 4, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16_ws");
     const size_t total = (size_t)p.M * (p.N / 4);
@@ -2178,10 +1080,12 @@ int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t
 }  // namespace
 
 extern "C" int bsi_gemm_set_variant(int v) {
-    BSI_CHECK_ARG(v >= 0 && (v & 0xff) <= 12, "bsi_gemm_set_variant: unknown variant %d", v);
+    BSI_CHECK_ARG(v >= 0 && ((v & 0xff) == 12 || (v & 0xff) == 6),
+                  "bsi_gemm_set_variant: unknown variant %d (12 = production, 6 = K = 32 ring; the other round-1 schedules live in "
+                  "tools/experiments/gemm_variants.inc)", v & 0xff);
     g_variant = v & 0xff;
-    g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger of variant 3, in units of 64 clocks per step
-    g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of variant 6
+    g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger, in units of 64 clocks per step
+    g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of the tile walk
     return BSI_OK;
 }
 
@@ -2238,8 +1142,9 @@ extern "C" size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K) {
 extern "C" int bsi_gemm_bf16_ws(const bsi_gemm_args* a, void* workspace, size_t workspace_bytes, bsi_stream_t stream) {
     // small-M latency path: split-K through the caller's workspace when the shape qualifies, the epilogue is a plain bf16 one
     // and the workspace is large enough; otherwise exactly bsi_gemm_bf16
-    if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 &&
-        a->lda >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && a->ldo >= a->N &&
+    // the SAME argument contract as bsi_gemm_bf16 on both paths (round 1 skipped the N % 16 and K % 64 checks here)
+    if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0 && a->N % 16 == 0 &&
+        a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && a->ldo >= a->N &&
         (a->epilogue == BSI_EPI_BIAS_BF16 || a->epilogue == BSI_EPI_BIAS_GELU_BF16 || a->epilogue == BSI_EPI_BIAS_SILU_BF16)) {
         const int sp = splitk_plan(a->M, a->N, a->K);
         if (sp > 1 && workspace_bytes >= (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float)) {

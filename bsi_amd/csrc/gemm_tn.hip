@@ -381,12 +381,7 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
         p.colsum = direct ? colsum_out : cs_slabs;
         p.colsum_stride = n4;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  T_R * T_SLOT);
-        attr_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T_R * T_SLOT);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");
     if (!direct) {

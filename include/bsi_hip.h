@@ -97,6 +97,15 @@ int bsi_refine_step(const float* mu, const float* f, const float* eps, const flo
                     const float* c_skip, const float* c_out, int i, int f_is_xhat, int rows, int D,
                     float* x_hat_out, float* y_out, float* mu_next, bsi_stream_t stream);
 
+/* The same step with the Gaussian measurement noise generated IN the kernel (opt-in, BSI.sample(device_noise=True)):
+ * Philox4x32-10 keyed by the 64-bit `seed` in device memory, counter = (group of four elements, noise stream `i`), Box-Muller.
+ * bsi_philox_normal writes the same stream to memory (out[4g .. 4g+3] = the four normals of group g of stream `stream_id`),
+ * used for mu_0 (bsi.py:325) and by the tests: bsi_refine_step with eps = bsi_philox_normal(seed, i) is bit-identical. */
+int bsi_refine_step_philox(const float* mu, const float* f, const unsigned long long* seed, const float* lam,
+                           const float* alpha, const float* c_skip, const float* c_out, int i, int f_is_xhat, int rows, int D,
+                           float* x_hat_out, float* y_out, float* mu_next, bsi_stream_t stream);
+int bsi_philox_normal(const unsigned long long* seed, unsigned stream_id, size_t n, float* out, bsi_stream_t stream);
+
 /* bsi.py:309-310, 273-274, 288-289: out[r] = w[r] * scale * reduce_D((x[r % B] - x_hat[r])^2),
  * reduce = mean if mean != 0 else sum.  diff_out (nullable) receives x - x_hat for the backward. */
 int bsi_sqerr_rows(const float* x, const float* x_hat, const float* w, float scale, int mean, int rows,
@@ -225,9 +234,9 @@ size_t bsi_colsum_workspace_bytes(int N);
 int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,
                     bsi_stream_t stream);
 
-/* Tuning/testing hook: main-loop schedule of the large-tile GEMM. 0 = two-barrier double buffer,
- * 1 = ping-pong wave groups, 2 = two workgroups per CU, 3 = persistent ping-pong (default).  Bits 8.. select the
- * start stagger of variant 3.  Results are bit-identical between variants. */
+/* Testing hook: schedule of the large-tile GEMM.  12 (default) = bf16-output epilogues on the K = 64 half-stage ring, fp32-output
+ * ones on the K = 32 ring; 6 = the K = 32 ring for every epilogue (A/B partner of the full-size tests).  Bits 8..15: start
+ * stagger (laboratory), bits 16..23: band height of the tile walk.  The two schedules agree to one bf16 ulp. */
 int bsi_gemm_set_variant(int variant);
 
 /* dit.py:50-55,66,96: out_bf16[m,:] = LayerNorm(x[m,:]; eps, no affine) * (1 + scale[row]) + shift[row]

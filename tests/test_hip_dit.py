@@ -652,3 +652,20 @@ def test_sample_graph_survives_weight_update_and_workspace_growth():
     a2, b2 = pair(5)
     assert torch.equal(a2, b2)
     assert not torch.equal(a2, a0)                                   # the weights did change
+
+
+def test_sample_with_device_noise():
+    """BSI.sample(device_noise=True): measurement noise generated in the kernels from one seed drawn from the generator --
+    reproducible for a generator state, different for another, finite, and statistically the same chain (first two moments
+    of the final samples over a batch agree with the torch.randn path within sampling error)."""
+    bsi = make_bsi(make_model("dit_ff", True), k=8)
+    dev = torch.device(DEV, 0)
+    with torch.no_grad():
+        a = bsi.sample(64, torch.Generator(dev).manual_seed(3), device_noise=True)
+        b = bsi.sample(64, torch.Generator(dev).manual_seed(3), device_noise=True)
+        c = bsi.sample(64, torch.Generator(dev).manual_seed(4), device_noise=True)
+        r = bsi.sample(64, torch.Generator(dev).manual_seed(3))
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all() and a.shape == r.shape
+    assert abs(float(a.mean()) - float(r.mean())) < 0.05 and abs(float(a.std()) / float(r.std()) - 1) < 0.1
+    with pytest.raises(RuntimeError):
+        bsi.sample(2, torch.Generator(dev).manual_seed(3), device_noise=True, graph=True)

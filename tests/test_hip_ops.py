@@ -129,6 +129,47 @@ def test_refine_step_and_combine(N):
     assert torch.equal(gf.cpu(), cor[:, None] * f) and torch.equal(gm.cpu(), csr[:, None] * f)
 
 
+def test_philox_device_noise(N):
+    """In-kernel Gaussian noise (opt-in): moments of the generator, independence of the streams, and the fused step
+    bsi_refine_step_philox == bsi_refine_step fed with the same stream written to memory by bsi_philox_normal (bit for bit)."""
+    P, o = params(N)
+    n = 1 << 20
+    seed = dev(torch.tensor([0x1234_5678_9ABC_DEF], dtype=torch.int64))
+    a, b, a2 = empty(n), empty(n), empty(n)
+    N.check(N.lib().bsi_philox_normal(N.ptr(seed), 3, n, N.ptr(a), N.stream()))
+    N.check(N.lib().bsi_philox_normal(N.ptr(seed), 4, n, N.ptr(b), N.stream()))
+    N.check(N.lib().bsi_philox_normal(N.ptr(seed), 3, n, N.ptr(a2), N.stream()))
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    for x in (a.double().cpu(), b.double().cpu()):
+        assert abs(float(x.mean())) < 5e-3 and abs(float(x.var()) - 1) < 1e-2
+        assert abs(float((x ** 3).mean())) < 2e-2 and abs(float((x ** 4).mean()) - 3) < 6e-2
+        assert float(x.abs().max()) < 6.0 and float((x.abs() > 3).double().mean()) == pytest.approx(0.0027, abs=5e-4)
+    assert abs(float((a.double() * b.double()).mean())) < 5e-3                       # streams are uncorrelated
+    assert abs(float((a[0::4].double() * a[1::4].double()).mean())) < 1e-2           # and so are a group's four normals
+    other = dev(torch.tensor([77], dtype=torch.int64))
+    N.check(N.lib().bsi_philox_normal(N.ptr(other), 3, n, N.ptr(a2), N.stream()))
+    assert not torch.equal(a, a2)
+    # fused step
+    gen = torch.Generator().manual_seed(5)
+    rows, D, k, i = 6, 192, 8, 3
+    mu, f = dev(torch.randn((rows, D), generator=gen)), dev(torch.randn((rows, D), generator=gen))
+    t = torch.linspace(0, 1, k + 1)
+    lam = o.p_lambda.icdf(t)
+    alpha = lam.diff()
+    cs, co, ci = o.edm_coeffs(t)
+    eps = empty(rows, D)
+    N.check(N.lib().bsi_philox_normal(N.ptr(seed), i, rows * D, N.ptr(eps), N.stream()))
+    outs = []
+    for philox in (False, True):
+        xh, y, mn = empty(rows, D), empty(rows, D), empty(rows, D)
+        fn = N.lib().bsi_refine_step_philox if philox else N.lib().bsi_refine_step
+        N.check(fn(N.ptr(mu), N.ptr(f), N.ptr(seed) if philox else N.ptr(eps), N.ptr(dev(lam)), N.ptr(dev(alpha)), N.ptr(dev(cs)),
+                   N.ptr(dev(co)), i, 0, rows, D, N.ptr(xh), N.ptr(y), N.ptr(mn), N.stream()))
+        outs.append((xh, y, mn))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
 def test_sqerr_and_backward(N):
     gen = torch.Generator().manual_seed(4)
     B, n, D = 5, 3, 3072

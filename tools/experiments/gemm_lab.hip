@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../bsi_amd/csrc/gemm_bf16.hip"
+#include "gemm_variants.inc"
 #include "../../bsi_amd/csrc/bsi_ops.hip"  // bsi_set_error
 
 template <int EPI, int ABL>

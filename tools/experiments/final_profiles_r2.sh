@@ -1,0 +1,44 @@
+# Produces every file of profiles/r2 that DESIGN.md / profiles/README.md cite, in one gpurun call:
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/experiments/final_profiles_r2.sh'
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r2; rm -rf $O; mkdir -p $O
+B1="--train-steps 0 --no-cpu-baseline --no-secondary"
+# PMC traffic of the dominant kernel first (bench.py reads profiles/fc1_traffic.json): two separate --pmc passes, k=4
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --k 4 --steps 1 --warmup 1 $B1 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --k 4 --steps 1 --warmup 1 $B1 > /dev/null 2>&1
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 'gemm_bf16_k64r_kernel<2, 0>' $O/fc1_traffic.json 256 > /dev/null && cp $O/fc1_traffic.json profiles/fc1_traffic.json
+rm -rf $O/pmc_fetch $O/pmc_write
+# the benchmark as the driver runs it by default, then the same command under the profiler (kernel stats must agree with the live HIP-event average)
+timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-300 $O/bench_default.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -- python3 bench.py --no-cpu-baseline --no-secondary > $O/bench_default_under_rocprof.json 2>/dev/null
+timeout 300 python bench.py --steps 1 --warmup 1 $B1 --breakdown 2> $O/bench_default_breakdown.txt >/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_prof -- python3 tools/train_profile.py > /dev/null 2>&1
+cp $O/bench_prof/*/*_kernel_stats.csv $O/bench_default_kernel_stats.csv
+cp $O/train_prof/*/*_kernel_stats.csv $O/train_step_kernel_stats.csv
+rm -rf $O/bench_prof $O/train_prof
+# utilisation counters of the dominant kernels (one --pmc pass per group, bench command with k=4)
+for grp in "MfmaUtil" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_TA_BUSY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_$tag -- python3 bench.py --k 4 --steps 1 --warmup 1 $B1 > /dev/null 2>&1
+done
+python3 - <<'PY'
+import csv, glob, json, collections
+O = "gpurun_out/r2"
+res = collections.defaultdict(dict)
+for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        short = "fc1 gemm_bf16_k64r_kernel<2,0>" if "k64r_kernel<2, 0>" in k else "qkv/out/fc2 gemm_bf16_k64r_kernel<1,0>" if "k64r_kernel<1, 0>" in k else \
+                "attention_fwd_p_kernel" if "attention_fwd_p_kernel" in k else "ln_modulate_kernel" if "ln_modulate" in k else None
+        if short:
+            acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        for c, v in cs.items():
+            res[k][c] = {"mean": sum(v) / len(v), "launches": len(v)}
+json.dump(res, open(O + "/pmc_util.json", "w"), indent=1)
+for k, cs in res.items():
+    print(k, {c: round(v["mean"], 1) for c, v in cs.items()})
+PY
+rm -rf $O/pmc_*/
+ls -la $O

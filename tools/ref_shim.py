@@ -5,9 +5,9 @@ The reference needs Python >= 3.11 (PEP 646 star-subscript at bsi/bsi.py:411) an
 and compiles `bsi/bsi.py` from an in-memory, one-token rewrite
 (`x[*(...)]` -> `x[(...)]`, semantically identical).  Nothing is written under
 /root/reference and nothing from it is copied into this repository: the shim is
-used only by `tools/gen_golden.py` (fixture generation) and by the optional
-`tests/test_oracle_vs_reference.py` cross-check, both of which skip when
-/root/reference is absent (e.g. on the GPU box).
+used only by the fixture generators (`tools/gen_golden.py`, `tools/gen_golden_algos.py`,
+`tools/gen_golden_drivers.py`), which run in the build container; nothing under `tests/`,
+`bench.py` or `__graft_entry__.py` imports it (the GPU box has no /root/reference).
 """
 import importlib
 import os

@@ -178,22 +178,27 @@ __host__ __device__ __forceinline__ unsigned bsi_mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned long long idx) {
-    const unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
-    return bsi_mix32(lo ^ bsi_mix32(hi + c.s0) ^ c.s1) >= c.thr;
+__host__ __device__ __forceinline__ bool drop_keep_rc(const DropCfg& c, unsigned rowh, unsigned col);
+__host__ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned long long idx) {  // (row, column) = (high, low) word
+    return drop_keep_rc(c, bsi_mix32((unsigned)(idx >> 32) + c.s0) ^ c.s1, (unsigned)idx);
 }
 // Elements are addressed as (row, column) = the (high, low) words of the index: the inner hash depends on the row only, so
 // kernels hoist it per row (drop_row) and pay one 32-bit mix per element (drop_keep_rc) with no 64-bit arithmetic.
 __host__ __device__ __forceinline__ unsigned drop_row(const DropCfg& c, unsigned row) { return bsi_mix32(row + c.s0) ^ c.s1; }
+// One 32-bit mix serves TWO neighbouring columns (its low / high 16 bits against the 16-bit threshold): the kernels visit columns
+// in aligned pairs, so the compiler shares the hash -- the two 32-bit multiplies of the mix (quarter rate on the vector ALU) were
+// most of what dropout cost the attention kernels (backward 949 -> 1330 us with dropout).  p is resolved to 2^-16.
 __host__ __device__ __forceinline__ bool drop_keep_rc(const DropCfg& c, unsigned rowh, unsigned col) {
-    return bsi_mix32(col ^ rowh) >= c.thr;  // == drop_keep(c, ((unsigned long long)row << 32) | col)
+    const unsigned h = bsi_mix32((col >> 1) ^ rowh);
+    return ((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= (c.thr >> 16);
 }
 inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
     DropCfg c{};
     if (p <= 0.f) return c;
     const unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 4294967296.0 + 32768.0;  // the kernels compare 16-bit hash halves with thr >> 16: round p to 2^-16
     c.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (c.thr < 65536u) c.thr = 65536u;            // dropout ON means at least 2^-16
     c.s0 = bsi_mix32((unsigned)s);
     c.s1 = bsi_mix32((unsigned)(s >> 32) ^ 0x85ebca6bu);
     c.scale = 1.0f / (1.0f - p);

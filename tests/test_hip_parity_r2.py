@@ -14,7 +14,7 @@ import torch
 
 from oracle import bsi_oracle as bo
 from oracle import dit_oracle as do
-from tests.util import CALIB, calib_weights, golden, max_rel, rel_linf, report
+from tests.util import CALIB, CALIB_UNET, calib_unet_weights, calib_weights, golden, max_rel, rel_linf, report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -222,3 +222,78 @@ def test_drivers_vs_reference_fixtures_on_the_native_path():
         n = len(a.bpd)
         assert n == 7 and abs(a.mean_var() - (a.bpd.var(ddof=1) + a.bpd_var.mean()) / n) < 1e-15
     report("drivers_native", schedule_max_abs_err=worst)
+
+
+def native_unet(W, shape, dim, levels, dropout=0.1):
+    from bsi_amd.models.pos_emb import NyquistPositionalEmbedding
+    from bsi_amd.models.vdm_unet import DenoisingVDMUNet
+    from bsi_amd.nn import FourierFeatures
+    m = DenoisingVDMUNet(shape, NyquistPositionalEmbedding(32, 100), "silu", dim, levels, 4, n_attention_heads=1, dropout=dropout,
+                         fourier_features=FourierFeatures(n_min=6, n_max=8))
+    m.load_state_dict(W)
+    return m.to(DEV)
+
+
+def test_unet_calibration_point_at_stated_tolerance():
+    """Config 2's denoiser family at the stated tolerances: VDM-UNet dim 128, 2 levels, 16x16, B = 64 (golden g13 generated
+    from the reference class): train_loss mean <= 1e-4, per sample <= 1e-3, teacher-forced x_hat <= 1e-2; gradients of every
+    parameter against autograd through the oracle."""
+    from oracle import unet_oracle as uo
+    c = CALIB_UNET
+    g = golden("g13_calib_unet")
+    W = calib_unet_weights()
+    model = native_unet(W, c["shape"], c["dim"], c["levels"]).eval()   # eval(): dropout off, as in the golden
+    bsi = make_bsi(model, c["shape"])
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss = bsi.train_loss(g["x"].to(DEV))
+    loss.mean().backward()
+    lc = loss.detach().cpu()
+    per = ((lc.double() - g["loss"].double()).abs() / g["loss"].double().abs())
+    mean_err = abs(float(lc.double().mean()) / float(g["loss"].double().mean()) - 1)
+    with torch.no_grad():
+        xh = bsi._predict_x(g["tf_mu"].to(DEV), g["tf_t"].to(DEV)).cpu()
+    tf = [rel_linf(xh[i], g["tf_xhat"][i]) for i in range(len(xh))]
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    f = lambda mu, t: uo.unet_forward(Wr, mu, t, levels=c["levels"], ff=c["ff"], has_dropout_slot=True)  # noqa: E731
+    ref = bo.BSIOracle(f, data_shape=c["shape"], k=128).train_loss(g["x"], g["offset"], g["perm"], g["eps"])
+    ref.mean().backward()
+    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters()) ** 0.5
+    report("unet_calibration", mean_rel=mean_err, per_sample_max=per.max(), per_sample_median=per.median(),
+           teacher_forced_xhat_max=max(tf), worst_tensor_rel_l2=worst[0], worst_tensor=worst[1],
+           grad_norm_rel_vs_reference=abs(gn / float(g["grad_norm"]) - 1), stated="mean 1e-4, per-sample 1e-3, x_hat 1e-2")
+    assert mean_err <= 1e-4, mean_err
+    assert float(per.max()) <= 1e-3, float(per.max())
+    assert max(tf) <= 1e-2, tf
+    assert worst[0] < 3e-2, worst
+    assert abs(gn / float(g["grad_norm"]) - 1) < 5e-3
+
+
+def test_full_size_unet_train_loss_and_gradients_vs_oracle():
+    """VDM-UNet of config/experiment/cifar10-vdm.yaml:32-39 (dim 128, 32 levels, 1 head, 3x32x32, 28.1 M parameters) at B = 2 in
+    eval() mode: BSI.train_loss and the gradient of its mean for every parameter against autograd through the fp32 oracle."""
+    from oracle import unet_oracle as uo
+    shape, dim, levels, B = (3, 32, 32), 128, 32, 2
+    W = uo.unet_random_weights(shape, dim, levels, seed=0, ff=(6, 8))
+    model = native_unet(W, shape, dim, levels).eval()
+    bsi = make_bsi(model, shape)
+    gen = torch.Generator().manual_seed(41)
+    x = (torch.randint(0, 256, (B, *shape), generator=gen).float() / 255) * 2 - 1
+    off, perm, eps = torch.rand((), generator=gen), torch.randperm(B, generator=gen), torch.randn((B, *shape), generator=gen)
+    with replay_noise(rand=[off], randperm=[perm], randn=[eps]):
+        loss = bsi.train_loss(x.to(DEV))
+    loss.mean().backward()
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    f = lambda mu, t: uo.unet_forward(Wr, mu, t, levels=levels, ff=(6, 8), has_dropout_slot=True)  # noqa: E731
+    ref = bo.BSIOracle(f, data_shape=shape, k=128).train_loss(x, off, perm, eps)
+    ref.mean().backward()
+    lc = loss.detach().cpu()
+    per = float(max_rel(lc, ref.detach()))
+    mean_err = abs(float(lc.double().mean()) / float(ref.detach().double().mean()) - 1)
+    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    report("unet_full_size_train", B=B, mean_rel=mean_err, per_sample_max=per, worst_tensor_rel_l2=worst[0],
+           worst_tensor=worst[1], grad_norm_rel=norm_err)
+    assert per <= 2e-3 and mean_err <= 2e-3, (per, mean_err)   # 67 residual blocks of bf16 convolutions, two samples
+    assert worst[0] < 5e-2, worst
+    assert norm_err < 2e-2, norm_err

@@ -159,6 +159,29 @@ def test_g11_calibration_point():
     assert rel_linf(xh, g["tf_xhat"]) < 1e-4 and rel_linf(xh, g["tf_xhat64"]) < 1e-4
 
 
+def test_g13_unet_calibration_point():
+    """UNet calibration model (dim 128, 2 levels, 16x16, B = 64): the fp32 oracle against the reference's fp32 and fp64
+    train_loss, per-tensor gradient norms and teacher-forced predictions."""
+    from tests.util import CALIB_UNET as c, calib_unet_weights
+    g = golden("g13_calib_unet")
+    W = {k: v.clone().requires_grad_(True) for k, v in calib_unet_weights().items()}
+    f = lambda mu, t: uo.unet_forward(W, mu, t, levels=c["levels"], ff=c["ff"], has_dropout_slot=True)  # noqa: E731
+    o = make(f, c["shape"], k=128)
+    loss = o.train_loss(g["x"], g["offset"], g["perm"], g["eps"])
+    assert max_rel(loss, g["loss"]) < 2e-5, max_rel(loss, g["loss"])
+    assert max_rel(loss, g["loss_fp64"]) < 2e-5
+    loss.mean().backward()
+    sq = 0.0
+    for k, v in W.items():
+        n = float(v.grad.double().norm())
+        sq += n * n
+        assert abs(n - float(g["GN." + k])) <= 2e-3 * float(g["GN." + k]) + 1e-7 * float(g["grad_norm"]), k
+    assert abs(math.sqrt(sq) / float(g["grad_norm"]) - 1) < 1e-4
+    with torch.no_grad():
+        xh = o.predict_x(g["tf_mu"], g["tf_t"])
+    assert rel_linf(xh, g["tf_xhat"]) < 1e-4 and rel_linf(xh, g["tf_xhat64"]) < 1e-4
+
+
 def test_g4_fp64_oracle_matches_fp64_reference():
     g = golden("g4_train_dit")
     W = {k: v.double() for k, v in weights("dit_ff").items()}

@@ -68,3 +68,18 @@ def report(name, **values):
     except OSError:
         pass
     return rec
+
+
+CALIB_UNET = dict(shape=(3, 16, 16), dim=128, levels=2, ff=(6, 8), seed=13, B=64)
+
+
+def calib_unet_weights():
+    """Weights of the UNet calibration model (g13_calib_unet), checked against the stored fingerprint."""
+    from oracle import unet_oracle as uo
+    c = CALIB_UNET
+    W = uo.unet_random_weights(c["shape"], c["dim"], c["levels"], seed=c["seed"], ff=c["ff"])
+    fp = torch.stack([torch.stack((v.double().sum(), v.double().abs().sum(), v.flatten()[0].double(),
+                                   v.flatten()[-1].double())) for _, v in sorted(W.items())])
+    ref = golden("g13_calib_unet")["weight_fingerprint"]
+    assert torch.allclose(fp, ref, rtol=1e-12, atol=0), "seeded weight stream differs from the one the golden was made with"
+    return W

@@ -429,6 +429,54 @@ def g11_calibration():
          grad_norm=gn, weight_fingerprint=fp, tf_t=tt, tf_mu=mu_t, tf_xhat=xh_t, tf_xhat64=xh_t64, **gnorms)
 
 
+def g13_calibration_unet():
+    """The UNet counterpart of g11: VDM-UNet dim 128, 2 levels, 1 head on 3x16x16, dropout slot present but eval(), B = 64.
+    Weights = `oracle.unet_oracle.unet_random_weights(..., seed=13)` loaded into the reference class (fingerprint stored);
+    expected: the reference's fp32 `train_loss`, the same in fp64, per-tensor gradient norms, teacher-forced `_predict_x`."""
+    import copy
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import unet_oracle as uo
+    shape, dim, levels, B = (3, 16, 16), 128, 2, 64
+    W = uo.unet_random_weights(shape, dim, levels, seed=13, ff=(6, 8))
+    model = ref.vdm_unet.DenoisingVDMUNet(
+        shape, ref.pos_emb.NyquistPositionalEmbedding(32, 100), "silu", dim, levels, 4, n_attention_heads=1, dropout=0.1,
+        downsampling_attention=False, fourier_features=ref.nn.FourierFeatures(n_min=6, n_max=8))
+    model.load_state_dict(W)
+    model.eval()
+    b = make_bsi(model, shape, k=128)
+    x = data(B, shape, 130)
+    g = torch.Generator().manual_seed(131)
+    loss = b.train_loss(x, g)
+    model.zero_grad()
+    loss.mean().backward()
+    gnorms = {"GN." + k: p.grad.double().norm() for k, p in model.named_parameters()}
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))
+    g = torch.Generator().manual_seed(131)
+    off = torch.rand((), generator=g)
+    perm = torch.randperm(B, generator=g)
+    eps = torch.randn((B, *shape), generator=g)
+    m64 = copy.deepcopy(model).double()
+    b64 = make_bsi(m64, shape, k=128, dtype=torch.float64)
+    lam64 = b64.p_lambda.icdf(torch.remainder(perm.double() / (1 + B) + off.double(), 1))
+    mu64 = torch.addcmul(((lam64 - b64.lambda_0) / lam64).view(-1, 1, 1, 1) * x.double(),
+                         torch.rsqrt(lam64).view(-1, 1, 1, 1), eps.double())
+    with torch.no_grad():
+        xh64 = b64._predict_x(mu64, b64.p_lambda.cdf(lam64))
+        loss64 = b64.p_lambda.reciprocal_pdf(lam64) * (x.double() - xh64).square().flatten(1).mean(1)
+        gt = torch.Generator().manual_seed(132)
+        tt = torch.tensor([0.0, 0.05, 0.2, 0.4, 0.6, 0.8, 0.95, 1.0])
+        lam_t = b.p_lambda.icdf(tt)
+        xs = data(len(tt), shape, 133)
+        mu_t = torch.addcmul(((lam_t - b.lambda_0) / lam_t).view(-1, 1, 1, 1) * xs, torch.rsqrt(lam_t).view(-1, 1, 1, 1),
+                             torch.randn((len(tt), *shape), generator=gt))
+        xh_t = b._predict_x(mu_t, tt)
+        xh_t64 = b64._predict_x(mu_t.double(), tt.double())
+    fp = torch.stack([torch.stack((v.double().sum(), v.double().abs().sum(), v.flatten()[0].double(),
+                                   v.flatten()[-1].double())) for _, v in sorted(W.items())])
+    save("g13_calib_unet", x=x, offset=off, perm=perm, eps=eps, loss=loss, loss_mean=loss.mean(), loss_fp64=loss64,
+         grad_norm=gn, weight_fingerprint=fp, tf_t=tt, tf_mu=mu_t, tf_xhat=xh_t, tf_xhat64=xh_t64, **gnorms)
+
+
 def kat_reference_tests():
     """Inputs/expected values of the reference's own four known-answer tests
     (tests/test_bsi.py:7-34, tests/models/components/test_fourier_features.py:9-28) evaluated
@@ -463,4 +511,5 @@ if __name__ == "__main__":
     g7_components()
     g8_optimizer()
     g11_calibration()
+    g13_calibration_unet()
     kat_reference_tests()

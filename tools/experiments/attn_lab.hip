@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../bsi_amd/csrc/attention.hip"
+#include "../../bsi_amd/csrc/attention_persist.hip"
 #include "../../bsi_amd/csrc/bsi_ops.hip"  // bsi_set_error
 
 template <int ABL>

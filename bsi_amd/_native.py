@@ -31,7 +31,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("zeros", C.c_void_p),
                 ("out", C.c_void_p), ("film", C.c_void_p), ("resid", C.c_void_p), ("film_rows", C.c_int),
                 ("film_stride", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
-                ("Cin2", C.c_int), ("Cout", C.c_int), ("taps", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int)]
+                ("Cin2", C.c_int), ("Cout", C.c_int), ("taps", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int),
+                ("gn_partial", C.c_void_p)]
 
 
 CONV_BIAS_BF16, CONV_FILM_SILU_BF16, CONV_BIAS_RESID_F32 = range(3)
@@ -190,6 +191,7 @@ _PROTOS = {
     "bsi_conv_wgrad_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_groupnorm_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "bsi_groupnorm_stats_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "bsi_groupnorm_apply_nhwc": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "bsi_groupnorm_bwd_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bsi_groupnorm_bwd_cast_nhwc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bsi_film_silu": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),

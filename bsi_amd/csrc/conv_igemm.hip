@@ -28,6 +28,7 @@ struct ConvParams {
     int K;                // taps*Cin + Cin2
     int tiles_m, tiles_n;
     int abl;              // experiments (bsi_conv_set_ablation): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 every pixel row out of range, 16 no fragment reads
+    float* gn_part;       // BIAS_RESID_F32_GN: [M/128][N/4][2] = (mean, M2) of every 128-pixel x 4-channel block of the output
 };
 
 constexpr int C_BM = 512, C_BN = 128, C_RB = 64, C_R = 4, C_D = C_R - 1;
@@ -36,7 +37,9 @@ constexpr int C_ABYTES = C_BM * C_RB;
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // buffer offset beyond num_records: the LDS-DMA writes zeros for that lane
 constexpr unsigned BUF_RECORDS = 0x80000000u;  // every valid offset is below 2 GB (checked by the launcher)
 
-enum { CEPI_BIAS_BF16 = 0, CEPI_FILM_SILU_BF16 = 1, CEPI_BIAS_RESID_F32 = 2 };
+// FILM_SILU_BF16: every wave's 128 rows lie in one image (H*W % 128 == 0, coefficients once per tile, applied in place);
+// FILM_ROWS_SILU_BF16: any image size, coefficients looked up per row (ring kernel only)
+enum { CEPI_BIAS_BF16 = 0, CEPI_FILM_SILU_BF16 = 1, CEPI_BIAS_RESID_F32 = 2, CEPI_BIAS_RESID_F32_GN = 3, CEPI_FILM_ROWS_SILU_BF16 = 4 };
 
 // Padding code of a pixel: which of the four image borders it touches.  A tap (dy, dx) reads outside the image exactly
 // when (code & tap_mask(dy, dx)) != 0.
@@ -63,11 +66,105 @@ __device__ __forceinline__ void store_rows_dpp(__bf16* out, int ldo, int M, int 
     if (m_even + 1 < M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(dst + ldo));
 }
 
+// FiLM + SiLU (residual_block.py:21-24,44-46: addcmul(shift, scale + 1, y), then SiLU) IN PLACE on a wave's accumulators when its
+// 128 rows lie in one image (H*W % 128 == 0): the (scale, shift) of 4 columns are loaded, applied to the 8 rows, and dropped
+// before the next 4 -- nothing but the accumulators stays live (the coefficient arrays of the earlier form cost 160 spilled
+// registers in the ring kernel, some of them inside the K loop).
+template <int TM>
+__device__ __forceinline__ void film_silu_inplace(const ConvParams& p, f32x4 (&acc)[4][TM], int mw0, int nb, int HW) {
+    const int m0w = mw0 < p.M ? mw0 : p.M - 1;
+    asm volatile("" : "+v"(nb));  // keeps the lane's column offsets out of loop-invariant code motion (they would live across the K loop)
+    const float* fr = p.film + (size_t)((m0w / HW) % p.film_rows) * p.film_stride + nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 sc = *reinterpret_cast<const f32x4*>(fr + 4 * i);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(fr + p.N + 4 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] += 1.0f;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(__fmaf_rn(sc[r], acc[i][j][r], sh[r]));
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);  // a few independent exp / rcp chains at a time, not all 128
+        }
+    }
+}
+
+// fp32 epilogue of a wave's 128-row x 64-column block (both kernels): lane (rho, qd) holds in acc[i][j] 4 consecutive floats
+// (columns nb0 + 16 qd + 4 i ..) of row mw0 + 16 j + rho.  A 4 x 4 transpose across the four 16-lane groups (two rounds of gfx950
+// lane-group swaps) makes the 4 lanes of a row write 64 contiguous bytes per store instruction instead of four 16-B pieces 64 B
+// apart; the residual is read in the same pattern.
+// GN: the block's GroupNorm partial statistics leave with it.  After the transpose a lane's float4 number s4 is exactly one
+// 4-channel unit (columns nb0 + 16 s4 + 4 qd ..) -- one group of GroupNorm(32) at 128 channels, half a group of the 256-channel
+// concatenation -- so the lane sums its 8 rows, the 16 lanes of a group are added by DPP, and (mean, M2) of the 128 x 4 block go
+// to gn_part[(mw0 / 128) * (N / 4) + unit]; bsi_groupnorm_apply_nhwc merges the blocks of an image in a fixed order (Chan et
+// al.).  Launcher: M % 128 == 0 and N % 64 == 0, so the row / column guards are wave-uniform here.  4 more store instructions
+// per wave (NSTORE of the kernels' vmcnt allowances).
+template <bool GN, int TM>
+__device__ __forceinline__ void store_f32_rows(const ConvParams& p, f32x4 (&acc)[4][TM], int mw0, int nb0, int rho, int qd) {
+    const int col = nb0 + 4 * qd;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+        transpose_lane_groups(r);
+        const int m = mw0 + 16 * j + rho;
+        if (m >= p.M) continue;
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
+        const float* rsd = p.resid ? p.resid + (size_t)m * p.ldo + col : nullptr;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (col + 16 * s4 >= p.N) continue;
+            f32x4 v = r[s4];
+            if (rsd) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(rsd + 16 * s4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
+            if constexpr (GN) acc[s4][j] = v;  // the stored values stay in the (dead) accumulators for the statistics below
+        }
+    }
+    if constexpr (GN) {
+        // two passes over the registers: mean, then the squares about it (no cancellation for any mean / std ratio)
+        if (mw0 >= p.M) return;
+        constexpr float inv_n = 1.0f / (16.0f * TM * 4.0f);
+        float mean[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                a += acc[s4][j][0] + acc[s4][j][1];
+                b += acc[s4][j][2] + acc[s4][j][3];
+            }
+            mean[s4] = row16_sum(a + b) * inv_n;
+        }
+        float* gp = p.gn_part + ((size_t)(mw0 >> 7) * (p.N >> 2) + (nb0 >> 2) + qd) * 2;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const float d0 = acc[s4][j][0] - mean[s4], d1 = acc[s4][j][1] - mean[s4], d2 = acc[s4][j][2] - mean[s4], d3 = acc[s4][j][3] - mean[s4];
+                a = __fmaf_rn(d0, d0, a); b = __fmaf_rn(d1, d1, b);
+                a = __fmaf_rn(d2, d2, a); b = __fmaf_rn(d3, d3, b);
+            }
+            const float m2 = row16_sum(a + b);
+            if (rho == 0) {
+                f32x2 st;
+                st[0] = mean[s4];
+                st[1] = m2;
+                *reinterpret_cast<f32x2*>(gp + 8 * s4) = st;
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;
-    constexpr bool BF16_OUT = (EPI != CEPI_BIAS_RESID_F32);
-    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM;  // store instructions of one wave's epilogue
+    constexpr bool BF16_OUT = (EPI < CEPI_BIAS_RESID_F32 || EPI == CEPI_FILM_ROWS_SILU_BF16);
+    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM + (EPI == CEPI_BIAS_RESID_F32_GN ? 4 : 0);  // store instructions of one wave's epilogue
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -93,20 +190,23 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     // out-of-range offset and the DMA writes zeros for them.  Per instruction: and, compare, select.
     const int srow = lane >> 2, spos = lane & 3;
     const int achunk = (spos ^ ((-(srow >> 2)) & 3)) * 16;  // swizzled 16-B chunk of this lane (same for every slot)
-    unsigned aoff[4], aoff2[4];  // byte offset of this lane's row (+ chunk) in the first / second source
-    int code[4];                 // border_code of the row's pixel
-    unsigned woffs;              // byte offset of this lane's weight row (+ chunk) from p.W
+    // Per-lane source state of a tile, kept to THREE registers (the K loop holds 176 accumulator / fragment registers, and every
+    // further loop-invariant one is a candidate for a spill inside that loop): the pixel row of slot 0 -- slot q lies
+    // q * 128 rows further, which goes into the instruction's scalar offset --, the four border codes packed 5 bits each
+    // (bit 4 = row beyond M: always out of range), and the weight row offset.
+    int mrow;        // pixel row (global) of this lane in slot q = 0
+    unsigned codes;  // border_code of the four slots' pixels, 5 bits each
+    unsigned woffs;  // byte offset of this lane's weight row (+ chunk) from p.W
     auto set_sources = [&](int t) {
         const int m0 = (t / p.tiles_n) * C_BM, n0 = (t % p.tiles_n) * C_BN;
+        mrow = m0 + wave * 16 + srow;
+        codes = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = (q * NW + wave) * 16 + srow;
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
+            const int m = mrow + q * NW * 16;
             const int rem = m % HW;
-            aoff[q] = (unsigned)m * (unsigned)(p.Cin * 2) + achunk;
-            aoff2[q] = (unsigned)m * (unsigned)(p.Cin2 * 2) + achunk;
-            code[q] = border_code(rem / p.Wd, rem % p.Wd, p.H, p.Wd);
+            const int cd = m < p.M ? border_code(rem / p.Wd, rem % p.Wd, p.H, p.Wd) : 16;
+            codes |= (unsigned)cd << (5 * q);
         }
         const int rw = wave * 16 + srow;  // slot 32 + wave
         const int c = spos ^ ((-(rw >> 4)) & 3);
@@ -127,14 +227,15 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         if (!src2 && p.taps == 9) { dy = itap / 3 - 1; dx = itap - (itap / 3) * 3 - 1; }
         const int rowb = src2 ? p.Cin2 * 2 : p.Cin * 2;
         const long delta = (long)(dy * p.Wd + dx) * rowb + icb;
-        const int tmask = (p.abl & 8) ? 15 : tap_mask(dy, dx);
+        const unsigned tmask = ((p.abl & 8) ? 15u : (unsigned)tap_mask(dy, dx)) | 16u;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((src2 ? A2b : Ab) + delta), 0, BUF_RECORDS, 0x00020000);
         if (!(p.abl & 64)) {
+            const unsigned vo0 = (unsigned)mrow * (unsigned)rowb + achunk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned vo = (code[q] & tmask) ? OOB_OFFSET : (src2 ? aoff2[q] : aoff[q]);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, 0, 0, 0);
+                const unsigned vo = ((codes >> (5 * q)) & tmask) ? OOB_OFFSET : vo0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, q * NW * 16 * rowb, 0, 0);
             }
         }
         if (!(p.abl & 32))
@@ -181,6 +282,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         if (nb0 >= p.N || (p.abl & 4)) return;  // wave-uniform: the lane-group exchanges below need every lane
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
+            if constexpr (EPI == CEPI_FILM_SILU_BF16) film_silu_inplace(p, acc, mw0, nb, HW);
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 float v[16];
@@ -188,7 +290,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
-                if constexpr (EPI == CEPI_FILM_SILU_BF16) {
+                if constexpr (EPI == CEPI_FILM_ROWS_SILU_BF16) {
                     // y*(scale+1)+shift (FeatureModulation, residual_block.py:21-24: addcmul(shift, scale+1, y)), then SiLU
                     int m = mw0 + 16 * j + rho;
                     m = m < p.M ? m : p.M - 1;
@@ -210,30 +312,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
                 store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
             }
         } else {
-            // fp32 rows: lane (rho, qd) holds 16 consecutive floats of row rho.  A 4 x 4 transpose across the four 16-lane
-            // groups (two rounds of gfx950 lane-group swaps) makes the 4 lanes of a row write 64 contiguous bytes per store
-            // instruction instead of four 16-B pieces 64 B apart; the residual is read in the same pattern.
-            const int col = nb0 + 4 * qd;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-                transpose_lane_groups(r);
-                const int m = mw0 + 16 * j + rho;
-                if (m >= p.M) continue;
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
-                const float* rsd = p.resid ? p.resid + (size_t)m * p.ldo + col : nullptr;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    if (col + 16 * s4 >= p.N) continue;
-                    f32x4 v = r[s4];
-                    if (rsd) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rsd + 16 * s4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                    }
-                    *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
-                }
-            }
+            store_f32_rows<EPI == CEPI_BIAS_RESID_F32_GN>(p, acc, mw0, nb0, rho, qd);
         }
     };
 
@@ -340,8 +419,8 @@ __device__ __forceinline__ void wait_vm_allowed(int n) {  // s_waitcnt vmcnt(n) 
 template <int EPI>
 __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;
-    constexpr bool BF16_OUT = (EPI != CEPI_BIAS_RESID_F32);
-    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM;
+    constexpr bool BF16_OUT = (EPI < CEPI_BIAS_RESID_F32 || EPI == CEPI_FILM_ROWS_SILU_BF16);
+    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM + (EPI == CEPI_BIAS_RESID_F32_GN ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -458,29 +537,11 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         if (nb0 >= p.N) return;
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
-            // FiLM + SiLU (residual_block.py:21-24,44-46): y*(scale+1)+shift per (image, channel).  The wave's 128 rows lie in ONE
-            // image (launcher: H*W % 128 == 0), so the 2 x 16 coefficients of this lane's columns are loaded once per tile.
-            f32x4 fsc[4], fsh[4];
-            if constexpr (EPI == CEPI_FILM_SILU_BF16) {
-                int m0w = mw0 < p.M ? mw0 : p.M - 1;
-                const float* fr = p.film + (size_t)((m0w / HW) % p.film_rows) * p.film_stride + nb;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    fsc[i] = *reinterpret_cast<const f32x4*>(fr + 4 * i);
-                    fsh[i] = *reinterpret_cast<const f32x4*>(fr + p.N + 4 * i);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) fsc[i][r] += 1.0f;
-                }
-            }
+            // FiLM + SiLU per (image, channel); the wave's 128 rows lie in ONE image (launcher: H*W % 128 == 0)
+            if constexpr (EPI == CEPI_FILM_SILU_BF16) film_silu_inplace(p, acc, mw0, nb, HW);
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 f32x4 v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-                if constexpr (EPI == CEPI_FILM_SILU_BF16) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[i][r] = silu_f(__fmaf_rn(fsc[i][r], v[i][r], fsh[i][r]));
-                }
                 u32x4 w0, w1;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -492,27 +553,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                 store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
             }
         } else {
-            const int col = nb0 + 4 * qd;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-                transpose_lane_groups(r);
-                const int m = mw0 + 16 * j + rho;
-                if (m >= p.M) continue;
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + col;
-                const float* rsd = p.resid ? p.resid + (size_t)m * p.ldo + col : nullptr;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    if (col + 16 * s4 >= p.N) continue;
-                    f32x4 v = r[s4];
-                    if (rsd) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rsd + 16 * s4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                    }
-                    *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
-                }
-            }
+            store_f32_rows<EPI == CEPI_BIAS_RESID_F32_GN>(p, acc, mw0, nb0, rho, qd);
         }
     };
 
@@ -664,18 +705,22 @@ int launch_conv(ConvParams p, hipStream_t s) {
     p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < conv_cus() ? nwg : conv_cus();
-    {
-        // 3x3 without folded skip steps on images whose rows are whole fragments run the slab kernel.  Measured on one MI355X
-        // (tools/conv_bench.py, 128 / 512 images): fp32-output epilogue 71 / 317 us against 84 / 349 us for the ring kernel (its
-        // stores get five phases to drain instead of two), 256 -> 128 channels bf16 93 / 336 against 94 / 341, 128 -> 128 bf16
-        // 57 / 214 against 50 / 189 (longer load phase: tap address arithmetic); UNet sampling at 256 images: 510 images/s (k=16)
-        // with the slab kernel wherever possible, 505 with it for fp32 outputs only, 497 without it.  Ablation flag 256 = never.
-        // (Numbers from before the slab's LDS swizzle fix; after it: 256 -> 128 bf16 312 vs 361 us, 384 -> 128 448 vs 535 us at 512 images.)
-        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0 &&
-                         (EPI != CEPI_FILM_SILU_BF16 || (p.H * p.Wd) % 128 == 0);  // FiLM: a wave's 128 rows within one image
-        // plain bf16 epilogue with at most 128 input channels: the ring kernel is 3-5 % faster there (4 chunks x 9 taps give the
-        // slab little to amortise); 512 forces the slab kernel wherever the shape allows
-        const bool want = !(g_conv_abl & 256) && (EPI != CEPI_BIAS_BF16 || p.Cin > 128 || (g_conv_abl & 512));
+    if constexpr (EPI != CEPI_FILM_ROWS_SILU_BF16) {
+        // 3x3 without folded skip steps on images whose rows are whole fragments CAN run the slab kernel.  Which one does is
+        // measured per epilogue (one MI355X, 256 images of 32 x 32, kernel times inside the UNet sampling loop):
+        //   FiLM + SiLU -> bf16 (conv1):  slab 105 us (128 -> 128) / 172 us (256 -> 128); ring 230 us average (its FiLM instance spills)
+        //   bias + residual -> fp32 (+ GroupNorm partials, conv2): ring 134 us, slab 172 us (128 -> 128) -- the ring kernel's
+        //     K loop is spill free since its per-lane source state shrank to three registers, the slab kernel's is not
+        //   bias -> bf16: slab for more than 128 input channels (312 vs 361 us at 512 images), ring otherwise (3-5 % faster)
+        // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
+        // 1024 / 2048 = ring kernel for the fp32 / FiLM epilogues, 4096 = slab kernel for the fp32 epilogues.
+        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
+        constexpr bool F32 = (EPI == CEPI_BIAS_RESID_F32 || EPI == CEPI_BIAS_RESID_F32_GN);
+        const bool want = (g_conv_abl & 512) ? true
+                          : (g_conv_abl & 256) ? false
+                          : F32 ? (g_conv_abl & 4096) != 0
+                          : EPI == CEPI_FILM_SILU_BF16 ? !(g_conv_abl & 2048)
+                                                       : p.Cin > 128;
         if (can && want) return launch_conv_slab<EPI>(p, grid, s);
     }
     const size_t lds = (size_t)C_R * C_SLOT;
@@ -730,8 +775,17 @@ extern "C" int bsi_conv_nhwc_bf16(const bsi_conv_args* a, bsi_stream_t stream) {
         case BSI_CONV_BIAS_BF16: return launch_conv<CEPI_BIAS_BF16>(p, s);
         case BSI_CONV_FILM_SILU_BF16:
             BSI_CHECK_ARG(a->film, "bsi_conv_nhwc_bf16: FILM epilogue needs the (scale, shift) table");
-            return launch_conv<CEPI_FILM_SILU_BF16>(p, s);
-        case BSI_CONV_BIAS_RESID_F32: return launch_conv<CEPI_BIAS_RESID_F32>(p, s);
+            if ((a->H * a->W) % 128 == 0) return launch_conv<CEPI_FILM_SILU_BF16>(p, s);
+            return launch_conv<CEPI_FILM_ROWS_SILU_BF16>(p, s);
+        case BSI_CONV_BIAS_RESID_F32:
+            if (a->gn_partial) {
+                // a wave's 128-row x 64-column block must be whole and lie in one image
+                BSI_CHECK_ARG((a->H * a->W) % 128 == 0 && a->Cout % 64 == 0,
+                              "bsi_conv_nhwc_bf16: GroupNorm partials need H*W %% 128 == 0 and Cout %% 64 == 0 (H*W=%d, Cout=%d)", a->H * a->W, a->Cout);
+                p.gn_part = a->gn_partial;
+                return launch_conv<CEPI_BIAS_RESID_F32_GN>(p, s);
+            }
+            return launch_conv<CEPI_BIAS_RESID_F32>(p, s);
         default: bsi_set_error("bsi_conv_nhwc_bf16: unknown epilogue %d", a->epilogue); return BSI_EINVAL;
     }
 }

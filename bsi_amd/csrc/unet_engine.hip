@@ -36,8 +36,9 @@ struct UWs {
     char* y;      // bf16 [M, dim]     FiLM + SiLU output / attention output
     char* h1;     // bf16 [M, dim]     conv1 output
     char* qkv;    // bf16 [M, 3 dim]
-    float* h[3];  // fp32 [M, dim] rotating feature maps
-    float* skips; // fp32 [levels][M, dim]
+    float* h[3];  // fp32 [M, dim] rotating feature maps, each followed by its GroupNorm partials (map_bytes: conv epilogue -> bsi_groupnorm_apply_nhwc)
+    float* skips; // fp32 [levels][M, dim], same
+    size_t map_bytes, fmap_bytes;  // one feature map without / with its partials
     size_t total;
 };
 
@@ -54,8 +55,10 @@ inline UWs carve(const bsi_unet_config* c, int B, void* base) {
     w.y = p + off; off += au(M * dim * 2);
     w.h1 = p + off; off += au(M * dim * 2);
     w.qkv = p + off; off += au(M * 3 * dim * 2);
-    for (int i = 0; i < 3; ++i) { w.h[i] = reinterpret_cast<float*>(p + off); off += au(M * dim * 4); }
-    w.skips = reinterpret_cast<float*>(p + off); off += au(M * dim * 4) * c->levels;
+    w.map_bytes = au(M * dim * 4);
+    w.fmap_bytes = w.map_bytes + au((M + 127) / 128 * (dim / 4) * 2 * 4);  // + (mean, M2) per 128 pixels x 4 channels
+    for (int i = 0; i < 3; ++i) { w.h[i] = reinterpret_cast<float*>(p + off); off += w.fmap_bytes; }
+    w.skips = reinterpret_cast<float*>(p + off); off += w.fmap_bytes * c->levels;
     w.total = off;
     return w;
 }
@@ -68,8 +71,9 @@ inline UWs carve(const bsi_unet_config* c, int B, void* base) {
 
 int conv(const void* x, const void* x2, const void* w, const float* bias, const void* zeros, void* out, const float* film,
          int film_rows, int film_stride, const float* resid, int B, int H, int W, int Cin, int Cin2, int Cout, int taps, int epi,
-         bsi_stream_t s) {
+         bsi_stream_t s, float* gn_part = nullptr) {
     bsi_conv_args a{};
+    a.gn_partial = gn_part;
     a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.zeros = zeros; a.out = out; a.film = film; a.film_rows = film_rows;
     a.film_stride = film_stride; a.resid = resid; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cin2 = Cin2; a.Cout = Cout;
     a.taps = taps; a.ldo = Cout; a.epilogue = epi;
@@ -141,15 +145,26 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
     // c_in*mu, Fourier features, NHWC bf16 with the channels padded to a multiple of 32 (vdm_unet.py:95-99)
     TRY(bsi_dit_prologue_launch(mu, c_in, coef_stride, B, cfg->C, H, W, 1, cfg->ff_nmin, d.nfreq, d.cin_pad, ws.xin, s));
     float* h = ws.h[0];
-    TRY(conv(ws.xin, nullptr, w->enc_w, w->enc_b, ws.zeros, h, nullptr, 0, 0, nullptr, B, H, W, d.cin_pad, 0, dim, 9,
-             BSI_CONV_BIAS_RESID_F32, stream));
     int cur = 0;
-    auto skip_buf = [&](int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws.skips) + (size_t)i * au(d.M * dim * 4)); };
+    auto skip_buf = [&](int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws.skips) + (size_t)i * ws.fmap_bytes); };
+    // GroupNorm statistics from the producing convolution's epilogue (one streaming normalisation pass instead of the
+    // register-resident reduce-then-normalise kernel); BSI_UNET_NO_GN_FUSE=1 keeps the separate kernel for comparison
+    static const bool no_gn_fuse = getenv("BSI_UNET_NO_GN_FUSE") != nullptr;
+    const bool gn_fuse = !no_gn_fuse && dim == 128 && d.HW % 128 == 0;
+    auto part_of = [&](const float* map) -> float* {
+        return gn_fuse ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(map)) + ws.map_bytes) : nullptr;
+    };
+    auto groupnorm = [&](const float* x1, const float* x2, int cin2, const float* gw, const float* gb, int silu, void* raw) -> int {
+        if (gn_fuse)
+            return bsi_groupnorm_apply_nhwc(x1, dim, part_of(x1), x2, cin2, x2 ? part_of(x2) : nullptr, B, d.HW, gw, gb, 1e-5f, silu, ws.a, raw,
+                                            nullptr, stream);
+        return bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, gw, gb, 1e-5f, silu, ws.a, raw, stream);
+    };
     // residual block (residual_block.py:61-64): out = skip(x) + conv2(silu(film(conv1(silu(gn(x))))))
     auto resblock = [&](int blk, const float* x1, const float* x2, float* dst) -> int {
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
         const int cin2 = x2 ? dim : 0;
-        TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, ws.a, x2 ? ws.raw : nullptr, stream));
+        TRY(groupnorm(x1, x2, cin2, rb.gn_w, rb.gn_b, 1, x2 ? ws.raw : nullptr));
         // conv1 with the FiLM + SiLU epilogue of the slab kernel (one image per wave: the (scale, shift) coefficients are loaded once
         // per tile); BSI_UNET_SPLIT_FILM=1 keeps conv1 -> bf16 + a separate FiLM/SiLU pass for comparison
         static const bool split_film = getenv("BSI_UNET_SPLIT_FILM") != nullptr;
@@ -163,8 +178,10 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
         }
         // conv2 (+ the 1x1 skip conv of cat(x, x_skip) folded in as extra K steps; its bias is folded into conv2_b)
         return conv(ws.y, x2 ? ws.raw : nullptr, rb.conv2_w, rb.conv2_b, ws.zeros, dst, nullptr, 0, 0, x2 ? nullptr : x1, B, H, W, dim,
-                    x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream);
+                    x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream, part_of(dst));
     };
+    TRY(conv(ws.xin, nullptr, w->enc_w, w->enc_b, ws.zeros, h, nullptr, 0, 0, nullptr, B, H, W, d.cin_pad, 0, dim, 9,
+             BSI_CONV_BIAS_RESID_F32, stream, part_of(h)));
     for (int i = 0; i < L; ++i) {  // down path: every block's output is also a skip tensor (simplified_unet.py:36-39)
         float* dst = skip_buf(i);
         TRY(resblock(i, h, nullptr, dst));
@@ -173,14 +190,14 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
     // centre: ResBlock, Residual(GroupNorm -> Attention2D), ResBlock (vdm_unet.py:80-89)
     TRY(resblock(L, h, nullptr, ws.h[cur]));
     h = ws.h[cur];
-    TRY(bsi_groupnorm_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, ws.a, nullptr, stream));
+    TRY(groupnorm(h, nullptr, 0, w->agn_w, w->agn_b, 0, nullptr));
     TRY(conv(ws.a, nullptr, w->aqkv_w, w->aqkv_b, ws.zeros, ws.qkv, nullptr, 0, 0, nullptr, B, H, W, dim, 0, 3 * dim, 9,
              BSI_CONV_BIAS_BF16, stream));
     TRY(bsi_attention_fwd(ws.qkv, 3 * dim, B, d.HW, cfg->heads, d.dh, ws.y, dim, stream));
     {
         float* dst = ws.h[cur ^ 1];
         TRY(conv(ws.y, nullptr, w->aout_w, w->aout_b, ws.zeros, dst, nullptr, 0, 0, h, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_RESID_F32,
-                 stream));
+                 stream, part_of(dst)));
         h = dst;
         cur ^= 1;
     }

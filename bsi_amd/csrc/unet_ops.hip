@@ -185,6 +185,85 @@ __global__ __launch_bounds__(GN_RTPB) void groupnorm_reg_kernel(const float* __r
     }
 }
 
+// GroupNorm as one streaming pass (bsi_groupnorm_apply_nhwc): the statistics arrive as (mean, M2) partials of 128-pixel x
+// 4-channel blocks from the epilogue of the convolution that produced x (conv_igemm.hip, store_f32_rows), so nothing has to be
+// held between a reduction and the normalisation.  Workgroup = 128 pixels of one image; its first wave merges the image's
+// partials per group (fixed order, Chan et al.'s pairwise update: deterministic), then every thread owns ONE 4-channel column
+// quad (its mean / rstd / gamma / beta stay in registers) and walks the pixels with 8 independent 16-B loads in flight.
+constexpr int GA_TPB = 256, GA_PIX = 128;
+template <int C>  // channels of cat(x1, x2): 128 or 256
+__global__ __launch_bounds__(GA_TPB) void groupnorm_apply_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ part1,
+                                                                 const float* __restrict__ x2, const float* __restrict__ part2, int HW,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 int silu, __bf16* __restrict__ out, __bf16* __restrict__ raw,
+                                                                 float* __restrict__ stats) {
+    __shared__ float mean_s[32], rstd_s[32];
+    constexpr int CPG = C / 32, UPG = CPG / 4, Q = C / 4, PPI = GA_TPB / Q;  // units per group, quads per pixel, pixels per trip
+    const int b = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
+    const int nblk = HW / 128, C2 = C - C1;
+    if (t < 32) {
+        const int c0 = t * CPG;
+        const bool second = c0 >= C1;
+        const int Cs = second ? C2 : C1;
+        const float* part = (second ? part2 : part1) + ((size_t)b * nblk * (Cs / 4) + (second ? c0 - C1 : c0) / 4) * 2;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int k = 0; k < nblk; ++k)
+#pragma unroll
+            for (int u = 0; u < UPG; ++u) {
+                const f32x2 pm = *reinterpret_cast<const f32x2*>(part + ((size_t)k * (Cs / 4) + u) * 2);
+                const float nb = 512.f, nn = n + nb, delta = pm[0] - mean;
+                mean += delta * (nb / nn);
+                m2 += pm[1] + delta * delta * (n * nb / nn);
+                n = nn;
+            }
+        const float rstd = 1.0f / sqrtf(m2 / n + eps);
+        mean_s[t] = mean;
+        rstd_s[t] = rstd;
+        if (stats && chunk == 0) {
+            float* st = stats + ((size_t)b * 32 + t) * 2;
+            st[0] = mean;
+            st[1] = rstd;
+        }
+    }
+    __syncthreads();
+    const int q = t % Q, prow = t / Q;
+    const int c0 = q * 4;
+    const bool second = c0 >= C1;
+    const int sstride = second ? C2 : C1;
+    const size_t pix0 = (size_t)b * HW + (size_t)chunk * GA_PIX;
+    const float* src = (second ? x2 + pix0 * C2 + (c0 - C1) : x1 + pix0 * C1 + c0);
+    const float mean = mean_s[c0 / CPG], rstd = rstd_s[c0 / CPG];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    constexpr int TRIPS = GA_PIX / PPI, U = 8;
+#pragma unroll 1
+    for (int k0 = 0; k0 < TRIPS; k0 += U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(prow + (k0 + u) * PPI) * sstride));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = __fmaf_rn((v[u][e] - mean) * rstd, ga[e], be[e]);
+                if (silu) y[e] = y[e] / (1.0f + __expf(-y[e]));
+            }
+            const size_t o = (pix0 + prow + (k0 + u) * PPI) * C + c0;
+            u32x2 w;
+            w[0] = pack_bf16x2(y[0], y[1]);
+            w[1] = pack_bf16x2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(out + o) = w;
+            if (raw) {
+                u32x2 r;
+                r[0] = pack_bf16x2(v[u][0], v[u][1]);
+                r[1] = pack_bf16x2(v[u][2], v[u][3]);
+                *reinterpret_cast<u32x2*>(raw + o) = r;
+            }
+        }
+    }
+}
+
 // decode: Conv2d(C -> Cout, 1x1) in fp32 on the NHWC fp32 feature map, written NCHW, fused with
 // x_hat = c_skip*mu + c_out*f (vdm_unet.py:72,100; bsi.py:382-386).  One thread per pixel.
 __global__ void unet_decode_kernel(const float* __restrict__ h, int M, int C, int HW, const float* __restrict__ w,
@@ -286,6 +365,25 @@ extern "C" int bsi_groupnorm_stats_nhwc(const float* x1, int C1, const float* x2
                                         bsi_stream_t stream) {
     BSI_CHECK_ARG(stats, "bsi_groupnorm_stats_nhwc: statistics pointer missing");
     return groupnorm_impl(x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, out_bf16, raw_bf16, stats, stream);
+}
+
+extern "C" int bsi_groupnorm_apply_nhwc(const float* x1, int C1, const float* part1, const float* x2, int C2, const float* part2, int B,
+                                        int HW, const float* gamma, const float* beta, float eps, int silu, void* out_bf16,
+                                        void* raw_bf16, float* stats, bsi_stream_t stream) {
+    BSI_CHECK_ARG(x1 && part1 && gamma && beta && out_bf16 && B > 0 && HW > 0, "bsi_groupnorm_apply_nhwc: bad args");
+    const int C = C1 + C2;
+    BSI_CHECK_ARG((C == 128 || C == 256) && C1 % (C / 32) == 0 && C1 % 4 == 0 && C2 % 4 == 0 && (C2 == 0 || (x2 && part2)),
+                  "bsi_groupnorm_apply_nhwc: C1=%d C2=%d unsupported (128 or 256 channels in all, groups within one tensor)", C1, C2);
+    BSI_CHECK_ARG(HW % 128 == 0, "bsi_groupnorm_apply_nhwc: H*W=%d must be a multiple of 128 (the partials' block)", HW);
+    __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
+    __bf16* r = reinterpret_cast<__bf16*>(raw_bf16);
+    const dim3 grid(B, HW / GA_PIX);
+    if (C == 128)
+        hipLaunchKernelGGL(groupnorm_apply_kernel<128>, grid, dim3(GA_TPB), 0, S(stream), x1, C1, part1, x2, part2, HW, gamma, beta, eps, silu, o, r, stats);
+    else
+        hipLaunchKernelGGL(groupnorm_apply_kernel<256>, grid, dim3(GA_TPB), 0, S(stream), x1, C1, part1, x2, part2, HW, gamma, beta, eps, silu, o, r, stats);
+    BSI_CHECK_LAUNCH("bsi_groupnorm_apply_nhwc");
+    return BSI_OK;
 }
 
 extern "C" int bsi_unet_decode(const float* h, int B, int HW, int C, const float* w, const float* bias, int Cout,

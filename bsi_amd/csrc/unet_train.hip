@@ -57,6 +57,9 @@ struct UTape {
     float* lse;     // fp32 [B, heads, HW]
     float* hatt;    // fp32 [M, dim]
     float* gnstats; // fp32 [nblocks + 1][B][32][2]: (mean, rstd) of every GroupNorm (block i; last = the attention's)
+    float* gnpart;  // fp32 [nblocks + 2][M/128][dim/4][2]: GroupNorm partials of every fp32 feature map (henc, hatt, block outputs),
+                    // written by the producing convolution's epilogue, read by bsi_groupnorm_apply_nhwc in the same forward pass
+    size_t gnpart_stride;  // floats per map
     char* blocks;
     size_t plain_bytes, up_bytes, total;
 };
@@ -82,6 +85,8 @@ inline UTape carve_tape(const bsi_unet_config* c, int B, void* base) {
     t.lse = reinterpret_cast<float*>(p + off); off += au((size_t)B * c->heads * d.HW * 4);
     t.hatt = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
     t.gnstats = reinterpret_cast<float*>(p + off); off += au((size_t)(d.nblocks + 1) * B * 64 * 4);
+    t.gnpart_stride = au((M + 127) / 128 * (dim / 4) * 2 * 4) / 4;
+    t.gnpart = reinterpret_cast<float*>(p + off); off += t.gnpart_stride * 4 * (d.nblocks + 2);
     t.blocks = p + off;
     t.plain_bytes = au(M * dim * 2) * 3 + au(M * dim * 4);
     t.up_bytes = au(M * 2 * dim * 2) * 2 + au(M * dim * 2) * 2 + au(M * dim * 4);
@@ -171,8 +176,9 @@ inline UBwd carve_bwd(const bsi_unet_config* c, int B, void* base) {
     } while (0)
 
 int conv(const void* x, const void* x2, const void* w, const float* bias, const void* zeros, void* out, const float* resid, int B,
-         int H, int W, int Cin, int Cin2, int Cout, int taps, int epi, bsi_stream_t s) {
+         int H, int W, int Cin, int Cin2, int Cout, int taps, int epi, bsi_stream_t s, float* gn_part = nullptr) {
     bsi_conv_args a{};
+    a.gn_partial = gn_part;
     a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.zeros = zeros; a.out = out; a.resid = resid; a.B = B; a.H = H; a.W = W;
     a.Cin = Cin; a.Cin2 = Cin2; a.Cout = Cout; a.taps = taps; a.ldo = Cout; a.epilogue = epi;
     return bsi_conv_nhwc_bf16(&a, s);
@@ -233,44 +239,57 @@ extern "C" int bsi_unet_train_forward(const bsi_unet_config* cfg, const bsi_unet
         TRY(gemm(tp.c2, cd, w->film_w, cd, w->film_b, tp.film, d.F, B, d.F, cd, BSI_EPI_BIAS_F32, stream));
     }
     TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, H, W, 1, cfg->ff_nmin, d.nfreq, d.cin_pad, tp.xin, s));
+    // GroupNorm statistics from the producing convolution's epilogue + one streaming normalisation pass (unet_engine.hip);
+    // partial slot of a feature map: 0 = encoder output, 1 = attention output, 2 + blk = block blk's output; x1p / x2p = slots of
+    // a GroupNorm's inputs.  BSI_UNET_NO_GN_FUSE=1 keeps the reduce-then-normalise kernel.
+    static const bool no_gn_fuse = getenv("BSI_UNET_NO_GN_FUSE") != nullptr;
+    const bool gn_fuse = !no_gn_fuse && dim == 128 && d.HW % 128 == 0 && d.HW <= 1024;
+    auto part = [&](int slot) -> float* { return gn_fuse ? tp.gnpart + (size_t)slot * tp.gnpart_stride : nullptr; };
+    auto groupnorm = [&](const float* x1, int x1p, const float* x2, int x2p, const float* gw, const float* gb, int silu, void* a, void* raw,
+                         float* stats) -> int {
+        const int cin2 = x2 ? dim : 0;
+        if (gn_fuse)
+            return bsi_groupnorm_apply_nhwc(x1, dim, part(x1p), x2, cin2, x2 ? part(x2p) : nullptr, B, d.HW, gw, gb, 1e-5f, silu, a, raw, stats,
+                                            stream);
+        if (d.HW <= 1024)  // the register-resident kernel also saves (mean, rstd) for the backward pass
+            return bsi_groupnorm_stats_nhwc(x1, dim, x2, cin2, B, d.HW, gw, gb, 1e-5f, silu, a, raw, stats, stream);
+        return bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, gw, gb, 1e-5f, silu, a, raw, stream);
+    };
     TRY(conv(tp.xin, nullptr, w->enc_w, w->enc_b, tp.zeros, tp.henc, nullptr, B, H, W, d.cin_pad, 0, dim, 9, BSI_CONV_BIAS_RESID_F32,
-             stream));
-    auto resblock = [&](int blk, const float* x1, const float* x2) -> int {
+             stream, part(0)));
+    auto resblock = [&](int blk, const float* x1, int x1p, const float* x2, int x2p) -> int {
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
         BlockTape bt = block_tape(tp, d, blk);
         const int cin2 = x2 ? dim : 0;
-        if (d.HW <= 1024)  // the register-resident kernel also saves (mean, rstd) for the backward pass
-            TRY(bsi_groupnorm_stats_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, bt.a, x2 ? bt.raw : nullptr,
-                                         tp.gnstats + (size_t)blk * B * 64, stream));
-        else
-            TRY(bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, bt.a, x2 ? bt.raw : nullptr, stream));
+        TRY(groupnorm(x1, x1p, x2, x2p, rb.gn_w, rb.gn_b, 1, bt.a, x2 ? bt.raw : nullptr, tp.gnstats + (size_t)blk * B * 64));
         TRY(conv(bt.a, nullptr, rb.conv1_w, rb.conv1_b, tp.zeros, bt.h1, nullptr, B, H, W, dim + cin2, 0, dim, 9, BSI_CONV_BIAS_BF16,
                  stream));
         TRY(bsi_film_silu_drop(bt.h1, M, dim, d.HW, tp.film + (size_t)blk * 2 * dim, B, d.F, make_drop(dropout_p, seed, blk), bt.y,
                                stream));
         return conv(bt.y, x2 ? bt.raw : nullptr, rb.conv2_w, rb.conv2_b, tp.zeros, bt.out, x2 ? nullptr : x1, B, H, W, dim,
-                    x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream);
+                    x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream, part(2 + blk));
     };
     const float* h = tp.henc;
+    int hp = 0;
     for (int i = 0; i < L; ++i) {
-        TRY(resblock(i, h, nullptr));
+        TRY(resblock(i, h, hp, nullptr, 0));
         h = block_tape(tp, d, i).out;
+        hp = 2 + i;
     }
-    TRY(resblock(L, h, nullptr));
+    TRY(resblock(L, h, hp, nullptr, 0));
     h = block_tape(tp, d, L).out;
-    if (d.HW <= 1024)
-        TRY(bsi_groupnorm_stats_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, tp.agn, nullptr,
-                                     tp.gnstats + (size_t)d.nblocks * B * 64, stream));
-    else
-        TRY(bsi_groupnorm_nhwc(h, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, tp.agn, nullptr, stream));
+    hp = 2 + L;
+    TRY(groupnorm(h, hp, nullptr, 0, w->agn_w, w->agn_b, 0, tp.agn, nullptr, tp.gnstats + (size_t)d.nblocks * B * 64));
     TRY(conv(tp.agn, nullptr, w->aqkv_w, w->aqkv_b, tp.zeros, tp.qkv, nullptr, B, H, W, dim, 0, 3 * dim, 9, BSI_CONV_BIAS_BF16, stream));
     TRY(bsi_attention_fwd_lse(tp.qkv, 3 * dim, B, d.HW, cfg->heads, d.dh, tp.ay, dim, tp.lse, stream));
-    TRY(conv(tp.ay, nullptr, w->aout_w, w->aout_b, tp.zeros, tp.hatt, h, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream));
-    TRY(resblock(L + 1, tp.hatt, nullptr));
+    TRY(conv(tp.ay, nullptr, w->aout_w, w->aout_b, tp.zeros, tp.hatt, h, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream, part(1)));
+    TRY(resblock(L + 1, tp.hatt, 1, nullptr, 0));
     h = block_tape(tp, d, L + 1).out;
+    hp = 2 + L + 1;
     for (int i = 0; i < L; ++i) {
-        TRY(resblock(L + 2 + i, h, block_tape(tp, d, L - 1 - i).out));
+        TRY(resblock(L + 2 + i, h, hp, block_tape(tp, d, L - 1 - i).out, 2 + (L - 1 - i)));
         h = block_tape(tp, d, L + 2 + i).out;
+        hp = 2 + L + 2 + i;
     }
     return bsi_unet_decode(h, B, d.HW, dim, w->dec_w, w->dec_b, cfg->C, mu, c_skip, c_out, 1, out, stream);
 }

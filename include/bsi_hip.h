@@ -363,6 +363,8 @@ typedef struct bsi_conv_args {
     const float* resid;/* BIAS_RESID_F32: fp32 [B*H*W, ldo] or NULL */
     int film_rows, film_stride;
     int B, H, W, Cin, Cin2, Cout, taps /* 9 = 3x3 pad 1, 1 = 1x1 */, ldo, epilogue;
+    float* gn_partial; /* BIAS_RESID_F32, optional: [B*H*W/128][Cout/4][2] = (mean, M2) of every 128-pixel x 4-channel block of
+                          `out`, written by the epilogue for bsi_groupnorm_apply_nhwc (needs H*W % 128 == 0, Cout % 64 == 0) */
 } bsi_conv_args;
 /* Conv2d(stride 1, zero padding) as implicit GEMM on bf16 MFMA; Cin, Cin2 multiples of 32, Cout of 16. */
 int bsi_conv_nhwc_bf16(const bsi_conv_args* a /*host*/, bsi_stream_t stream);
@@ -401,6 +403,13 @@ int bsi_groupnorm_nhwc(const float* x1, int C1, const float* x2, int C2, int B, 
 /* Same, and saves (mean, rstd) of every (image, group) to stats[B][32][2] for the backward pass (H*W <= 1024). */
 int bsi_groupnorm_stats_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma, const float* beta,
                              float eps, int silu, void* out_bf16, void* raw_bf16, float* stats, bsi_stream_t stream);
+/* The same GroupNorm as ONE streaming pass: the statistics come from the partials the producing convolutions wrote
+ * (bsi_conv_args::gn_partial: part1 [B*HW/128][C1/4][2], part2 [B*HW/128][C2/4][2] = (mean, M2) of 128 pixels x 4 channels),
+ * merged per (image, group) in a fixed order, so x is read once and never held.  C1 + C2 = 128 or 256, H*W % 128 == 0;
+ * stats (nullable) receives (mean, rstd) as bsi_groupnorm_stats_nhwc writes them. */
+int bsi_groupnorm_apply_nhwc(const float* x1, int C1, const float* part1, const float* x2, int C2, const float* part2, int B, int HW,
+                             const float* gamma, const float* beta, float eps, int silu, void* out_bf16, void* raw_bf16,
+                             float* stats, bsi_stream_t stream);
 /* Backward of bsi_groupnorm_nhwc: da bf16 [B*HW, C1+C2] is the gradient of the (SiLU'd) output.
  *   out1 [B*HW, C1] = dx1 (+ add[:, :C1]) (+ add_b),  out2 [B*HW, C2] = dx2 (+ add[:, C1:]);  add: fp32 [B*HW, C1+C2] or NULL,
  *   add_b: fp32 [B*HW, C1] or NULL (out1 may alias add when C2 == 0);  dgamma, dbeta [C1+C2] are ACCUMULATED (atomics). */

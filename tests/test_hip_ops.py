@@ -713,7 +713,7 @@ def test_conv_full_size_slab_against_ring(N, epi_name):
     res = dev(torch.randn((M, Cout), generator=gen)) if f32 else None
     outs = {}
     try:
-        for abl in (0, 256):  # 0 = slab kernel, 256 = ring kernel
+        for abl in (512, 256):  # 512 = slab kernel, 256 = ring kernel
             N.check(N.lib().bsi_conv_set_ablation(abl))
             for rep in range(2):
                 out = torch.full((M, Cout), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
@@ -729,7 +729,7 @@ def test_conv_full_size_slab_against_ring(N, epi_name):
                 outs[abl] = out
     finally:
         N.check(N.lib().bsi_conv_set_ablation(0))
-    a0, a1 = outs[0].float(), outs[256].float()
+    a0, a1 = outs[512].float(), outs[256].float()
     assert bool(torch.isfinite(a0).all())
     # different fp32 summation orders (chunk-major vs tap-major K), bf16 rounding on top for the bf16 epilogue
     tol = 2e-5 if f32 else 1.6e-2
@@ -764,6 +764,94 @@ def test_groupnorm_nhwc(N, B, HW, C1, C2, silu):
                                        N.ptr(dev(be)), 1e-5, silu, N.ptr(out), N.ptr(raw), N.stream()))
     assert float((out.cpu().double() - ref).abs().max()) <= float(ref.abs().max()) * 2 ** -8 + 1e-3
     assert torch.equal(raw.cpu(), xc.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,H,Cin,Cin2,cat,kern,offset", [
+    (3, 32, 128, 0, False, "slab", 0.0), (3, 32, 128, 0, True, "ring", 0.0), (2, 32, 128, 256, True, "ring", 0.0),
+    (5, 16, 128, 0, True, "slab", 0.0), (2, 32, 128, 0, False, "slab", 300.0), (12, 32, 128, 0, True, "persistent", 0.0)])
+def test_conv_groupnorm_partials_and_apply(N, B, H, Cin, Cin2, cat, kern, offset):
+    """GroupNorm statistics from the convolution epilogue (bsi_conv_args.gn_partial) + the streaming normalisation
+    (bsi_groupnorm_apply_nhwc) against fp64 GroupNorm of the convolution's own fp32 output (residual_block.py:42-43): partial
+    (mean, M2) per 128 pixels x 4 channels, merged statistics, normalised bf16 output, raw bf16 copy; `offset` shifts the
+    residual so that |mean| >> std (the pivot keeps M2 exact); `cat` normalises cat(x1, x2) with 8-channel groups."""
+    from oracle.unet_oracle import group_norm
+    Cout, HW, M = 128, H * H, B * H * H
+    gen = torch.Generator().manual_seed(B + H + Cin + Cin2 + int(offset))
+    K = 9 * Cin + Cin2
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    N.check(N.lib().bsi_conv_set_ablation(256 if kern == "ring" else 512))
+    if kern == "persistent":
+        N.check(N.lib().bsi_conv_set_grid_limit(8))
+    try:
+        maps, parts = [], []
+        for which in range(2 if cat else 1):
+            x = torch.randn((M, Cin), generator=gen).to(torch.bfloat16)
+            w = bf16r(torch.randn((Cout, Cin, 3, 3), generator=gen) / math.sqrt(9 * Cin))
+            bias = torch.randn(Cout, generator=gen)
+            res = torch.randn((M, Cout), generator=gen) * (1 + which) + offset
+            wp = empty(Cout, K, dtype=torch.bfloat16)
+            N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w)), Cout, Cin, 9, Cin, K, 0, N.ptr(wp), N.stream()))
+            out = torch.full((M, Cout), float("nan"), device=DEV)
+            part = torch.full((M // 128, Cout // 4, 2), float("nan"), device=DEV)
+            xd, bd, rd = dev(x), dev(bias), dev(res)
+            a = N.ConvArgs(x=xd.data_ptr(), w=wp.data_ptr(), bias=bd.data_ptr(), zeros=zeros.data_ptr(), B=B, H=H, W=H, Cin=Cin, Cin2=Cin2,
+                           Cout=Cout, taps=9, ldo=Cout, out=out.data_ptr(), epilogue=N.CONV_BIAS_RESID_F32, resid=rd.data_ptr(),
+                           gn_partial=part.data_ptr())
+            if Cin2:
+                x2 = torch.randn((M, Cin2), generator=gen).to(torch.bfloat16)
+                w2 = bf16r(torch.randn((Cout, Cin2, 1, 1), generator=gen) / math.sqrt(Cin2))
+                N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w2)), Cout, Cin2, 1, Cin2, K, 9 * Cin, N.ptr(wp), N.stream()))
+                x2d = dev(x2)
+                a.x2 = x2d.data_ptr()
+            N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+            # the same convolution without the statistics: identical output
+            out0 = torch.empty_like(out)
+            a.out, a.gn_partial = out0.data_ptr(), None
+            N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(out, out0)
+            o64 = out.cpu().double().reshape(M // 128, 128, Cout // 4, 4)
+            mean = o64.mean(dim=(1, 3))
+            m2 = ((o64 - mean[:, None, :, None]) ** 2).sum(dim=(1, 3))
+            pc = part.cpu().double()
+            assert bool(torch.isfinite(pc).all())
+            assert float((pc[..., 0] - mean).abs().max()) < 1e-5 * (1 + abs(offset))
+            assert float(((pc[..., 1] - m2).abs() / m2).max()) < 2e-4, float(((pc[..., 1] - m2).abs() / m2).max())
+            maps.append(out)
+            parts.append(part)
+    finally:
+        N.check(N.lib().bsi_conv_set_ablation(0))
+        N.check(N.lib().bsi_conv_set_grid_limit(0))
+    Cc = Cout * len(maps)
+    ga, be = torch.randn(Cc, generator=gen), torch.randn(Cc, generator=gen)
+    xc = torch.cat([m.cpu() for m in maps], 1).reshape(B, HW, Cc)
+    xn = xc.permute(0, 2, 1).reshape(B, Cc, H, H).double()
+    for silu in (1, 0):
+        ref = group_norm(xn, 32, ga.double(), be.double())
+        if silu:
+            ref = do.silu(ref)
+        ref = ref.reshape(B, Cc, HW).permute(0, 2, 1)
+        outn = torch.full((B, HW, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+        raw = torch.full((B, HW, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+        stats = torch.full((B, 32, 2), float("nan"), device=DEV)
+        gad, bed = dev(ga), dev(be)
+        N.check(N.lib().bsi_groupnorm_apply_nhwc(N.ptr(maps[0]), Cout, N.ptr(parts[0]), N.ptr(maps[1]) if cat else None, Cout if cat else 0,
+                                                 N.ptr(parts[1]) if cat else None, B, HW, N.ptr(gad), N.ptr(bed), 1e-5, silu, N.ptr(outn),
+                                                 N.ptr(raw), N.ptr(stats), N.stream()))
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        assert float((outn.cpu().double() - ref).abs().max()) <= scale * 2 ** -8 + 1e-3
+        assert torch.equal(raw.cpu(), xc.to(torch.bfloat16))
+        g = xn.reshape(B, 32, -1)
+        st = stats.cpu().double()
+        assert float((st[..., 0] - g.mean(2)).abs().max()) < 1e-5 * (1 + abs(offset))
+        rstd = 1.0 / torch.sqrt(g.var(2, unbiased=False) + 1e-5)
+        assert float(((st[..., 1] - rstd).abs() / rstd).max()) < 1e-4
+        # against the reduce-then-normalise kernel on the same input: at most one bf16 rounding apart
+        old = empty(B, HW, Cc, dtype=torch.bfloat16)
+        N.check(N.lib().bsi_groupnorm_nhwc(N.ptr(maps[0]), Cout, N.ptr(maps[1]) if cat else None, Cout if cat else 0, B, HW, N.ptr(gad),
+                                           N.ptr(bed), 1e-5, silu, N.ptr(old), None, N.stream()))
+        assert float((old.float() - outn.float()).abs().max()) <= scale * 2 ** -7 + 1e-3
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cin2,Cout,taps", [(2, 8, 8, 128, 0, 128, 9), (3, 16, 16, 256, 256, 128, 9),

@@ -152,6 +152,7 @@ class DPTrainer:
         self.ema_beta, self.ema_after = ema_beta, ema_update_after_step
         self._invalidate(self.model)
         self.model._ws = None
+        self.model._flat_grad_only = True  # the HIP backward leaves its flat gradient in _last_flat_grad; no per-parameter .grad copies
         self.ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
         self.fp = FlatParams(self.model)
         self.ema_fp = FlatParams(self.ema_model) if ema else None

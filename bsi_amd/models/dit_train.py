@@ -105,6 +105,10 @@ class _DitTrainFn(torch.autograd.Function):
         model._last_flat_grad = flat  # the data-parallel trainer all-reduces and consumes this buffer directly
         kin = named["dit.patch_encoder.weight"].shape[1]
         views["dit.patch_encoder.weight"].copy_(enc_pad[:, :kin])
+        if getattr(model, "_flat_grad_only", False):
+            # the data-parallel trainer consumes `_last_flat_grad` itself: handing the views to autograd would make it copy every
+            # one of them into a .grad tensor nobody reads (one copy kernel per parameter tensor)
+            return (None,) * (8 + len(order))
         return (None, None, None, None, None, None, None, None, *[views[n] for n in order])
 
 

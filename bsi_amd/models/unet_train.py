@@ -152,6 +152,10 @@ class _UNetTrainFn(torch.autograd.Function):
             views[pfx + "project_onto_scale_shift.bias"].copy_(film_b[i * 2 * dim:(i + 1) * 2 * dim])
         views["pos_map.1.weight"].copy_(pm1_pad[:, :named["pos_map.1.weight"].shape[1]])
         model._last_flat_grad = flat
+        if getattr(model, "_flat_grad_only", False):
+            # the data-parallel trainer consumes `_last_flat_grad` itself: handing the views to autograd would make it copy every
+            # one of them into a .grad tensor nobody reads (one copy kernel per parameter tensor)
+            return (None,) * (8 + len(order))
         return (None, None, None, None, None, None, None, None, *[views[n] for n in order])
 
 

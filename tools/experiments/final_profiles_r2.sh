@@ -16,6 +16,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_pro
 cp $O/bench_prof/*/*_kernel_stats.csv $O/bench_default_kernel_stats.csv
 cp $O/train_prof/*/*_kernel_stats.csv $O/train_step_kernel_stats.csv
 rm -rf $O/bench_prof $O/train_prof
+# secondary configuration (VDM-UNet): kernel statistics of the sampling loop (k=8, 256 images) and of the train step (batch 128)
+K=8 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_s -- python3 tools/unet_bench.py > /dev/null 2>&1
+WHICH=unet_train timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_t -- python3 tools/secondary_bench.py > /dev/null 2>&1
+cp $O/unet_s/*/*_kernel_stats.csv $O/unet_sample_kernel_stats.csv
+cp $O/unet_t/*/*_kernel_stats.csv $O/unet_train_kernel_stats.csv
+rm -rf $O/unet_s $O/unet_t
 # utilisation counters of the dominant kernels (one --pmc pass per group, bench command with k=4)
 for grp in "MfmaUtil" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_TA_BUSY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)

@@ -45,6 +45,7 @@ struct GemmParams {
     void* out2;       // BIAS_GELU_DUAL: pre-activation output (bf16, layout of out)
     int tiles_m, tiles_n;
     int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
+    int groups, group_delay;  // k64r kernel: phase groups per XCD and their start offset (units of 64 clocks), see the kernel
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
     // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
     // split s multiplies the K range [s*kslice, (s+1)*kslice) and writes its partial sums to out + s*slab_stride floats
@@ -730,11 +731,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     const int wm = wave >> 2, wn = wave & 3;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
-    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int xcd = blockIdx.x & 7, wl0 = blockIdx.x >> 3;
+    const int wpx0 = (gridDim.x + 7 - xcd) >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    const int lo0 = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi0 = lo0 + q8 + (xcd < r8 ? 1 : 0);
+    // Phase groups (p.groups = 2 or 4; 1 = off): the XCD's workgroups split into groups that walk their own contiguous share of
+    // its tiles (a 4 x 32/(4 groups) block per round instead of 4 x 8) and START a fraction of a tile period apart, so that the
+    // XCD's output bursts -- 32 epilogues at once saturate its ~0.55 TB/s write path for 7.6 us per tile, 8 of them take 2 us --
+    // fall under the other groups' main loops.  Workgroups of one group stay in lockstep, which the L2 sharing of their A / W
+    // panels needs (a per-workgroup stagger loses it).
+    int wl = wl0, wpx = wpx0, lo = lo0, hi = hi0, group = 0;
+    if (p.groups > 1 && wpx0 % p.groups == 0) {
+        const int per = wpx0 / p.groups;
+        group = wl0 / per;
+        wl = wl0 - group * per;
+        wpx = per;
+        const int span = hi0 - lo0, qg = span / p.groups, rg = span % p.groups;
+        lo = lo0 + group * qg + min(group, rg);
+        hi = lo + qg + (group < rg ? 1 : 0);
+    }
     int tile = lo + wl;
     if (tile >= hi) return;
     const int nk = p.K / 64;
@@ -835,6 +851,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     // tiles of all CUs do not hit the memory system in one burst
     if (p.stagger > 0) {
         const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    if (group > 0) {  // group g starts g / groups of a tile period late: group_delay = that fraction in units of 64 clocks
+        const int n = group * p.group_delay;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
     }
     // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase

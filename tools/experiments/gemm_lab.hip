@@ -128,7 +128,8 @@ static void dma_bench() {
 }
 
 template <int EPI, int ABL>
-float time_k64r(GemmParams p, int iters, int gm = 4) {
+float time_k64r(GemmParams p, int iters, int gm = 4, int grid = 256, int groups = 0, int group_delay = 0) {
+    p.groups = groups; p.group_delay = group_delay;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = gm;
@@ -137,9 +138,9 @@ float time_k64r(GemmParams p, int iters, int gm = 4) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms = 0;
@@ -192,6 +193,53 @@ int main() {
                     printf("%s %-14s %8.3f ms %8.0f TF   shader clock %.0f MHz\n", sh.name, pass ? "randn data" : "lab data", ms,
                            fl / ms / 1e9, 100.0 * hc[0] / hc[1]);
                 }
+            }
+            continue;
+        }
+        if (getenv("LAB_GROUPS")) {
+            // phase groups per XCD (k64r): 1 / 2 / 4 groups, start offset = frac x (tile period / groups); tile period from the plain run
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            const float t1 = time_k64r<E, 0>(p, 20);
+            rep("k64r plain", t1);
+            const int tiles_per_wg = ((M + 255) / 256) * ((sh.N + 255) / 256) / 256;
+            const double period64 = (double)t1 * 1e-3 / tiles_per_wg * 1.7e9 / 64.0;  // tile period in 64-clock units at ~1.7 GHz
+            for (int ng : {2, 4})
+                for (double frac : {0.0, 0.5, 1.0, 1.5}) {
+                    const int d = (int)(frac * period64 / ng);
+                    char nm[96];
+                    snprintf(nm, sizeof nm, "k64r %d groups, delay %.1f (%d x 64 clk)", ng, frac, d);
+                    rep(nm, time_k64r<E, 0>(p, 20, 4, 256, ng, d));
+                }
+            rep("k64r plain (again)", time_k64r<E, 0>(p, 20));
+            if (sh.N == 4096) {
+                rep("k64r gelu plain", time_k64r<G, 0>(p, 20));
+                rep("k64r gelu 2 groups, delay 1.0", time_k64r<G, 0>(p, 20, 4, 256, 2, (int)(period64 / 2)));
+                rep("k64r gelu 4 groups, delay 1.0", time_k64r<G, 0>(p, 20, 4, 256, 4, (int)(period64 / 4)));
+            }
+            continue;
+        }
+        if (getenv("LAB_STORES")) {
+            // what the epilogue's stores cost with and without the operand stream beside them (256 CUs), each row twice
+            for (int r = 0; r < 2; ++r) {
+                rep("k64r full", time_k64r<E, 0>(p, 20));
+                rep("k64r without global stores", time_k64r<E, 128>(p, 20));
+                rep("k64r no operand DMA, with stores", time_k64r<E, 1>(p, 20));
+                rep("k64r no operand DMA, without stores", time_k64r<E, 1 | 128>(p, 20));
+                rep("k64r no operand DMA, no epilogue", time_k64r<E, 1 | 4>(p, 20));
+            }
+            continue;
+        }
+        if (getenv("LAB_FEWCU")) {
+            // Is the epilogue's store tail a per-CU limit or the chip-wide write bandwidth of 256 synchronised epilogues?  The same
+            // number of tiles per workgroup (M = 256 rows per workgroup) on 256 / 64 / 16 / 8 CUs: time per tile with the stores,
+            // without them, without the epilogue.
+            for (int ncu : {256, 64, 16, 8}) {
+                GemmParams q = p;
+                q.M = 256 * ncu;
+                const int tiles_per_wg = (sh.N + 255) / 256;
+                const float f = time_k64r<E, 0>(q, 20, 4, ncu), ns = time_k64r<E, 128>(q, 20, 4, ncu), ne = time_k64r<E, 4>(q, 20, 4, ncu);
+                printf("%s %3d CUs, %d tiles each: per tile %.2f us full, %.2f us without the global stores, %.2f us without epilogue\n", sh.name, ncu,
+                       tiles_per_wg, 1e3 * f / tiles_per_wg, 1e3 * ns / tiles_per_wg, 1e3 * ne / tiles_per_wg);
             }
             continue;
         }

@@ -38,6 +38,11 @@ class ConvArgs(C.Structure):
 CONV_BIAS_BF16, CONV_FILM_SILU_BF16, CONV_BIAS_RESID_F32 = range(3)
 
 
+class ConvPackDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("cin_pad", C.c_int),
+                ("ld", C.c_int), ("col0", C.c_int)]
+
+
 class UNetConfig(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("C", "H", "W", "dim", "levels", "heads", "ff_nmin", "ff_nmax", "emb_size", "c_dim")]
 
@@ -185,6 +190,7 @@ _PROTOS = {
     "bsi_conv_nhwc_bf16": (_i, [C.POINTER(ConvArgs), _vp]),
     "bsi_conv_weight_pack": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "bsi_conv_weight_pack_t": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "bsi_conv_weight_pack_batch": (_i, [_vp, _i, _i, _vp]),
     "bsi_conv_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "bsi_conv_wgrad_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "bsi_conv_wgrad_bias_nhwc_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -12,6 +12,8 @@
 // [32 pixels][256 B] = 40 KB, 4-slot ring = all 160 KB of LDS.  8 waves = 8 slices of 64 im2col columns, every wave
 // against all 128 dY columns.  The pixel range is split over workgroups; partial tiles go to fp32 slabs summed by
 // reduce_slabs (deterministic).  Output layout = the forward's packed weight layout [Cout][taps*Cin + Cin2].
+#include <stdlib.h>
+
 #include "common.h"
 
 int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out,
@@ -29,6 +31,7 @@ struct WgParams {
     int M, H, Wd, HW, Cin, Cin2, taps, Cout, ldy, Ktot;
     int tiles_u, tiles_n, splits, m_per_split, units;
     size_t slab_stride;
+    int abl;  // experiments (BSI_WGRAD_ABL, tools/wgrad_bench.py): 1 no DMA after the prologue, 2 no fragment reads, 4 no MFMA
 };
 
 constexpr int G_RB = 256;          // bytes per sub-tile row (128 bf16 columns)
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 
     int slot = 0, pslot = G_D;
     for (int v = 0; v < nk; ++v) {
-        load_frags(lds + slot * G_SLOT);
-        if (v + G_D < nk) {
+        if (!(p.abl & 2)) load_frags(lds + slot * G_SLOT);
+        if (v + G_D < nk && !(p.abl & 1)) {
             stage(pslot);
             if (!extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI + 1) * (G_D - 1)) : "memory");
@@ -214,11 +217,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         WG_BARRIER();
         __builtin_amdgcn_s_setprio(1);
+        if (!(p.abl & 4)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int i = 0; i < UNITS; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < UNITS; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         if (do_colsum) {
             bf16x8 bsel = bf[0];
 #pragma unroll
@@ -328,6 +333,10 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     p.M = B * H * W; p.H = H; p.Wd = W; p.HW = H * W; p.Cin = Cin; p.Cin2 = Cin2; p.taps = taps; p.Cout = Cout; p.ldy = ldy;
     p.Ktot = taps * Cin + Cin2;
     plan(p);
+    {
+        const char* e = getenv("BSI_WGRAD_ABL");  // kernel experiments only; results are wrong with flags != 0
+        p.abl = e ? atoi(e) : 0;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     p.colsum = dbias ? p.out + (size_t)p.splits * p.slab_stride : nullptr;
     set_max_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<4>), 160 * 1024);

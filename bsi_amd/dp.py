@@ -153,6 +153,9 @@ class DPTrainer:
         self._invalidate(self.model)
         self.model._ws = None
         self.model._flat_grad_only = True  # the HIP backward leaves its flat gradient in _last_flat_grad; no per-parameter .grad copies
+        for attr in ("_plan", "_plan_t"):  # persistent shadow buffers + ctypes tables (rebuilt on demand; not deep-copyable)
+            if hasattr(self.model, attr):
+                setattr(self.model, attr, None)
         self.ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
         self.fp = FlatParams(self.model)
         self.ema_fp = FlatParams(self.ema_model) if ema else None

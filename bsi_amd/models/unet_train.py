@@ -19,29 +19,45 @@ def _block_names(model):
 
 
 def transposed_pack(model):
-    """bf16 shadows for the input-gradient products (rotated conv weights, transposed Linear weights), cached per
-    parameter version like `native_pack`."""
+    """bf16 shadows for the input-gradient products (rotated conv weights, transposed Linear weights), cached per parameter
+    version like `native_pack`: persistent buffers, one batched launch for all convolution weights."""
     key = model._weights_key()
     if getattr(model, "_pack_t", None) is not None and model._pack_t_key == key:
         return model._pack_t
     lib = N.lib()
+    skey = model._storage_key()
+    if getattr(model, "_plan_t", None) is None or model._plan_t["skey"] != skey:
+        model._plan_t = _build_plan_t(model, skey)
+    plan = model._plan_t
+    with torch.no_grad():
+        N.check(lib.bsi_conv_weight_pack_batch(N.ptr(plan["descs"]), plan["ndesc"], 1, N.stream()))
+        torch.cat(plan["film_ws"], dim=0, out=plan["film_w_cat"])
+        for src, rows, cols, dst in plan["lin_t"]:
+            N.check(lib.bsi_cast_transpose_bf16(N.ptr(src), rows, cols, N.ptr(dst), rows, N.stream()))
+    model._pack_t = plan["pack"]
+    model._pack_t_key = key
+    return model._pack_t
+
+
+def _build_plan_t(model, skey):
     dev = model.encode.weight.device
-    keep = []
+    keep, descs, lin = [], [], []
 
     def conv_t(conv: nn.Conv2d):
         cout, cin, kh, kw = conv.weight.shape
         taps = kh * kw
-        w = conv.weight.detach().contiguous()
+        w = conv.weight.detach()
+        assert w.is_contiguous()
         out = torch.empty((cin, taps * cout), dtype=torch.bfloat16, device=dev)
-        N.check(lib.bsi_conv_weight_pack_t(N.ptr(w), cout, cin, taps, taps * cout, N.ptr(out), N.stream()))
+        descs.append(N.ConvPackDesc(w.data_ptr(), out.data_ptr(), cout, cin, taps, cin, taps * cout, 0))
         keep.extend([w, out])
         return out.data_ptr()
 
     def lin_t(w: Tensor):
-        w = w.detach().contiguous()
+        assert w.is_contiguous()
         rows, cols = w.shape
         out = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev)
-        N.check(lib.bsi_cast_transpose_bf16(N.ptr(w), rows, cols, N.ptr(out), rows, N.stream()))
+        lin.append((w, rows, cols, out))
         keep.extend([w, out])
         return out.data_ptr()
 
@@ -55,11 +71,15 @@ def transposed_pack(model):
     wt.blocks = C.cast(arr, C.POINTER(N.UNetResBlockWeightsT))
     att = model.u_net.center_block[1].fn[1]
     wt.aqkv_wT, wt.aout_wT = conv_t(att.to_qkv), conv_t(att.to_out)
-    wt.film_wT = lin_t(torch.cat([rb.project_onto_scale_shift.weight.detach() for rb in blocks], dim=0))
-    wt.pm3_wT = lin_t(model.pos_map[3].weight)
-    model._pack_t = (wt, arr, keep)
-    model._pack_t_key = key
-    return model._pack_t
+    film_ws = [rb.project_onto_scale_shift.weight.detach() for rb in blocks]
+    film_w_cat = torch.empty((sum(t.shape[0] for t in film_ws), film_ws[0].shape[1]), dtype=torch.float32, device=dev)
+    wt.film_wT = lin_t(film_w_cat)
+    wt.pm3_wT = lin_t(model.pos_map[3].weight.detach())
+    darr = (N.ConvPackDesc * len(descs))(*descs)
+    descs_dev = torch.frombuffer(bytearray(bytes(darr)), dtype=torch.uint8).to(dev)
+    keep.extend([film_ws, film_w_cat, descs_dev])
+    return {"skey": skey, "pack": (wt, arr, keep), "descs": descs_dev, "ndesc": len(descs), "lin_t": lin, "film_ws": film_ws,
+            "film_w_cat": film_w_cat}
 
 
 class _UNetTrainFn(torch.autograd.Function):

@@ -110,6 +110,8 @@ class DenoisingVDMUNet(nn.Module):
         self._pack_key = None
         self._pack_t = None
         self._pack_t_key = None
+        self._plan = None
+        self._plan_t = None
         self._ws = None
 
     # ------------------------------------------------------------------------------------------------
@@ -129,20 +131,48 @@ class DenoisingVDMUNet(nn.Module):
         return ([b[0] for b in u.downsampling_blocks] + [u.center_block[0], u.center_block[2]] +
                 [b[0] for b in u.upsampling_blocks])
 
+    def _storage_key(self):
+        ps = list(self.parameters())
+        return (ps[0].device, len(ps), ps[0].data_ptr(), ps[-1].data_ptr())
+
     def native_pack(self):
+        """(config, weight table, block array, keep-alive) for the HIP engines.  The bf16 shadows live in PERSISTENT buffers described
+        once by a plan (rebuilt only when the parameters' storage moves); a new parameter version -- every optimizer step in
+        training -- refreshes them with a handful of launches (one batched re-pack of all convolution weights, concatenations
+        and casts of the FiLM / pos_map matrices) instead of ~170 small ones."""
         key = self._weights_key()
         if self._pack is not None and self._pack_key == key:
             return self._pack
+        skey = self._storage_key()
+        if getattr(self, "_plan", None) is None or self._plan["skey"] != skey:
+            self._plan = self._build_plan(skey)
+        plan = self._plan
+        lib = N.lib()
+        with torch.no_grad():
+            N.check(lib.bsi_conv_weight_pack_batch(N.ptr(plan["descs"]), plan["ndesc"], 0, N.stream()))
+            if plan["b2_dst"] is not None:  # conv2 bias + skip conv bias (both add to the block output, residual_block.py:63)
+                torch.stack(plan["b2_a"], out=plan["b2_tmp"])
+                torch.stack(plan["b2_b"], out=plan["b2_dst"])
+                plan["b2_dst"].add_(plan["b2_tmp"])
+            torch.cat(plan["film_ws"], dim=0, out=plan["film_w_cat"])
+            torch.cat(plan["film_bs"], dim=0, out=plan["film_b_cat"])
+            for src, rows, cols, dst, ld in plan["casts"]:
+                N.check(lib.bsi_cast_bf16(N.ptr(src), rows, cols, N.ptr(dst), ld, N.stream()))
+        self._pack = plan["pack"]
+        self._pack_key = key
+        return self._pack
+
+    def _build_plan(self, skey):
         lib = N.lib()
         dev = self.encode.weight.device
         if dev.type != "cuda":
             raise RuntimeError("bsi_amd.DenoisingVDMUNet: parameters must live on a HIP device (no CPU path)")
         cfg = self._config()
-        dim = cfg.dim
-        keep = []
+        keep, descs, casts = [], [], []
 
         def f32(p: Tensor):
-            t = p.detach().contiguous()
+            t = p.detach()
+            assert t.is_contiguous(), "parameters must be contiguous"
             keep.append(t)
             return t.data_ptr()
 
@@ -151,28 +181,29 @@ class DenoisingVDMUNet(nn.Module):
             taps = kh * kw
             cin_pad = cin_pad or cin
             k = taps * cin_pad + (extra.weight.shape[1] if extra is not None else 0)
-            out = torch.zeros((cout, k), dtype=torch.bfloat16, device=dev)
-            w = conv.weight.detach().contiguous()
-            keep.append(w)
-            N.check(lib.bsi_conv_weight_pack(N.ptr(w), cout, cin, taps, cin_pad, k, 0, N.ptr(out), N.stream()))
+            out = torch.empty((cout, k), dtype=torch.bfloat16, device=dev)
+            descs.append(N.ConvPackDesc(f32(conv.weight), out.data_ptr(), cout, cin, taps, cin_pad, k, 0))
             if extra is not None:
-                w2 = extra.weight.detach().contiguous()
-                keep.append(w2)
-                N.check(lib.bsi_conv_weight_pack(N.ptr(w2), cout, w2.shape[1], 1, w2.shape[1], k, taps * cin_pad,
-                                                 N.ptr(out), N.stream()))
+                c2 = extra.weight.shape[1]
+                descs.append(N.ConvPackDesc(f32(extra.weight), out.data_ptr(), cout, c2, 1, c2, k, taps * cin_pad))
             keep.append(out)
             return out.data_ptr()
 
         def lin_shadow(w: Tensor, ld=None):
-            w = w.detach().contiguous()
+            w = w.detach()
+            assert w.is_contiguous()
             rows, cols = w.shape
             ld = ld or cols
-            out = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
-            N.check(lib.bsi_cast_bf16(N.ptr(w), rows, cols, N.ptr(out), ld, N.stream()))
-            keep.append(out)
+            out = torch.zeros((rows, ld), dtype=torch.bfloat16, device=dev)  # padding columns (ld > cols) stay zero
+            casts.append((w, rows, cols, out, ld))
+            keep.extend([w, out])
             return out.data_ptr()
 
         blocks = self._blocks()
+        dim = cfg.dim
+        skips = [i for i, rb in enumerate(blocks) if isinstance(rb.skip, nn.Conv2d)]
+        b2_dst = torch.empty((len(skips), dim), dtype=torch.float32, device=dev) if skips else None
+        b2_tmp = torch.empty_like(b2_dst) if skips else None
         arr = (N.UNetResBlockWeights * len(blocks))()
         for i, rb in enumerate(blocks):
             conv2 = rb.layers[-1]
@@ -180,25 +211,30 @@ class DenoisingVDMUNet(nn.Module):
             arr[i].gn_w, arr[i].gn_b = f32(rb.layers[0].weight), f32(rb.layers[0].bias)
             arr[i].conv1_w, arr[i].conv1_b = conv_pack(rb.layers[2]), f32(rb.layers[2].bias)
             arr[i].conv2_w = conv_pack(conv2, extra=rb.skip if has_skip else None)
-            b2 = conv2.bias.detach() + (rb.skip.bias.detach() if has_skip else 0)
-            arr[i].conv2_b = f32(b2)
+            arr[i].conv2_b = b2_dst[skips.index(i)].data_ptr() if has_skip else f32(conv2.bias)
         w = N.UNetWeights()
         w.enc_w, w.enc_b = conv_pack(self.encode, cin_pad=lib.bsi_unet_cin_pad(C.byref(cfg))), f32(self.encode.bias)
         w.dec_w, w.dec_b = f32(self.decode.weight.detach().reshape(self.decode.weight.shape[0], -1)), f32(self.decode.bias)
         w.pe_scale, w.pe_bias = f32(self.pos_emb.scale), f32(self.pos_emb.bias)
         w.pm1_w, w.pm1_b = lin_shadow(self.pos_map[1].weight, 64), f32(self.pos_map[1].bias)
         w.pm3_w, w.pm3_b = lin_shadow(self.pos_map[3].weight), f32(self.pos_map[3].bias)
-        film_w = torch.cat([rb.project_onto_scale_shift.weight.detach() for rb in blocks], dim=0)
-        film_b = torch.cat([rb.project_onto_scale_shift.bias.detach() for rb in blocks], dim=0)
-        w.film_w, w.film_b = lin_shadow(film_w), f32(film_b)
+        film_ws = [rb.project_onto_scale_shift.weight.detach() for rb in blocks]
+        film_bs = [rb.project_onto_scale_shift.bias.detach() for rb in blocks]
+        film_w_cat = torch.empty((sum(t.shape[0] for t in film_ws), film_ws[0].shape[1]), dtype=torch.float32, device=dev)
+        film_b_cat = torch.empty(film_w_cat.shape[0], dtype=torch.float32, device=dev)
+        w.film_w, w.film_b = lin_shadow(film_w_cat), film_b_cat.data_ptr()
         att = self.u_net.center_block[1].fn
         w.agn_w, w.agn_b = f32(att[0].weight), f32(att[0].bias)
         w.aqkv_w, w.aqkv_b = conv_pack(att[1].to_qkv), f32(att[1].to_qkv.bias)
         w.aout_w, w.aout_b = conv_pack(att[1].to_out), f32(att[1].to_out.bias)
         w.blocks = C.cast(arr, C.POINTER(N.UNetResBlockWeights))
-        self._pack = (cfg, w, arr, keep)
-        self._pack_key = key
-        return self._pack
+        darr = (N.ConvPackDesc * len(descs))(*descs)
+        descs_dev = torch.frombuffer(bytearray(bytes(darr)), dtype=torch.uint8).to(dev)
+        keep.extend([b2_dst, b2_tmp, film_w_cat, film_b_cat, descs_dev, film_ws, film_bs])
+        return {"skey": skey, "pack": (cfg, w, arr, keep), "descs": descs_dev, "ndesc": len(descs), "casts": casts,
+                "b2_dst": b2_dst, "b2_tmp": b2_tmp, "b2_a": [blocks[i].layers[-1].bias.detach() for i in skips],
+                "b2_b": [blocks[i].skip.bias.detach() for i in skips], "film_ws": film_ws, "film_bs": film_bs,
+                "film_w_cat": film_w_cat, "film_b_cat": film_b_cat}
 
     def _workspace(self, nbytes: int, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:

@@ -379,6 +379,15 @@ int bsi_conv_weight_pack(const float* w, int Cout, int Cin, int taps, int cin_pa
  * out[ci][(taps-1-tap)*Cout + co] = w[co][ci][tap] (taps rotated by 180 degrees, channels swapped); feeding it to
  * bsi_conv_nhwc_bf16 with dY as the input computes autograd's conv2d input gradient. */
 int bsi_conv_weight_pack_t(const float* w, int Cout, int Cin, int taps, int ld, void* out, bsi_stream_t stream);
+/* Both re-arrangements for many convolutions in ONE launch (a train step re-packs every convolution weight after the optimizer
+ * update).  descs: n descriptors in DEVICE memory; transposed = 0: bsi_conv_weight_pack(w, Cout, Cin, taps, cin_pad, ld, col0, out),
+ * transposed = 1: bsi_conv_weight_pack_t(w, Cout, Cin, taps, ld, out) (cin_pad, col0 ignored). */
+typedef struct bsi_conv_pack_desc {
+    const float* w;
+    void* out;
+    int Cout, Cin, taps, cin_pad, ld, col0;
+} bsi_conv_pack_desc;
+int bsi_conv_weight_pack_batch(const bsi_conv_pack_desc* descs /*device*/, int n, int transposed, bsi_stream_t stream);
 /* WEIGHT gradient of bsi_conv_nhwc_bf16 (autograd of nn.Conv2d w.r.t. weight, residual_block.py:40-48, attention.py:29-30):
  *   out_packed[co][tap*Cin + ci] (+)= sum_m dy[m, co] * x[pixel m shifted by tap, ci]   (zero outside the image)
  *   out_packed[co][taps*Cin + c] (+)= sum_m dy[m, co] * x2[m, c]                        (folded 1x1 skip conv)

@@ -854,6 +854,52 @@ def test_conv_groupnorm_partials_and_apply(N, B, H, Cin, Cin2, cat, kern, offset
         assert float((old.float() - outn.float()).abs().max()) <= scale * 2 ** -7 + 1e-3
 
 
+def test_conv_weight_pack_batch(N):
+    """bsi_conv_weight_pack_batch (all convolution weights of a model in one launch) against the per-convolution entry points:
+    3x3 with channel padding (the encoder: 21 -> 32), a 3x3 with the 1x1 skip weights appended behind it, a 1x1, and the
+    transposed (input-gradient) layout; bit-equal."""
+    gen = torch.Generator().manual_seed(7)
+    convs = [(128, 21, 9, 32, None), (128, 128, 9, 128, 256), (64, 256, 1, 256, None), (384, 128, 9, 128, None)]
+    keep, descs, want = [], [], []
+    for cout, cin, taps, cin_pad, extra in convs:
+        ks = 3 if taps == 9 else 1
+        w = dev(torch.randn((cout, cin, ks, ks), generator=gen))
+        k = taps * cin_pad + (extra or 0)
+        out = torch.full((cout, k), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ref = torch.full((cout, k), float("nan"), dtype=torch.bfloat16, device=DEV)
+        descs.append(N.ConvPackDesc(w.data_ptr(), out.data_ptr(), cout, cin, taps, cin_pad, k, 0))
+        N.check(N.lib().bsi_conv_weight_pack(N.ptr(w), cout, cin, taps, cin_pad, k, 0, N.ptr(ref), N.stream()))
+        keep.append(w)
+        if extra:
+            w2 = dev(torch.randn((cout, extra, 1, 1), generator=gen))
+            descs.append(N.ConvPackDesc(w2.data_ptr(), out.data_ptr(), cout, extra, 1, extra, k, taps * cin_pad))
+            N.check(N.lib().bsi_conv_weight_pack(N.ptr(w2), cout, extra, 1, extra, k, taps * cin_pad, N.ptr(ref), N.stream()))
+            keep.append(w2)
+        want.append((out, ref))
+    darr = (N.ConvPackDesc * len(descs))(*descs)
+    ddev = torch.frombuffer(bytearray(bytes(darr)), dtype=torch.uint8).to(DEV)
+    N.check(N.lib().bsi_conv_weight_pack_batch(N.ptr(ddev), len(descs), 0, N.stream()))
+    torch.cuda.synchronize()
+    for out, ref in want:
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # transposed layout
+    tdescs, twant = [], []
+    for w in keep[:2] + keep[3:]:
+        cout, cin, kh, kw = w.shape
+        taps = kh * kw
+        out = torch.full((cin, taps * cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ref = torch.empty_like(out)
+        tdescs.append(N.ConvPackDesc(w.data_ptr(), out.data_ptr(), cout, cin, taps, cin, taps * cout, 0))
+        N.check(N.lib().bsi_conv_weight_pack_t(N.ptr(w), cout, cin, taps, taps * cout, N.ptr(ref), N.stream()))
+        twant.append((out, ref))
+    darr = (N.ConvPackDesc * len(tdescs))(*tdescs)
+    ddev = torch.frombuffer(bytearray(bytes(darr)), dtype=torch.uint8).to(DEV)
+    N.check(N.lib().bsi_conv_weight_pack_batch(N.ptr(ddev), len(tdescs), 1, N.stream()))
+    torch.cuda.synchronize()
+    for out, ref in twant:
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cin2,Cout,taps", [(2, 8, 8, 128, 0, 128, 9), (3, 16, 16, 256, 256, 128, 9),
                                                      (2, 16, 8, 32, 0, 128, 9), (2, 8, 8, 128, 0, 384, 9),
                                                      (5, 16, 16, 384, 0, 128, 9), (2, 8, 8, 256, 0, 128, 1)])

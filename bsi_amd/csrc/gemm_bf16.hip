@@ -82,7 +82,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // that every global_store_dwordx4 instruction writes 8 complete 128-B lines (8 lanes x 16 B per row).  Without it a
 // row's line is written as 16-B pieces by several instructions, and the L2 answers such partial-line writes with a
 // fill read of the destination line (measured: fabric reads grew by exactly the output size).
-template <int TM, int EPI>
+template <int TM, int EPI, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][TM], int mw0, int nw0, int lane,
                                               char* scratch = nullptr) {
     // lane owns rows m = mw0 + 16j + (lane&15), columns nb .. nb+15
@@ -91,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     float bias[16];
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
-        f32x4 bv = (p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 bv = (!BIAS_IN_ACC && p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
         bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
     }
 #pragma unroll
@@ -105,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bias[4 * i + r];
+            for (int r = 0; r < 4; ++r) v[4 * i + r] = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bias[4 * i + r];
 
         if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // generic path: direct stores of the pre-activation
             if (m < p.M && nb_ok) {
@@ -280,11 +280,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     const int c0 = (((lane >> 4)) ^ fx) << 4;
     const int c1 = (((lane >> 4) + 4) ^ fx) << 4;
 
+    // bf16-output epilogues: the accumulators START at the bias of their column, exactly as in the K = 64 ring kernel that takes
+    // these epilogues for M > 128 -- the same fp32 summation order on both sides of that threshold, so a result does not depend on
+    // how many rows were computed with it (the conditioning tables of a batch vs. of its halves: bit-identical)
+    constexpr bool BIAS_IN_ACC = EpiTraits<EPI>::out_bf16;
     f32x4 acc[4][TM];
+    {
+        f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (BIAS_IN_ACC) {
+            const int nb = n0 + wn * 64 + 16 * (lane >> 4);
+            if (p.bias && nb < p.N) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * i);
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
+    }
 
     const int nk = p.K / BK;
     stage(0, 0);
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
         }
     }
 
-    gemm_epilogue<TM, EPI>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
+    gemm_epilogue<TM, EPI, BIAS_IN_ACC>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
 }
 
 template <int EPI, int ABL, bool SCRATCH = true, bool BIAS_IN_ACC = false>

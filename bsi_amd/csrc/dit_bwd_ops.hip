@@ -228,11 +228,15 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
     const __bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats,
     const float* __restrict__ scale, int mod_stride, float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride,
     float* dX, const __bf16* __restrict__ delta, const float* __restrict__ gate, int gate_stride, float* __restrict__ dgate,
-    int dgate_stride, __bf16* __restrict__ ddelta, int M, int d, int tokens, DropCfg dc) {
+    int dgate_stride, __bf16* __restrict__ ddelta, int M, int d, int tokens, DropCfg dc, size_t part_stride) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][nacc][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * FRB;
     const int b = row0 / tokens;
+    // part_stride > 0: this 64-row slab STORES its sums into plane (slab index inside the image) of the modulation gradients --
+    // planes are part_stride floats apart and summed in fixed order by bsi_sum_cast_rows_bf16 (reproducible, no zero fill);
+    // part_stride == 0: the sums are added to dshift / dscale / dgate with fp32 atomics (the C-ABI entry's accumulate contract)
+    const size_t poff = part_stride ? (size_t)((row0 - b * tokens) / FRB) * part_stride : 0;
     const int d4 = d >> 2;
     const float inv_d = 1.0f / (float)d;
     f32x4 sc1[VPL], gt[VPL], ash[VPL], asc[VPL], agt[VPL];
@@ -363,15 +367,24 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
                     }
                 }
                 if constexpr (HAS_LN) {
-                    float* d0 = dshift + (size_t)b * dmod_stride + c * 4;
-                    float* d1 = dscale + (size_t)b * dmod_stride + c * 4;
+                    float* d0 = dshift + poff + (size_t)b * dmod_stride + c * 4;
+                    float* d1 = dscale + poff + (size_t)b * dmod_stride + c * 4;
+                    if (part_stride) {
+                        *reinterpret_cast<f32x4*>(d0) = t0;
+                        *reinterpret_cast<f32x4*>(d1) = t1;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { atomicAdd(d0 + k, t0[k]); atomicAdd(d1 + k, t1[k]); }
+                        for (int k = 0; k < 4; ++k) { atomicAdd(d0 + k, t0[k]); atomicAdd(d1 + k, t1[k]); }
+                    }
                 }
                 if constexpr (HAS_GATE) {
-                    float* d2 = dgate + (size_t)b * dgate_stride + c * 4;
+                    float* d2 = dgate + poff + (size_t)b * dgate_stride + c * 4;
+                    if (part_stride) {
+                        *reinterpret_cast<f32x4*>(d2) = t2;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(d2 + k, t2[k]);
+                        for (int k = 0; k < 4; ++k) atomicAdd(d2 + k, t2[k]);
+                    }
                 }
             }
         }
@@ -392,10 +405,10 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
                                      const float* __restrict__ dec_w, int C, int H, int W, int ps,
                                      const float* __restrict__ g_xhat, const float* __restrict__ c_out, int coef_stride,
                                      float* __restrict__ dX, __bf16* __restrict__ yb, __bf16* __restrict__ dYb,
-                                     float* __restrict__ d_dec_b, float* __restrict__ d_ln_w, float* __restrict__ d_ln_b) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][d] reduction, then (WLDS) [P][d] weights
+                                     float* __restrict__ parts) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][d] + [64] reduction, then (WLDS) [P][d] weights
     float* gsm = sm;
-    float* wsm = sm + 2 * (size_t)d;
+    float* wsm = sm + 2 * (size_t)d + 64;
     const int d4 = d >> 2;
     for (int i = threadIdx.x; i < 2 * d4; i += blockDim.x) reinterpret_cast<f32x4*>(gsm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (WLDS)
@@ -499,23 +512,31 @@ __global__ void dit_final_bwd_kernel(const float* __restrict__ x, int Mtok, int 
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = i * 64 + lane;
-        if (c < d4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                atomicAdd(gsm + c * 4 + k, glw[i][k]);
-                atomicAdd(gsm + d + c * 4 + k, glb[i][k]);
-            }
-        }
-    }
+    // waves add their sums to the block's in wave order (one barrier each: once per block, and the order is fixed), the block
+    // stores them as slab blockIdx.x of `parts` = [gridDim.x][2 d + 64]; bsi_dit_final_bwd_launch sums the slabs in index order.
+    // No atomics: the three gradients are bit reproducible.
+    float* dbs = gsm + 2 * (size_t)d;  // [64] decoder bias sums: behind the two LayerNorm rows (the launcher sizes the region)
+    if (threadIdx.x < 64) dbs[threadIdx.x] = 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += blockDim.x) {
-        atomicAdd(d_ln_w + i, gsm[i]);
-        atomicAdd(d_ln_b + i, gsm[d + i]);
+    for (int w = 0; w < wpb; ++w) {
+        if ((int)(threadIdx.x >> 6) == w) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+                    f32x4 a = reinterpret_cast<f32x4*>(gsm)[c], b2 = reinterpret_cast<f32x4*>(gsm + d)[c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { a[k] += glw[i][k]; b2[k] += glb[i][k]; }
+                    reinterpret_cast<f32x4*>(gsm)[c] = a;
+                    reinterpret_cast<f32x4*>(gsm + d)[c] = b2;
+                }
+            }
+            if (lane < P) dbs[lane] += db_acc;
+        }
+        __syncthreads();
     }
-    if (lane < P) atomicAdd(d_dec_b + lane, db_acc);
+    float* slab = parts + (size_t)blockIdx.x * (2 * (size_t)d + 64);
+    for (int i = threadIdx.x; i < 2 * d + 64; i += blockDim.x) slab[i] = gsm[i];
 }
 
 // out_bf16 = in_f32 elementwise (optionally * silu'(pre) with pre fp32): used for the adaLN MLP backward
@@ -528,6 +549,25 @@ __global__ void silu_bwd_kernel(const float* __restrict__ ds, const float* __res
             g *= sg * (1.0f + p * (1.0f - sg));
         }
         out[i] = (__bf16)g;
+    }
+}
+
+// out_bf16[r][c] = bf16(sum_p parts[p * part_stride + r * row_stride + c]), planes added in index order (fixed -> reproducible):
+// the modulation gradients of one DiT block from the per-slab planes ln_gate_bwd_kernel stored
+__global__ void sum_cast_rows_kernel(const float* __restrict__ parts, int nparts, size_t part_stride, int row_stride, int rows, int cols,
+                                     __bf16* __restrict__ out, int ld_out) {
+    const int c4 = cols >> 2;
+    const size_t total = (size_t)rows * c4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+        const float* src = parts + (size_t)r * row_stride + c;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        for (int p = 1; p < nparts; ++p) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * part_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += v[k];
+        }
+        *reinterpret_cast<u32x2*>(out + (size_t)r * ld_out + c) = f32x4_to_bf16(a);
     }
 }
 
@@ -591,8 +631,11 @@ extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scal
 // dxn == NULL: gate part only (top of the network); delta == NULL: LayerNorm part only (bottom of the network).
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
-                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream) {
+                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream,
+                         size_t part_stride) {
     const bool ln = dxn != nullptr, gt = delta != nullptr;
+    BSI_CHECK_ARG(part_stride % 4 == 0 && (part_stride == 0 || (dmod_stride % 4 == 0 && dgate_stride % 4 == 0)),
+                  "bsi_ln_gate_bwd: partial planes need 16-B aligned strides");
     BSI_CHECK_ARG(dX && (ln || gt), "bsi_ln_gate_bwd: nothing to do");
     BSI_CHECK_ARG(!ln || (x && stats && scale && dshift && dscale), "bsi_ln_gate_bwd: LayerNorm part needs x, stats, scale, dshift, dscale");
     BSI_CHECK_ARG(!gt || (gate && dgate && ddelta), "bsi_ln_gate_bwd: gate part needs gate, dgate, ddelta");
@@ -605,7 +648,7 @@ int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, co
     const size_t lds = (size_t)3 * ((ln ? 2 : 0) + (gt ? 1 : 0)) * d * sizeof(float);
 #define LGB(V, L, G)                                                                                                         \
     hipLaunchKernelGGL((ln_gate_bwd_kernel<V, L, G>), grid, dim3(TPB), lds, S(stream), g, x, stats, scale, mod_stride, dshift,   \
-                       dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc)
+                       dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc, part_stride)
 #define LGB_V(L, G)                   \
     do {                              \
         if (d <= 256) LGB(1, L, G);   \
@@ -625,38 +668,79 @@ extern "C" int bsi_ln_gate_bwd(const void* dxn, const float* x, const float* sta
                                int gate_stride, float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens,
                                bsi_stream_t stream) {
     return bsi_ln_gate_bwd_drop(dxn, x, stats, scale, mod_stride, dshift, dscale, dmod_stride, dX, delta, gate, gate_stride, dgate,
-                                dgate_stride, ddelta, M, d, tokens, DropCfg{}, stream);
+                                dgate_stride, ddelta, M, d, tokens, DropCfg{}, stream, 0);
+}
+
+int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out, hipStream_t s);
+
+static int final_bwd_grid(int Mtok) {
+    int grid = (Mtok + 4 * 16 - 1) / (4 * 16);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    return grid;
+}
+
+int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, int row_stride, int rows, int cols, void* out, int ld_out,
+                           bsi_stream_t stream) {
+    BSI_CHECK_ARG(parts && out && nparts > 0 && rows > 0 && cols > 0 && cols % 4 == 0 && row_stride % 4 == 0 && part_stride % 4 == 0 &&
+                      ld_out % 4 == 0,
+                  "bsi_sum_cast_rows_bf16: bad args");
+    const size_t total = (size_t)rows * (cols / 4);
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(sum_cast_rows_kernel, dim3((int)g), dim3(256), 0, S(stream), parts, nparts, part_stride, row_stride, rows, cols,
+                       reinterpret_cast<__bf16*>(out), ld_out);
+    BSI_CHECK_LAUNCH("bsi_sum_cast_rows_bf16");
+    return BSI_OK;
 }
 
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
                              const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
                              int coef_stride, float* dX, void* yb, void* dYb, float* d_dec_b, float* d_ln_w,
-                             float* d_ln_b, hipStream_t s) {
+                             float* d_ln_b, float* parts, hipStream_t s) {
+    // parts: bsi_dit_final_bwd_parts_floats(Mtok, d) floats of scratch; d_dec_b / d_ln_w / d_ln_b are WRITTEN (not accumulated)
+    if (!parts) {
+        bsi_set_error("bsi_dit_final_bwd: scratch for the per-block sums missing");
+        return BSI_EINVAL;
+    }
     if (P > 64) {
         bsi_set_error("bsi_dit_final_bwd: decoder P=%d unsupported (needs patch*patch*C <= 64)", P);
         return BSI_EINVAL;
     }
     const int Pp = (P + 7) / 8 * 8;
-    const bool wlds = (size_t)(P + 2) * d * sizeof(float) <= 128 * 1024;
-    const size_t lds = (size_t)(wlds ? P + 2 : 2) * d * sizeof(float);
-    int grid = (Mtok + 4 * 16 - 1) / (4 * 16);
-    if (grid < 1) grid = 1;
-    if (grid > 1024) grid = 1024;
+    const bool wlds = (size_t)(P + 2) * d * sizeof(float) + 256 <= 128 * 1024;
+    const size_t lds = (size_t)(wlds ? P + 2 : 2) * d * sizeof(float) + 64 * sizeof(float);
+    const int grid = final_bwd_grid(Mtok);
 #define LAUNCH_FB(V)                                                                                                   \
     do {                                                                                                               \
         auto kern = wlds ? dit_final_bwd_kernel<V, true> : dit_final_bwd_kernel<V, false>;                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, s, x, Mtok, d, P, Pp, ln_w, ln_b, dec_w, C, H, W, ps, g_xhat, \
-                           c_out, coef_stride, dX, reinterpret_cast<__bf16*>(yb), reinterpret_cast<__bf16*>(dYb),       \
-                           d_dec_b, d_ln_w, d_ln_b);                                                                    \
+                           c_out, coef_stride, dX, reinterpret_cast<__bf16*>(yb), reinterpret_cast<__bf16*>(dYb), parts);  \
     } while (0)
     if (d <= 256) LAUNCH_FB(1);
     else if (d <= 1024) LAUNCH_FB(4);
     else LAUNCH_FB(8);
 #undef LAUNCH_FB
     BSI_CHECK_LAUNCH("bsi_dit_final_bwd");
-    return BSI_OK;
+    // slabs [grid][2 d + 64] -> the three gradients, summed in slab order
+    const size_t stride = 2 * (size_t)d + 64;
+    int rc = bsi_reduce_slabs_launch(parts, stride, grid, (size_t)d, 0, d_ln_w, s);
+    if (rc == BSI_OK) rc = bsi_reduce_slabs_launch(parts + d, stride, grid, (size_t)d, 0, d_ln_b, s);
+    if (rc == BSI_OK && P % 4 == 0) {
+        rc = bsi_reduce_slabs_launch(parts + 2 * (size_t)d, stride, grid, (size_t)P, 0, d_dec_b, s);
+    } else if (rc == BSI_OK) {  // odd decoder widths: sum the padded 64 columns behind the slabs, copy the first P
+        float* tmp = parts + (size_t)grid * stride;
+        rc = bsi_reduce_slabs_launch(parts + 2 * (size_t)d, stride, grid, 64, 0, tmp, s);
+        if (rc == BSI_OK && hipMemcpyAsync(d_dec_b, tmp, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            bsi_set_error("bsi_dit_final_bwd: bias gradient copy failed");
+            rc = BSI_ELAUNCH;
+        }
+    }
+    return rc;
 }
+
+size_t bsi_dit_final_bwd_parts_floats(int Mtok, int d) { return (size_t)final_bwd_grid(Mtok) * (2 * (size_t)d + 64) + 64; }
 
 extern "C" int bsi_silu_bwd_bf16(const float* ds, const float* pre, size_t n, void* out, bsi_stream_t stream) {
     BSI_CHECK_ARG(ds && out && n > 0, "bsi_silu_bwd_bf16: bad args");

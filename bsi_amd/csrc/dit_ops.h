@@ -16,7 +16,10 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
                                float* x_out = nullptr, float* stats = nullptr);
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
-                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream);
+                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream, size_t part_stride = 0);
+// out_bf16[r][c] = bf16(sum over nparts planes), fixed order: the reproducible counterpart of the atomics (part_stride above)
+int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, int row_stride, int rows, int cols, void* out, int ld_out,
+                           bsi_stream_t stream);
 int bsi_ln_mod_bwd_drop(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
                         float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps, DropCfg dc,
                         bsi_stream_t stream);

@@ -14,7 +14,8 @@
 int bsi_dit_final_bwd_launch(const float* x, int Mtok, int d, int P, const float* ln_w, const float* ln_b,
                              const float* dec_w, int C, int H, int W, int ps, const float* g_xhat, const float* c_out,
                              int coef_stride, float* dX, void* yb, void* dYb, float* d_dec_b, float* d_ln_w,
-                             float* d_ln_b, hipStream_t s);
+                             float* d_ln_b, float* parts, hipStream_t s);
+size_t bsi_dit_final_bwd_parts_floats(int Mtok, int d);
 
 namespace {
 
@@ -101,8 +102,9 @@ struct BwdWs {
     char* dd;      // bf16 [M, dim]     gradient of a branch delta
     char* dbig;    // bf16 [M, 4 dim]   dhp / dqkv
     char* dsmall;  // bf16 [M, dim]     dxn / dao
-    float* dmod;   // fp32 [B, depth, 6 dim]
+    float* dmod;   // fp32 [2 (block parity)][tokens / 64 planes][B, 6 dim]: per-slab sums of the modulation gradients (reproducible: no atomics)
     char* dmod_bf; // bf16 [B, 6 dim]
+    float* fin_parts;  // per-block sums of the final layer's parameter gradients (bsi_dit_final_bwd_launch)
     float* ds;     // fp32 [B, dim]
     char* dpre_bf; // bf16 [B, dim]
     char* tn;      // TN GEMM slabs
@@ -120,8 +122,9 @@ inline BwdWs carve_bwd(const Dims& d, int B, void* base) {
     w.dd = p + off; off += au(M * dim * 2);
     w.dbig = p + off; off += au(M * 4 * dim * 2);
     w.dsmall = p + off; off += au(M * dim * 2);
-    w.dmod = reinterpret_cast<float*>(p + off); off += au((size_t)B * d.depth * 6 * dim * 4);
+    w.dmod = reinterpret_cast<float*>(p + off); off += au((size_t)2 * (d.tokens / 64 > 0 ? d.tokens / 64 : 1) * B * 6 * dim * 4);
     w.dmod_bf = p + off; off += au((size_t)B * 6 * dim * 2);
+    w.fin_parts = reinterpret_cast<float*>(p + off); off += au(bsi_dit_final_bwd_parts_floats((int)d.M, (int)dim) * 4);
     w.ds = reinterpret_cast<float*>(p + off); off += au((size_t)B * dim * 4);
     w.dpre_bf = p + off; off += au((size_t)B * dim * 2);
     w.tn = p + off; off += au(bsi_gemm_tn_workspace_bytes((int)M, 4 * (int)dim, (int)dim));
@@ -239,20 +242,21 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
     Tape tp = carve_tape(d, B, tape_mem);
     BwdWs ws = carve_bwd(d, B, workspace);
 
-    if (hipMemsetAsync(ws.dmod, 0, (size_t)B * mod_stride * sizeof(float), s) != hipSuccess ||
-        hipMemsetAsync(g->dec_b, 0, (size_t)d.P * sizeof(float), s) != hipSuccess ||
-        hipMemsetAsync(g->dec_ln_w, 0, (size_t)dim * sizeof(float), s) != hipSuccess ||
-        hipMemsetAsync(g->dec_ln_b, 0, (size_t)dim * sizeof(float), s) != hipSuccess) {
-        bsi_set_error("bsi_dit_backward: memset failed");
-        return BSI_ELAUNCH;
-    }
+    // modulation gradients: every 64-token slab of an image stores its sums into its own plane (bsi_ln_gate_bwd_drop with a plane
+    // stride), the planes are added in fixed order when the block's adaLN backward needs them: no atomics, no zero fill, bit
+    // reproducible.  Two blocks are in flight at a time (the fused kernel of block l also writes g_m of block l - 1): parity slots.
+    BSI_CHECK_ARG(d.tokens % 64 == 0, "bsi_dit_backward: tokens=%d must be a multiple of 64", d.tokens);
+    const int nplanes = d.tokens / 64;
+    const size_t plane = (size_t)B * 6 * dim;  // floats per plane
+    const int dstride = 6 * dim;               // row stride inside a plane
+    auto dmod_of = [&](int l) { return ws.dmod + (size_t)(l & 1) * nplanes * plane; };
     // decoder: dX = d/dx_final, parameter gradients of patch_decoder (dit.py:163-165)
     {
         const int Pp = (d.P + 7) / 8 * 8;  // yb -> ws.dd, dYb -> ws.dsmall (Pp <= 64 <= dim columns)
         BSI_CHECK_ARG(Pp <= dim, "bsi_dit_backward: decoder width %d exceeds dim %d", Pp, dim);
         TRY(bsi_dit_final_bwd_launch(tp.x, M, dim, d.P, w->dec_ln_w, w->dec_ln_b, w->dec_w, cfg->C, cfg->H, cfg->W,
                                      cfg->patch, g_out, c_out, 1, ws.dX, ws.dd, ws.dsmall, g->dec_b, g->dec_ln_w,
-                                     g->dec_ln_b, s));
+                                     g->dec_ln_b, ws.fin_parts, s));
         TRY(bsi_gemm_tn_bf16(ws.dsmall, Pp, ws.dd, dim, M, Pp, dim, ws.decw, dim, 0, ws.tn, stream));
         if (hipMemcpyAsync(g->dec_w, ws.decw, (size_t)d.P * dim * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
             bsi_set_error("bsi_dit_backward: decoder gradient copy failed");
@@ -264,8 +268,8 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         const int l = d.depth - 1;
         BlockTape bt = block_tape(tp, d, B, l);
         TRY(bsi_ln_gate_bwd_drop(nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, ws.dX, bt.d2,
-                                 tp.mod + (size_t)l * 6 * dim + 5 * dim, mod_stride, ws.dmod + (size_t)l * 6 * dim + 5 * dim,
-                                 mod_stride, ws.dd, M, dim, d.tokens, DropCfg{}, stream));
+                                 tp.mod + (size_t)l * 6 * dim + 5 * dim, mod_stride, dmod_of(l) + 5 * dim, dstride, ws.dd, M, dim,
+                                 d.tokens, DropCfg{}, stream, plane));
     }
     for (int l = d.depth - 1; l >= 0; --l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
@@ -273,7 +277,7 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         const bsi_dit_block_grads& bg = g->blocks[l];
         BlockTape bt = block_tape(tp, d, B, l);
         const float* ml = tp.mod + (size_t)l * 6 * dim;
-        float* dml = ws.dmod + (size_t)l * 6 * dim;
+        float* dml = dmod_of(l);
         (void)bw;
         // ---- MLP branch: x2 = xb + g_m * d2.  ws.dd = g_m * dX was produced by the fused kernel of the block above (or by the
         //      gate-only launch in front of the loop).  dh = dd2 . W2, times gelu'(hp)  -> dhp
@@ -283,9 +287,9 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, bg.fc1_b, 0, ws.tn, stream));
         // LayerNorm 2 backward (dX becomes dL/dxb) + attention branch xb = xa + g_a * d1: dd = g_a * dX, dg_a
-        TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xb, bt.sb, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, mod_stride, ws.dX,
-                                 bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, mod_stride, ws.dd, M, dim, d.tokens,
-                                 make_drop(dropout_p, seed, 2 * l + 1), stream));
+        TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xb, bt.sb, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, dstride, ws.dX,
+                                 bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, dstride, ws.dd, M, dim, d.tokens,
+                                 make_drop(dropout_p, seed, 2 * l + 1), stream, plane));
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
         TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
@@ -296,18 +300,18 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         if (l > 0) {
             BlockTape below = block_tape(tp, d, B, l - 1);
             const float* mlb = tp.mod + (size_t)(l - 1) * 6 * dim;
-            float* dmlb = ws.dmod + (size_t)(l - 1) * 6 * dim;
-            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, below.d2,
-                                     mlb + 5 * dim, mod_stride, dmlb + 5 * dim, mod_stride, ws.dd, M, dim, d.tokens, DropCfg{}, stream));
+            float* dmlb = dmod_of(l - 1);
+            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, dstride, ws.dX, below.d2,
+                                     mlb + 5 * dim, mod_stride, dmlb + 5 * dim, dstride, ws.dd, M, dim, d.tokens, DropCfg{}, stream, plane));
         } else {
-            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, mod_stride, ws.dX, nullptr, nullptr,
-                                     0, nullptr, 0, nullptr, M, dim, d.tokens, DropCfg{}, stream));
+            TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, dstride, ws.dX, nullptr, nullptr,
+                                     0, nullptr, 0, nullptr, M, dim, d.tokens, DropCfg{}, stream, plane));
         }
         {   // adaLN MLP of this block (dit.py:77-81): mod_l = W2 silu(W1 c + b1) + b2, rows = samples
             const float* pre = tp.ada_pre + (size_t)l * B * dim;
             const char* sl = tp.ada_s + (size_t)l * B * dim * 2;
-            // contiguous bf16 copy of dmod[:, l, :]
-            TRY(bsi_cast_rows_bf16(ws.dmod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
+            // bf16 dmod[:, l, :] = the slab planes of this block summed in fixed order
+            TRY(bsi_sum_cast_rows_bf16(dml, nplanes, plane, dstride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
             TRY(bsi_gemm_tn_bias_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, bg.ada2_b, 0, ws.tn, stream));
             TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
             TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));

@@ -7,6 +7,8 @@
 #include "dit_ops.h"
 #include "unet_ops.h"
 
+int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out, hipStream_t s);
+
 namespace {
 
 __device__ __forceinline__ float silu_grad_f(float z) {
@@ -59,7 +61,9 @@ constexpr int FB_ROWS = 64;
 __global__ __launch_bounds__(256) void film_silu_bwd_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ h1, int N,
                                                             int HW, const float* __restrict__ film, int film_rows,
                                                             int film_stride, DropCfg dc, __bf16* __restrict__ dh1,
-                                                            float* __restrict__ dfilm, int dfilm_stride) {
+                                                            float* __restrict__ dfilm, int dfilm_stride, size_t part_stride) {
+    // part_stride > 0: the slab STORES its sums into plane (slab index inside the image) of dfilm, planes part_stride floats apart,
+    // summed later in fixed order (bsi_sum_cast_rows_bf16): reproducible, no zero fill; 0: fp32 atomics (the C-ABI contract)
     __shared__ float red[2][256 * 8];
     const int n8 = N / 8;            // chunks per pixel (8, 16)
     const int rows_par = 256 / n8;   // pixel rows handled in parallel
@@ -97,7 +101,9 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(const __bf16* __rest
         const int which = i / N, n = i % N;
         float a = 0.f;
         for (int s = 0; s < rows_par; ++s) a += red[which][(s * n8 + n / 8) * 8 + (n & 7)];
-        atomicAdd(dfilm + (size_t)b * dfilm_stride + which * N + n, a);
+        float* dst = dfilm + (size_t)b * dfilm_stride + which * N + n;
+        if (part_stride) dst[(size_t)((m0 % HW) / FB_ROWS) * part_stride] = a;
+        else atomicAdd(dst, a);
     }
 }
 
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
                                                              float eps, int silu, const float* __restrict__ add,
                                                              const float* __restrict__ add_b, float* __restrict__ out1,
                                                              float* __restrict__ out2, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf, const float* __restrict__ stats) {
+                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf, const float* __restrict__ stats,
+                                                             float* __restrict__ partials) {
     __shared__ float red_s[512], red_q[512];
     __shared__ float red_g[1024], red_b[1024];  // [pixel row][channel of the slice]
     __shared__ float mean_s[16], rstd_s[16], m1_s[16], m2_s[16];
@@ -217,8 +224,13 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
         const int c = t - 64;
         float a = 0.f, bb = 0.f;
         for (int r = 0; r < PPI; ++r) { a += red_g[r * GN_CS + c]; bb += red_b[r * GN_CS + c]; }
-        atomicAdd(dgamma + cs0 + c, a);
-        atomicAdd(dbeta + cs0 + c, bb);
+        if (partials) {  // [B][2][C] per-image sums, added over the images in fixed order by the launcher: reproducible
+            partials[((size_t)b * 2 + 0) * C + cs0 + c] = a;
+            partials[((size_t)b * 2 + 1) * C + cs0 + c] = bb;
+        } else {
+            atomicAdd(dgamma + cs0 + c, a);
+            atomicAdd(dbeta + cs0 + c, bb);
+        }
     }
     __syncthreads();
     float m1[4], m2[4];
@@ -267,9 +279,12 @@ __global__ __launch_bounds__(256) void unet_decode_bwd_kernel(const float* __res
                                                               int coef_stride, const float* __restrict__ h, int M, int C,
                                                               int HW, const float* __restrict__ w, int Cout,
                                                               float* __restrict__ dh, float* __restrict__ dw,
-                                                              float* __restrict__ db) {
+                                                              float* __restrict__ db, float* __restrict__ parts) {
+    // parts != null: the block STORES its sums as slab blockIdx.x = [Cout * C weight sums][4 bias sums]; the launcher adds the slabs
+    // in index order (reproducible); null: fp32 atomics into dw / db (the C-ABI contract)
     __shared__ float dys[DB_PIX][4];
     __shared__ float red[256][4];
+    __shared__ float dbw[4][4];
     const int m0 = blockIdx.x * DB_PIX;
     {
         const int m = m0 + threadIdx.x;
@@ -283,10 +298,15 @@ __global__ __launch_bounds__(256) void unet_decode_bwd_kernel(const float* __res
         for (int o = 0; o < 4; ++o) {
             dys[threadIdx.x][o] = v[o];
             const float s = wave_sum(v[o]);
-            if ((threadIdx.x & 63) == 0 && o < Cout) atomicAdd(db + o, s);
+            if ((threadIdx.x & 63) == 0) {
+                if (parts) dbw[threadIdx.x >> 6][o] = s;
+                else if (o < Cout) atomicAdd(db + o, s);
+            }
         }
     }
     __syncthreads();
+    float* slab = parts ? parts + (size_t)blockIdx.x * ((size_t)Cout * C + 4) : nullptr;
+    if (parts && threadIdx.x < 4) slab[(size_t)Cout * C + threadIdx.x] = (dbw[0][threadIdx.x] + dbw[1][threadIdx.x]) + (dbw[2][threadIdx.x] + dbw[3][threadIdx.x]);
     const int c = threadIdx.x % C, sub = threadIdx.x / C, S = 256 / C;
     float wv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -308,7 +328,8 @@ __global__ __launch_bounds__(256) void unet_decode_bwd_kernel(const float* __res
         for (int o = 0; o < Cout; ++o) {
             float a = 0.f;
             for (int s = 0; s < S; ++s) a += red[s * C + c][o];
-            atomicAdd(dw + (size_t)o * C + c, a);
+            if (parts) slab[(size_t)o * C + c] = a;
+            else atomicAdd(dw + (size_t)o * C + c, a);
         }
     }
 }
@@ -331,13 +352,14 @@ int bsi_film_silu_drop(const void* h1, int M, int N, int HW, const float* film, 
 }
 
 int bsi_film_silu_bwd_drop(const void* dy, const void* h1, int M, int N, int HW, const float* film, int film_rows,
-                           int film_stride, DropCfg dc, void* dh1, float* dfilm, int dfilm_stride, bsi_stream_t stream) {
+                           int film_stride, DropCfg dc, void* dh1, float* dfilm, int dfilm_stride, bsi_stream_t stream,
+                           size_t part_stride) {
     BSI_CHECK_ARG(dy && h1 && film && dh1 && dfilm && M > 0, "bsi_film_silu_bwd: bad args");
     BSI_CHECK_ARG((N == 64 || N == 128) && HW % FB_ROWS == 0 && M % HW == 0 && film_rows > 0,
                   "bsi_film_silu_bwd: N=%d (64 or 128), HW=%d (multiple of %d)", N, HW, FB_ROWS);
     hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(M / FB_ROWS), dim3(256), 0, S_(stream), reinterpret_cast<const __bf16*>(dy),
                        reinterpret_cast<const __bf16*>(h1), N, HW, film, film_rows, film_stride, dc,
-                       reinterpret_cast<__bf16*>(dh1), dfilm, dfilm_stride);
+                       reinterpret_cast<__bf16*>(dh1), dfilm, dfilm_stride, part_stride);
     BSI_CHECK_LAUNCH("bsi_film_silu_bwd");
     return BSI_OK;
 }
@@ -351,20 +373,35 @@ extern "C" int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, i
                                  int film_stride, float dropout_p, unsigned long long seed, unsigned site, void* dh1,
                                  float* dfilm, int dfilm_stride, bsi_stream_t stream) {
     return bsi_film_silu_bwd_drop(dy, h1, M, N, HW, film, film_rows, film_stride, make_drop(dropout_p, seed, site), dh1, dfilm,
-                                  dfilm_stride, stream);
+                                  dfilm_stride, stream, 0);
 }
 
 static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
                               const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1, float* out2,
-                              float* dgamma, float* dbeta, void* out1_bf16, const float* stats, bsi_stream_t stream) {
+                              float* dgamma, float* dbeta, void* out1_bf16, const float* stats, bsi_stream_t stream,
+                              float* partials = nullptr) {
     BSI_CHECK_ARG(da && x1 && gamma && beta && out1 && dgamma && dbeta && B > 0 && HW > 0, "bsi_groupnorm_bwd_nhwc: bad args");
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
     hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
-                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats);
+                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats, partials);
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
+    if (partials) {  // dgamma / dbeta are WRITTEN: per-image rows summed in image order
+        int rc = bsi_reduce_slabs_launch(partials, (size_t)2 * C, B, (size_t)C, 0, dgamma, S_(stream));
+        if (rc == BSI_OK) rc = bsi_reduce_slabs_launch(partials + C, (size_t)2 * C, B, (size_t)C, 0, dbeta, S_(stream));
+        return rc;
+    }
     return BSI_OK;
+}
+
+// engine-internal (unet_ops.h): the reproducible form of bsi_groupnorm_bwd_cast_nhwc -- `partials`: B * 2 * (C1 + C2) floats of scratch
+int bsi_groupnorm_bwd_cast_det(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW, const float* gamma,
+                               const float* beta, float eps, int silu, const float* add, const float* add_b, float* out1, float* out2,
+                               float* dgamma, float* dbeta, void* out1_bf16, const float* stats, float* partials, bsi_stream_t stream) {
+    BSI_CHECK_ARG(out1_bf16 && partials, "bsi_groupnorm_bwd_cast_det: bf16 output or scratch missing");
+    return groupnorm_bwd_impl(da, x1, C1, x2, C2, B, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, out1_bf16, stats, stream,
+                              partials);
 }
 
 extern "C" int bsi_groupnorm_bwd_nhwc(const void* da, const float* x1, int C1, const float* x2, int C2, int B, int HW,
@@ -389,7 +426,29 @@ extern "C" int bsi_unet_decode_bwd(const float* g_xhat, const float* c_out, int 
                   Cout, C);
     const int M = B * HW;
     hipLaunchKernelGGL(unet_decode_bwd_kernel, dim3((M + DB_PIX - 1) / DB_PIX), dim3(256), 0, S_(stream), g_xhat, c_out, coef_stride,
-                       h, M, C, HW, w, Cout, dh, dw, db);
+                       h, M, C, HW, w, Cout, dh, dw, db, static_cast<float*>(nullptr));
     BSI_CHECK_LAUNCH("bsi_unet_decode_bwd");
     return BSI_OK;
+}
+
+// engine-internal (unet_ops.h): reproducible form; dw / db are WRITTEN.  parts: bsi_unet_decode_bwd_parts_floats(B*HW, C, Cout) floats.
+size_t bsi_unet_decode_bwd_parts_floats(int M, int C, int Cout) { return (size_t)((M + DB_PIX - 1) / DB_PIX) * ((size_t)Cout * C + 4) + 4; }
+int bsi_unet_decode_bwd_det(const float* g_xhat, const float* c_out, int coef_stride, const float* h, int B, int HW, int C, const float* w,
+                            int Cout, float* dh, float* dw, float* db, float* parts, bsi_stream_t stream) {
+    BSI_CHECK_ARG(g_xhat && h && w && dh && dw && db && parts && B > 0 && HW > 0, "bsi_unet_decode_bwd: bad args");
+    BSI_CHECK_ARG(Cout >= 1 && Cout <= 4 && C >= 4 && C <= 256 && 256 % C == 0, "bsi_unet_decode_bwd: Cout=%d (<= 4), C=%d (divides 256)",
+                  Cout, C);
+    const int M = B * HW, nb = (M + DB_PIX - 1) / DB_PIX;
+    hipLaunchKernelGGL(unet_decode_bwd_kernel, dim3(nb), dim3(256), 0, S_(stream), g_xhat, c_out, coef_stride, h, M, C, HW, w, Cout, dh, dw, db,
+                       parts);
+    BSI_CHECK_LAUNCH("bsi_unet_decode_bwd");
+    const size_t stride = (size_t)Cout * C + 4;
+    int rc = bsi_reduce_slabs_launch(parts, stride, nb, (size_t)Cout * C, 0, dw, S_(stream));
+    float* tmp = parts + (size_t)nb * stride;  // 4 padded bias sums, the first Cout are copied out
+    if (rc == BSI_OK) rc = bsi_reduce_slabs_launch(parts + (size_t)Cout * C, stride, nb, 4, 0, tmp, S_(stream));
+    if (rc == BSI_OK && hipMemcpyAsync(db, tmp, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) {
+        bsi_set_error("bsi_unet_decode_bwd: bias gradient copy failed");
+        rc = BSI_ELAUNCH;
+    }
+    return rc;
 }

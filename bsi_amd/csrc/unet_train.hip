@@ -123,7 +123,9 @@ struct UBwd {
     char* dh1;       // bf16 [M, dim]
     char* da;        // bf16 [M, 2 dim]
     char* dqkv;      // bf16 [M, 3 dim]
-    float* dfilm;    // fp32 [B, F]
+    float* dfilm;    // fp32 [HW / 64 planes][B, F]: per-slab sums of the FiLM gradients (reproducible: no atomics)
+    float* gnpart;   // fp32 [B][2][2 dim]: per-image sums of a GroupNorm's affine gradients
+    float* decparts; // per-block sums of the decode convolution's parameter gradients
     char* dfilm_bf;  // bf16 [B, F]
     float* dc;       // fp32 [B, c_dim]
     char* dpre_bf;   // bf16 [B, c_dim]
@@ -148,7 +150,9 @@ inline UBwd carve_bwd(const bsi_unet_config* c, int B, void* base) {
     w.dh1 = p + off; off += au(M * dim * 2);
     w.da = p + off; off += au(M * 2 * dim * 2);
     w.dqkv = p + off; off += au(M * 3 * dim * 2);
-    w.dfilm = reinterpret_cast<float*>(p + off); off += au((size_t)B * d.F * 4);
+    w.dfilm = reinterpret_cast<float*>(p + off); off += au((size_t)(d.HW / 64 > 0 ? d.HW / 64 : 1) * B * d.F * 4);
+    w.gnpart = reinterpret_cast<float*>(p + off); off += au((size_t)B * 2 * 2 * dim * 4);
+    w.decparts = reinterpret_cast<float*>(p + off); off += au(bsi_unet_decode_bwd_parts_floats((int)M, (int)dim, c->C) * 4);
     w.dfilm_bf = p + off; off += au((size_t)B * d.F * 2);
     w.dc = reinterpret_cast<float*>(p + off); off += au((size_t)B * cd * 4);
     w.dpre_bf = p + off; off += au((size_t)B * cd * 2);
@@ -301,25 +305,16 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
                   "bsi_unet_backward: bad args");
     const UD d = ud(cfg, B);
     TRY(check_geometry(cfg, d, "bsi_unet_backward"));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int dim = d.dim, H = cfg->H, W = cfg->W, L = d.L, M = (int)d.M, cd = cfg->c_dim;
     UTape tp = carve_tape(cfg, B, tape_mem);
     UBwd ws = carve_bwd(cfg, B, workspace);
     auto dskip = [&](int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws.dskips) + (size_t)i * ws.skip_stride); };
 
-    // gradients accumulated with atomics start from zero
-    bool ok = hipMemsetAsync(ws.dfilm, 0, (size_t)B * d.F * 4, s) == hipSuccess &&
-              hipMemsetAsync(g->dec_w, 0, (size_t)cfg->C * dim * 4, s) == hipSuccess &&
-              hipMemsetAsync(g->dec_b, 0, (size_t)cfg->C * 4, s) == hipSuccess &&
-              hipMemsetAsync(g->agn_w, 0, (size_t)dim * 4, s) == hipSuccess && hipMemsetAsync(g->agn_b, 0, (size_t)dim * 4, s) == hipSuccess;
-    for (int blk = 0; ok && blk < d.nblocks; ++blk) {
-        const size_t c = (size_t)(blk >= L + 2 ? 2 * dim : dim) * 4;
-        ok = hipMemsetAsync(g->blocks[blk].gn_w, 0, c, s) == hipSuccess && hipMemsetAsync(g->blocks[blk].gn_b, 0, c, s) == hipSuccess;
-    }
-    if (!ok) {
-        bsi_set_error("bsi_unet_backward: memset failed");
-        return BSI_ELAUNCH;
-    }
+    // No atomics anywhere in this backward (bit reproducible): FiLM gradients go to per-slab planes that are summed in fixed order
+    // at the end, GroupNorm affine and decode gradients to per-image / per-block rows summed by reduce_slabs -- nothing to zero.
+    BSI_CHECK_ARG(d.HW % 64 == 0, "bsi_unet_backward: H*W=%d must be a multiple of 64", d.HW);
+    const int fplanes = d.HW / 64;
+    const size_t fplane = (size_t)B * d.F;
 
     // residual block backward: dOut fp32 [M, dim] -> out1 (gradient of x1, + add_b) and out2 (gradient of the skip tensor x2)
     // `g_ready`: ws.g already holds the bf16 copy of dOut (written by the GroupNorm backward that produced dOut)
@@ -336,7 +331,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
                                           rg.conv2_w, rg.conv2_b, 0, ws.wg, stream));
         TRY(conv(ws.g, nullptr, rT.conv2_wT, nullptr, tp.zeros, ws.dy, nullptr, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_film_silu_bwd_drop(ws.dy, bt.h1, M, dim, d.HW, tp.film + (size_t)blk * 2 * dim, B, d.F, make_drop(dropout_p, seed, blk),
-                                   ws.dh1, ws.dfilm + (size_t)blk * 2 * dim, d.F, stream));
+                                   ws.dh1, ws.dfilm + (size_t)blk * 2 * dim, d.F, stream, fplane));
         TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.dh1, dim, bt.a, nullptr, tp.zeros, B, H, W, cx, 0, dim, 9, rg.conv1_w, rg.conv1_b, 0, ws.wg,
                                           stream));
         TRY(conv(ws.dh1, nullptr, rT.conv1_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, dim, 0, cx, 9, BSI_CONV_BIAS_BF16, stream));
@@ -348,13 +343,13 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         (void)rb;
         // out1 is the next block's dOut: its bf16 copy goes straight into ws.g (no longer read by this block)
         g_ready = true;
-        return bsi_groupnorm_bwd_cast_nhwc(ws.da, x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, add, add_b, out1, out2, rg.gn_w,
-                                           rg.gn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)blk * B * 64 : nullptr, stream);
+        return bsi_groupnorm_bwd_cast_det(ws.da, x1, dim, x2, cin2, B, d.HW, rb.gn_w, rb.gn_b, 1e-5f, 1, add, add_b, out1, out2, rg.gn_w,
+                                          rg.gn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)blk * B * 64 : nullptr, ws.gnpart, stream);
     };
 
     int cur = 0;
     const float* hlast = block_tape(tp, d, d.nblocks - 1).out;
-    TRY(bsi_unet_decode_bwd(g_out, c_out, 1, hlast, B, d.HW, dim, w->dec_w, cfg->C, ws.dcur[cur], g->dec_w, g->dec_b, stream));
+    TRY(bsi_unet_decode_bwd_det(g_out, c_out, 1, hlast, B, d.HW, dim, w->dec_w, cfg->C, ws.dcur[cur], g->dec_w, g->dec_b, ws.decparts, stream));
     for (int i = L - 1; i >= 0; --i) {  // up blocks
         const int blk = L + 2 + i;
         const float* x1 = i == 0 ? block_tape(tp, d, L + 1).out : block_tape(tp, d, blk - 1).out;
@@ -374,9 +369,9 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.dqkv, 3 * dim, tp.agn, nullptr, tp.zeros, B, H, W, dim, 0, 3 * dim, 9, g->aqkv_w, g->aqkv_b, 0,
                                           ws.wg, stream));
         TRY(conv(ws.dqkv, nullptr, wT->aqkv_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, 3 * dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
-        TRY(bsi_groupnorm_bwd_cast_nhwc(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
-                                        nullptr, g->agn_w, g->agn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)d.nblocks * B * 64 : nullptr,
-                                        stream));
+        TRY(bsi_groupnorm_bwd_cast_det(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
+                                       nullptr, g->agn_w, g->agn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)d.nblocks * B * 64 : nullptr,
+                                       ws.gnpart, stream));
         g_ready = true;
         cur ^= 1;
     }
@@ -394,7 +389,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
     TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, tp.xin, nullptr, tp.zeros, B, H, W, d.cin_pad, 0, dim, 9, g->enc_w, g->enc_b, 0, ws.wg, stream));
 
     // FiLM projections and pos_map (rows = samples)
-    TRY(bsi_cast_rows_bf16(ws.dfilm, d.F, B, d.F, ws.dfilm_bf, d.F, stream));
+    TRY(bsi_sum_cast_rows_bf16(ws.dfilm, fplanes, fplane, d.F, B, d.F, ws.dfilm_bf, d.F, stream));
     TRY(bsi_gemm_tn_bias_bf16(ws.dfilm_bf, d.F, tp.c2, cd, B, d.F, cd, g->film_w, cd, g->film_b, 0, ws.tn, stream));
     TRY(gemm(ws.dfilm_bf, d.F, wT->film_wT, d.F, nullptr, ws.dc, cd, B, cd, d.F, BSI_EPI_BIAS_F32, stream));
     TRY(bsi_silu_bwd_bf16(ws.dc, tp.pre2, (size_t)B * cd, ws.dpre_bf, stream));

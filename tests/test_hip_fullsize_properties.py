@@ -140,3 +140,28 @@ def test_full_size_gradient_of_a_batch_is_the_mean_of_its_shards(make, batch):
     report("fullsize_shard_equivalence", model=make.__name__.strip("_"), batch=batch, per_sample_max_rel=per_rel, flat_gradient_rel_l2=rel)
     assert per_rel < 1e-3, per_rel  # measured: 0 (both shard sizes take the same conditioning GEMM kernel)
     assert rel < 1e-4, rel          # measured: 3e-6 (DiT-L/2), 7e-7 (UNet)
+
+
+@pytest.mark.parametrize("make,batch", [(_dit, 32), (_unet, 64)], ids=["dit_l2", "vdm_unet"])
+def test_train_steps_are_bit_reproducible(make, batch):
+    """Two runs of three optimizer steps (forward + backward + clip + AdamW + EMA, dropout ON) from the same initial state, data and
+    generator seed end in bit-identical parameters: the backward has no atomics -- modulation / FiLM gradients go to per-slab
+    planes summed in fixed order, GroupNorm / final-LayerNorm / decoder gradients to per-image or per-block rows summed by
+    reduce_slabs, weight gradients to split-M slabs -- and the dropout masks are counter based."""
+    from bsi_amd.dp import DPTrainer
+    shape = (3, 32, 32)
+    finals = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        model = make().train()
+        trainer = DPTrainer(_bsi(model, shape), lr=2e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+        gen = torch.Generator(DEV).manual_seed(5)
+        x = (torch.randint(0, 256, (batch, *shape), device=DEV, generator=torch.Generator(DEV).manual_seed(1)).float() / 255) * 2 - 1
+        losses = [float(trainer.train_step(x, gen)) for _ in range(3)]
+        torch.cuda.synchronize()
+        finals.append((losses, trainer.fp.flat.clone(), trainer.ema_fp.flat.clone() if trainer.ema_fp is not None else None))
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]), float((finals[0][1] - finals[1][1]).abs().max())
+    if finals[0][2] is not None:
+        assert torch.equal(finals[0][2], finals[1][2])
+    report("train_step_reproducibility", model=make.__name__.strip("_"), batch=batch, steps=3, bit_identical=True)

@@ -119,6 +119,19 @@ __global__ void vdm_step_coeffs_kernel(const float* t, int k, float g0, float g1
     std_[i] = sqrtf(sigmoid_f(gs) * r);
 }
 
+// Sum of `acc` over the workgroup, waves added in index order through LDS (reproducible; one workgroup owns one output row, so
+// the row needs neither atomics nor a zero fill).  Returned to thread 0.
+__device__ __forceinline__ float block_sum_ordered(float acc) {
+    __shared__ float wsum[16];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+    return t;
+}
+
 // VDM reconstruction term with a discretisation (vdm.py:152-195): x_hat = z_0 / alpha_0, the Normal(x_hat, std) density is
 // evaluated at the k bin centres and normalised (log_softmax over bins); out[r] = -sum_D log p[bin(x)].
 // One wave per (row, 64-element chunk); every lane owns one element and loops over the bins.
@@ -150,8 +163,8 @@ __global__ void vdm_recon_nll_kernel(const float* __restrict__ x, const float* _
         const float dl = centers[idx] - mu;
         acc += ((-(dl * dl) / var2 + log_norm) - mx) - logf(se);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out + r, -acc);
+    const float tot = block_sum_ordered(acc);
+    if (threadIdx.x == 0) out[r] = -tot;
 }
 
 // out[r] = 0.5 * sum_D (var1 + (1 - var1) x^2 - log(var1) - 1)   (prior_loss, vdm.py:127-136), var1 = sigma2(t = 1)
@@ -163,8 +176,8 @@ __global__ void vdm_prior_kernel(const float* __restrict__ x, float var1, int D,
         const float v = x[(size_t)r * D + i];
         acc += ((var1 + omv * (v * v)) - lv) - 1.0f;
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out + r, 0.5f * acc);
+    const float tot = block_sum_ordered(acc);
+    if (threadIdx.x == 0) out[r] = 0.5f * tot;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -273,12 +286,7 @@ extern "C" int bsi_vdm_recon_nll(const float* x, const float* x_hat, float std_,
                                  int rows, int B, int D, float* out, bsi_stream_t stream) {
     BSI_CHECK_ARG(x && x_hat && bounds && out && std_ > 0.f && k > 0 && k <= 4096 && rows > 0 && B > 0 && D > 0,
                   "bsi_vdm_recon_nll: bad args");
-    if (hipMemsetAsync(out, 0, (size_t)rows * sizeof(float), S(stream)) != hipSuccess) {
-        bsi_set_error("bsi_vdm_recon_nll: memset failed");
-        return BSI_ELAUNCH;
-    }
-    int gx = (D + TPB - 1) / TPB;
-    if (gx > 64) gx = 64;
+    const int gx = 1;  // one workgroup per row: its sum is ordered (no atomics); rows = samples x batch give the parallelism
     hipLaunchKernelGGL(vdm_recon_nll_kernel, dim3(gx, rows), dim3(TPB), (size_t)k * sizeof(float), S(stream), x, x_hat, std_, bounds,
                        lo_edge, dx, k, B, D, out);
     BSI_CHECK_LAUNCH("bsi_vdm_recon_nll");
@@ -287,12 +295,7 @@ extern "C" int bsi_vdm_recon_nll(const float* x, const float* x_hat, float std_,
 
 extern "C" int bsi_vdm_prior(const float* x, float var_1, int rows, int D, float* out, bsi_stream_t stream) {
     BSI_CHECK_ARG(x && out && var_1 > 0.f && rows > 0 && D > 0, "bsi_vdm_prior: bad args");
-    if (hipMemsetAsync(out, 0, (size_t)rows * sizeof(float), S(stream)) != hipSuccess) {
-        bsi_set_error("bsi_vdm_prior: memset failed");
-        return BSI_ELAUNCH;
-    }
-    int gx = (D + TPB - 1) / TPB;
-    if (gx > 16) gx = 16;
+    const int gx = 1;
     hipLaunchKernelGGL(vdm_prior_kernel, dim3(gx, rows), dim3(TPB), 0, S(stream), x, var_1, D, out);
     BSI_CHECK_LAUNCH("bsi_vdm_prior");
     return BSI_OK;

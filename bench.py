@@ -260,7 +260,7 @@ def secondary_bench(a, bsi, dev, budget_s):
             for blk in m.dit.blocks:
                 blk.adaLN_modulation[-1].weight.normal_(0, 0.02)
         db = mk(m.to(dev).eval(), shape, 256)
-        b = 64
+        b = 128
         with torch.no_grad():
             dt, s = timed(lambda: db.sample(b, g), lambda: db.sample(b, g, t=t4(b)))
         assert torch.isfinite(s).all()

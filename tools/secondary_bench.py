@@ -73,7 +73,7 @@ with torch.no_grad():
         del bsi
     if "dit64" in WHICH:
         shape = (3, 64, 64)
-        bsi = make_bsi(dit(shape, 4), shape, 256)
+        bsi = make_bsi(dit(shape, 4), shape, int(os.environ.get("DIT64_K", "256")))
         g = torch.Generator(dev).manual_seed(0)
         b = 128
         dt, out = timed(lambda: bsi.sample(b, g))

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libbsi_hip.so binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbsi_hip.so")
+LIB_PATH = os.environ.get("BSI_HIP_LIB") or os.path.join(_HERE, "lib", "libbsi_hip.so")  # BSI_HIP_LIB: an experimental build for A/B runs
 
 _lib = None
 

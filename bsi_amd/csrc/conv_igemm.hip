@@ -595,6 +595,10 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                     int row = xrow0 + dy * p.Wd + dx;
                     asm volatile("" : "+v"(row));  // recompute per phase: hoisting the 9 taps' addresses out of the chunk loop costs 20+ VGPRs
                     const int xaddr = row * C_RB + ((qd ^ ((row >> 1) & 3)) << 4);
+                    // the four border words are re-materialised per phase: left to itself the compiler derives a 64-bit lane mask
+                    // for every (tap, fragment) once per tile -- 144 scalar registers, all spilled and read back lane by lane in
+                    // every phase; per phase they are 8 short-lived masks
+                    asm volatile("" : "+s"(ytop), "+s"(ybot), "+s"(xl), "+s"(xr));
                     const unsigned zall = dy < 0 ? ytop : dy > 0 ? ybot : 0u;
                     const unsigned zlane = dx < 0 ? xl : dx > 0 ? xr : 0u;
                     if ((zall | zlane) == 0) {  // no fragment of this wave touches a border under this tap
@@ -692,11 +696,12 @@ int launch_conv(ConvParams p, hipStream_t s) {
     const int grid = nwg < conv_cus() ? nwg : conv_cus();
     if constexpr (EPI != CEPI_FILM_ROWS_SILU_BF16) {
         // 3x3 without folded skip steps on images whose rows are whole fragments CAN run the slab kernel.  Which one does is
-        // measured per epilogue (one MI355X, 256 images of 32 x 32, kernel times inside the UNet sampling loop):
-        //   FiLM + SiLU -> bf16 (conv1):  slab 105 us (128 -> 128) / 172 us (256 -> 128); ring 230 us average (its FiLM instance spills)
-        //   bias + residual -> fp32 (+ GroupNorm partials, conv2): ring 134 us, slab 172 us (128 -> 128) -- the ring kernel's
-        //     K loop is spill free since its per-lane source state shrank to three registers, the slab kernel's is not
-        //   bias -> bf16: slab for more than 128 input channels (312 vs 361 us at 512 images), ring otherwise (3-5 % faster)
+        // measured per epilogue (one MI355X, 256 images of 32 x 32; tools/conv_bench.py with ABL=0,512,256 after the slab kernel
+        // lost its run-time issue bookkeeping and its spilled border masks):
+        //   bias -> bf16:                 slab 89 us (128 -> 128), 133 us (256 -> 128), 208 us (128 -> 384), 175 us (384 -> 128);
+        //                                 ring 102 / 175 / 235 / 252 us
+        //   FiLM + SiLU -> bf16 (conv1):  slab (the ring kernel's FiLM instance spills inside its K loop: 230 us average)
+        //   bias + residual -> fp32 (+ GroupNorm partials, conv2): ring 141-143 us, slab 148 us (128 -> 128)
         // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
         // 1024 / 2048 = ring kernel for the fp32 / FiLM epilogues, 4096 = slab kernel for the fp32 epilogues.
         const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
@@ -705,7 +710,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
                           : (g_conv_abl & 256) ? false
                           : F32 ? (g_conv_abl & 4096) != 0
                           : EPI == CEPI_FILM_SILU_BF16 ? !(g_conv_abl & 2048)
-                                                       : p.Cin > 128;
+                                                       : true;
         if (can && want) return launch_conv_slab<EPI>(p, grid, s);
     }
     const size_t lds = (size_t)C_R * C_SLOT;

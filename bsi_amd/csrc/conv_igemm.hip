@@ -659,6 +659,8 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         if (!has_next) break;
         tile = next;
     }
+    // the dummy DMAs of the last phases must have landed before the workgroup's LDS can be handed to the next one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wm == 0) PHASE_BARRIER();
 #undef PHASE_BARRIER
 }

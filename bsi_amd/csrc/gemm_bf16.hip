@@ -789,8 +789,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             gW[q] = (unsigned)n * (unsigned)(p.ldw * 2) + ((spos ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1))) << 4);
         }
     };
+    // ABL & 65536 (laboratory): the issue stream never ends -- past the last tile it re-reads that tile's panels into ring slots that
+    // are free -- so every phase issues and every vmcnt allowance is an immediate.  +2-4 % per kernel in the laboratory loop
+    // (LAB_REGULAR), +0.25 % on the sampling loop (A/B of two builds on one box): not worth surplus loads in the product.
+    constexpr bool REGULAR = (ABL & 65536) != 0;
     auto issue_next = [&]() -> bool {  // issues one half-stage; false when the stream is exhausted
-        if (itile >= hi) return false;
+        if (!REGULAR && itile >= hi) return false;
         char* base = lds + islot * HALF + wave * 1024;
         const size_t koff = (size_t)iv * 128;
 #pragma unroll
@@ -955,6 +959,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
         if (!has_next) break;
         tile = next;
     }
+    if constexpr (REGULAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus loads land before the LDS is released
     if (wm == 0) PHASE_BARRIER();
 #undef PHASE_BARRIER
 }

@@ -218,6 +218,19 @@ int main() {
             }
             continue;
         }
+        if (getenv("LAB_REGULAR")) {
+            // never-ending issue stream (ABL 65536) against the production stream that stops after the last tile
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            for (int r = 0; r < 3; ++r) {
+                rep("k64r stream ends", time_k64r<E, 0>(p, 20));
+                rep("k64r never-ending stream", time_k64r<E, 65536>(p, 20));
+                if (sh.N == 4096) {
+                    rep("k64r gelu stream ends", time_k64r<G, 0>(p, 20));
+                    rep("k64r gelu never-ending stream", time_k64r<G, 65536>(p, 20));
+                }
+            }
+            continue;
+        }
         if (getenv("LAB_STORES")) {
             // what the epilogue's stores cost with and without the operand stream beside them (256 CUs), each row twice
             for (int r = 0; r < 2; ++r) {

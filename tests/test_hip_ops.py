@@ -634,7 +634,8 @@ def _nhwc(x):
     (2, 32, 128, 256, 128, 9, "resid_skip"), (2, 32, 32, 0, 128, 9, "resid0"), (2, 32, 128, 0, 384, 9, "bias"),
     (9, 8, 256, 0, 64, 1, "bias"), (3, 16, 384, 0, 128, 9, "bias"), (5, 16, 256, 128, 128, 9, "resid_skip"),
     (12, 32, 128, 0, 128, 9, "bias_persistent"), (12, 32, 64, 0, 128, 9, "resid_persistent"), (3, 8, 128, 0, 384, 1, "resid"), (3, 32, 256, 0, 384, 9, "bias_ring"), (2, 32, 128, 0, 128, 9, "resid_ring"), (3, 32, 128, 0, 128, 9, "bias_slab"), (2, 32, 256, 0, 384, 9, "bias"), (5, 16, 128, 0, 256, 9, "resid"), (48, 16, 64, 0, 128, 9, "bias_persistent_slab"),
-    (48, 16, 128, 0, 128, 9, "bias_persistent_ring")])
+    (48, 16, 128, 0, 128, 9, "bias_persistent_ring"), (5, 8, 128, 0, 128, 9, "film"), (3, 32, 128, 0, 128, 9, "film_ring"),
+    (6, 16, 256, 0, 128, 9, "film")])
 def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
     if epi.endswith("_slab"):  # the pixel-slab kernel on a shape the dispatcher gives to the ring kernel
         N.check(N.lib().bsi_conv_set_ablation(512))

@@ -257,6 +257,181 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3, image width 32, C_in a multiple of 128, no second source: the three taps of one filter ROW share their pixels.
+// A stage is one image row of 32 output pixels; the im2col units of taps (dy, -1), (dy, 0), (dy, +1) for a 128-channel block are
+// the SAME input row y + dy shifted by one pixel, so the stage DMAs that row ONCE into LDS rows 1..32 of a 34-row image whose rows
+// 0 and 33 (x = -1 and x = 32) are zeros written at kernel start, and unit q reads its fragments at row offset q.  Per stage and
+// wave: 1 X + 1 dY DMA instruction instead of 3 + 1 (the generic kernel's operand DMA is a third of its time,
+// tools/wgrad_bench.py).  Tile = (filter row dy, channel block): 128 output channels x 3 x 128 im2col columns; everything else
+// -- ping-pong groups, ring of 5 stages, transposed fragment reads, split-M slabs, fused bias gradient -- as above.
+__global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) {
+    constexpr int UNITS = 3;
+    constexpr int G_SLOT = (UNITS + 1) * G_SUB;              // 32 KB: X image (34 rows used) in the first 24 KB, dY behind it
+    constexpr int G_R = 160 * 1024 / G_SLOT, G_D = G_R - 1;  // 5 slots, 4 in flight
+    constexpr int NI = 2;                                    // DMA instructions per stage and wave
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+
+    const int tiles = p.tiles_n * p.tiles_u;
+    const int total = tiles * p.splits, per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= total) return;
+    const int tile = logical % tiles, split = logical / tiles;
+    const int n0 = (tile / p.tiles_u) * 128, tu = tile % p.tiles_u;
+    const int cblocks = p.Cin >> 7;
+    const int cb = tu % cblocks, dyi = tu / cblocks, dy = dyi - 1;  // channel block, filter row
+    const int mbeg = split * p.m_per_split;                          // multiple of 32 (plan): stages are whole image rows
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 31) / 32;
+    if (nk <= 0) return;
+
+    // zero rows 0 and 33 of every slot's X image (never written again)
+    for (int i = tid; i < G_R * 2 * (G_RB / 16); i += 512) {
+        const int slot_i = i / (2 * (G_RB / 16)), r = (i / (G_RB / 16)) & 1, c16 = i % (G_RB / 16);
+        *reinterpret_cast<u32x4*>(lds + slot_i * G_SLOT + (r ? 33 : 0) * G_RB + c16 * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    constexpr unsigned OOB = 0xC0000000u;
+    const int srow = 4 * wave + (lane >> 4), spos = lane & 15;  // pixel x of this lane's X / dY row, 16-B chunk position
+    const unsigned xconst = (unsigned)(cb * 256 + ((spos ^ wg_swz(srow + 1)) << 4));  // X lands in LDS row srow + 1
+    const int ycol = n0 + ((spos ^ wg_swz(srow)) << 3);
+    const unsigned yconst = ycol < p.Cout ? (unsigned)(ycol * 2) : OOB;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dY), 0, 0x80000000u, 0x00020000);
+    int sm = mbeg + srow;               // this lane's output pixel in the stage to issue next
+    int sy = (mbeg >> 5) % p.H;         // image row of that stage (wave-uniform)
+    auto stage = [&](int slot_i) {
+        char* base = lds + slot_i * G_SLOT + wave * 1024;
+        const bool m_ok = sm < mend;
+        const bool row_ok = dy < 0 ? sy > 0 : dy > 0 ? sy < p.H - 1 : true;
+        const unsigned vx = (m_ok && row_ok) ? (unsigned)(sm + dy * 32) * (unsigned)(p.Cin * 2) + xconst : OOB;
+        const unsigned vy = m_ok ? (unsigned)sm * (unsigned)(p.ldy * 2) + yconst : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + G_RB), 16, vx, 0, 0, 0);  // rows 1 + 4 wave ..
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + UNITS * G_SUB), 16, vy, 0, 0, 0);
+        sm += 32;
+        sy = sy + 1 == p.H ? 0 : sy + 1;
+    };
+
+    const int q4 = lane >> 4, qp = (lane & 15) >> 2, pp = lane & 3;
+    const int mA = 8 * q4 + qp, mB = mA + 4;
+    const int half8 = 8 * (pp & 1), chp = pp >> 1;
+    const int wcol0 = 16 * UNITS * wave;  // first of this wave's 48 im2col columns inside the tile (3 units x 128 channels)
+    // X fragment i: unit q = column / 128 reads pixel rows shifted by q; addresses are per-lane constants of the kernel
+    int xa[UNITS], xb[UNITS];
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int col = wcol0 + 16 * i, q = col >> 7, ch = ((col & 127) >> 3) + chp;
+        xa[i] = (mA + q) * G_RB + ((ch ^ wg_swz(mA + q)) << 4) + half8;
+        xb[i] = (mB + q) * G_RB + ((ch ^ wg_swz(mB + q)) << 4) + half8;
+    }
+    const int swA = wg_swz(mA), swB = wg_swz(mB);
+    const int rowA = mA * G_RB, rowB = mB * G_RB;
+
+    f32x4 acc[UNITS][8];
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[UNITS], bf[8];
+    const bool do_colsum = p.colsum != nullptr && tu == 0;
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 onesf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) onesf[e] = (__bf16)1.0f;
+
+#define WG_BARRIER()                             \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#define TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
+
+    auto load_frags = [&](const char* b) {
+        union U { bf16x8 v; s16x4 h[2]; };
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            U u;
+            u.h[0] = TR(b + xa[i]);
+            u.h[1] = TR(b + xb[i]);
+            af[i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = 2 * j + chp;
+            U u;
+            u.h[0] = TR(b + UNITS * G_SUB + rowA + ((ch ^ swA) << 4) + half8);
+            u.h[1] = TR(b + UNITS * G_SUB + rowB + ((ch ^ swB) << 4) + half8);
+            bf[j] = u.v;
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < G_D; ++d)
+        if (d < nk) stage(d);
+    if (nk >= G_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows
+    WG_BARRIER();
+    if (grp == 1) WG_BARRIER();
+
+    int slot = 0, pslot = G_D;
+    for (int v = 0; v < nk; ++v) {
+        if (!(p.abl & 2)) load_frags(lds + slot * G_SLOT);
+        if (v + G_D < nk && !(p.abl & 1)) {
+            stage(pslot);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WG_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        if (!(p.abl & 4)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_colsum) {
+            bf16x8 bsel = bf[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) bsel = wave == j ? bf[j] : bsel;
+            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bsel, accb, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        WG_BARRIER();
+        slot = (slot == G_R - 1) ? 0 : slot + 1;
+        pslot = (pslot == G_R - 1) ? 0 : pslot + 1;
+    }
+    if (grp == 0) WG_BARRIER();
+#undef WG_BARRIER
+#undef TR
+
+    if (do_colsum && lane < 16) {
+        const int n = n0 + 16 * wave + lane;
+        if (n < p.Cout) p.colsum[(size_t)split * p.Cout + n] = accb[0];
+    }
+    // D rows = im2col column of the tile (4*(lane>>4) + reg inside slice tile i), D cols = output channel (lane & 15 inside tile j);
+    // column c of unit q is K index (3 dyi + q) * Cin + 128 cb + c of the packed weight layout
+    float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 16 * j + (lane & 15);
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int colt = wcol0 + 16 * i + 4 * q4, q = colt >> 7, c = colt & 127;
+            const int k = (3 * dyi + q) * p.Cin + 128 * cb + c;
+            __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(out + (size_t)n * p.Ktot + k));
+        }
+    }
+}
+
 int g_wg_cus = 0;
 
 void plan(WgParams& p) {
@@ -342,7 +517,14 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     set_max_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<4>), 160 * 1024);
     set_max_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), 160 * 1024);
     const dim3 grid(8 * ((p.tiles_n * p.tiles_u * p.splits + 7) / 8));  // whole rounds of the 8 XCDs (the kernel drops the excess)
-    if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
+    // one filter row's three taps share their pixels (conv_wgrad_halo_kernel): 3x3, width 32, C_in % 128 == 0, no second source
+    static const bool no_halo = getenv("BSI_WGRAD_NO_HALO") != nullptr;
+    const bool halo = !no_halo && taps == 9 && W == 32 && Cin % 128 == 0 && Cin2 == 0 && p.units == 3 && p.tiles_u == 3 * (Cin / 128) &&
+                      p.m_per_split % 32 == 0;
+    if (halo) {
+        set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel), 160 * 1024);
+        hipLaunchKernelGGL(conv_wgrad_halo_kernel, grid, dim3(512), 160 * 1024, s, p);
+    } else if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");
     if (dbias) {

@@ -905,7 +905,7 @@ def test_conv_weight_pack_batch(N):
                                                      (2, 16, 8, 32, 0, 128, 9), (2, 8, 8, 128, 0, 384, 9),
                                                      (5, 16, 16, 384, 0, 128, 9), (2, 8, 8, 256, 0, 128, 1),
                                                      (3, 32, 32, 128, 0, 128, 9), (2, 32, 32, 256, 0, 128, 9), (2, 32, 32, 128, 0, 384, 9),
-                                                     (7, 8, 32, 128, 0, 128, 9)])
+                                                     (7, 8, 32, 128, 0, 128, 9), (2, 32, 32, 128, 256, 128, 9)])
 def test_conv_weight_and_input_gradients(N, B, H, W, Cin, Cin2, Cout, taps):
     """bsi_conv_wgrad_nhwc_bf16 (+ unpack) and the input-gradient convolution (bsi_conv_weight_pack_t + the forward
     kernel) against autograd of torch.nn.functional.conv2d in float64."""

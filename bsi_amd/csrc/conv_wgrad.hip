@@ -267,9 +267,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
 // -- ping-pong groups, ring of 5 stages, transposed fragment reads, split-M slabs, fused bias gradient -- as above.
 __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) {
     constexpr int UNITS = 3;
-    constexpr int G_SLOT = (UNITS + 1) * G_SUB;              // 32 KB: X image (34 rows used) in the first 24 KB, dY behind it
-    constexpr int G_R = 160 * 1024 / G_SLOT, G_D = G_R - 1;  // 5 slots, 4 in flight
-    constexpr int NI = 2;                                    // DMA instructions per stage and wave
+    // a stage = TWO image rows (64 output pixels): X images of 34 rows each (36 allocated), then the 64 dY rows; ring of 4 stages.
+    // Two rows per phase halve the barriers and loop overhead per MFMA (48 MFMAs per wave and phase instead of 24).
+    constexpr int H_X = 36 * G_RB, H_Y = 2 * H_X, H_SLOT = H_Y + 64 * G_RB;  // 9216 + 9216 + 16384 = 34816 B
+    constexpr int G_R = 4, G_D = G_R - 1;
+    constexpr int NI = 4;  // DMA instructions per stage and wave: X and dY of both rows
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,15 +285,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
     const int n0 = (tile / p.tiles_u) * 128, tu = tile % p.tiles_u;
     const int cblocks = p.Cin >> 7;
     const int cb = tu % cblocks, dyi = tu / cblocks, dy = dyi - 1;  // channel block, filter row
-    const int mbeg = split * p.m_per_split;                          // multiple of 32 (plan): stages are whole image rows
+    const int mbeg = split * p.m_per_split;                          // multiple of 32 (plan): image rows
     const int mend = min(p.M, mbeg + p.m_per_split);
-    const int nk = (mend - mbeg + 31) / 32;
+    const int nk = (mend - mbeg + 63) / 64;
     if (nk <= 0) return;
 
-    // zero rows 0 and 33 of every slot's X image (never written again)
-    for (int i = tid; i < G_R * 2 * (G_RB / 16); i += 512) {
-        const int slot_i = i / (2 * (G_RB / 16)), r = (i / (G_RB / 16)) & 1, c16 = i % (G_RB / 16);
-        *reinterpret_cast<u32x4*>(lds + slot_i * G_SLOT + (r ? 33 : 0) * G_RB + c16 * 16) = u32x4{0u, 0u, 0u, 0u};
+    // zero rows 0 and 33 of both X images of every slot (never written again)
+    for (int i = tid; i < G_R * 4 * (G_RB / 16); i += 512) {
+        const int slot_i = i / (4 * (G_RB / 16)), which = (i / (G_RB / 16)) & 3, c16 = i % (G_RB / 16);
+        *reinterpret_cast<u32x4*>(lds + slot_i * H_SLOT + (which >> 1) * H_X + ((which & 1) ? 33 : 0) * G_RB + c16 * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
     constexpr unsigned OOB = 0xC0000000u;
@@ -301,18 +303,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
     const unsigned yconst = ycol < p.Cout ? (unsigned)(ycol * 2) : OOB;
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X), 0, 0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dY), 0, 0x80000000u, 0x00020000);
-    int sm = mbeg + srow;               // this lane's output pixel in the stage to issue next
-    int sy = (mbeg >> 5) % p.H;         // image row of that stage (wave-uniform)
+    int sm = mbeg + srow;               // this lane's output pixel in the first row of the stage to issue next
+    int sy = (mbeg >> 5) % p.H;         // image row of that row (wave-uniform)
     auto stage = [&](int slot_i) {
-        char* base = lds + slot_i * G_SLOT + wave * 1024;
-        const bool m_ok = sm < mend;
-        const bool row_ok = dy < 0 ? sy > 0 : dy > 0 ? sy < p.H - 1 : true;
-        const unsigned vx = (m_ok && row_ok) ? (unsigned)(sm + dy * 32) * (unsigned)(p.Cin * 2) + xconst : OOB;
-        const unsigned vy = m_ok ? (unsigned)sm * (unsigned)(p.ldy * 2) + yconst : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + G_RB), 16, vx, 0, 0, 0);  // rows 1 + 4 wave ..
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + UNITS * G_SUB), 16, vy, 0, 0, 0);
-        sm += 32;
-        sy = sy + 1 == p.H ? 0 : sy + 1;
+        char* base = lds + slot_i * H_SLOT + wave * 1024;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool m_ok = sm < mend;
+            const bool row_ok = dy < 0 ? sy > 0 : dy > 0 ? sy < p.H - 1 : true;
+            const unsigned vx = (m_ok && row_ok) ? (unsigned)(sm + dy * 32) * (unsigned)(p.Cin * 2) + xconst : OOB;
+            const unsigned vy = m_ok ? (unsigned)sm * (unsigned)(p.ldy * 2) + yconst : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(base + h * H_X + G_RB), 16, vx, 0, 0, 0);  // rows 1 + 4 wave ..
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(base + H_Y + h * 32 * G_RB), 16, vy, 0, 0, 0);
+            sm += 32;
+            sy = sy + 1 == p.H ? 0 : sy + 1;
+        }
     };
 
     const int q4 = lane >> 4, qp = (lane & 15) >> 2, pp = lane & 3;
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
     for (int i = 0; i < UNITS; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[UNITS], bf[8];
+    bf16x8 af[2][UNITS], bf[2][8];
     const bool do_colsum = p.colsum != nullptr && tu == 0;
     f32x4 accb = {0.f, 0.f, 0.f, 0.f};
     bf16x8 onesf;
@@ -353,19 +358,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
     auto load_frags = [&](const char* b) {
         union U { bf16x8 v; s16x4 h[2]; };
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            U u;
-            u.h[0] = TR(b + xa[i]);
-            u.h[1] = TR(b + xb[i]);
-            af[i] = u.v;
-        }
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ch = 2 * j + chp;
-            U u;
-            u.h[0] = TR(b + UNITS * G_SUB + rowA + ((ch ^ swA) << 4) + half8);
-            u.h[1] = TR(b + UNITS * G_SUB + rowB + ((ch ^ swB) << 4) + half8);
-            bf[j] = u.v;
+            for (int i = 0; i < UNITS; ++i) {
+                U u;
+                u.h[0] = TR(b + h * H_X + xa[i]);
+                u.h[1] = TR(b + h * H_X + xb[i]);
+                af[h][i] = u.v;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = 2 * j + chp;
+                U u;
+                u.h[0] = TR(b + H_Y + h * 32 * G_RB + rowA + ((ch ^ swA) << 4) + half8);
+                u.h[1] = TR(b + H_Y + h * 32 * G_RB + rowB + ((ch ^ swB) << 4) + half8);
+                bf[h][j] = u.v;
+            }
         }
     };
 
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
 
     int slot = 0, pslot = G_D;
     for (int v = 0; v < nk; ++v) {
-        if (!(p.abl & 2)) load_frags(lds + slot * G_SLOT);
+        if (!(p.abl & 2)) load_frags(lds + slot * H_SLOT);
         if (v + G_D < nk && !(p.abl & 1)) {
             stage(pslot);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (G_D - 1)) : "memory");
@@ -392,16 +400,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
         __builtin_amdgcn_s_setprio(1);
         if (!(p.abl & 4)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < UNITS; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < UNITS; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][i], bf[h][j], acc[i][j], 0, 0, 0);
         }
         if (do_colsum) {
-            bf16x8 bsel = bf[0];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) bsel = wave == j ? bf[j] : bsel;
-            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bsel, accb, 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 bsel = bf[h][0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) bsel = wave == j ? bf[h][j] : bsel;
+                accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bsel, accb, 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         WG_BARRIER();

@@ -18,6 +18,8 @@
 
 int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out,
                             hipStream_t s);
+int bsi_reduce_slabs2_launch(const float* slabsA, size_t strideA, size_t nA, float* outA, const float* slabsB, size_t strideB, size_t nB,
+                             float* outB, int splits, int accumulate, hipStream_t s);
 
 namespace {
 
@@ -540,10 +542,9 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     } else if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");
-    if (dbias) {
-        const int rc = bsi_reduce_slabs_launch(p.colsum, (size_t)Cout, p.splits, (size_t)Cout, accumulate, dbias, s);
-        if (rc != BSI_OK) return rc;
-    }
+    if (dbias)  // weight slabs and bias slabs summed by one launch
+        return bsi_reduce_slabs2_launch(p.out, p.slab_stride, p.slab_stride, out_packed, p.colsum, (size_t)Cout, (size_t)Cout, dbias, p.splits,
+                                        accumulate, s);
     return bsi_reduce_slabs_launch(p.out, p.slab_stride, p.splits, p.slab_stride, accumulate, out_packed, s);
 }
 

@@ -264,6 +264,55 @@ __global__ __launch_bounds__(256) void reduce_slabs_par_kernel(const float* __re
     }
 }
 
+// Two such reductions in one launch (a convolution's weight slabs and its bias slabs: the second job is a handful of workgroups
+// that would otherwise cost a launch of their own).  Blocks [0, gA) work on job A, the rest on job B.
+struct ReduceJob {
+    const float* slabs;
+    size_t slab_stride;
+    int splits;
+    size_t n4;
+    float* out;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_par2_kernel(ReduceJob ja, ReduceJob jb, int gA, int accumulate) {
+    __shared__ f32x4 part[3][64];
+    const bool second = (int)blockIdx.x >= gA;
+    const ReduceJob j = second ? jb : ja;
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)(second ? blockIdx.x - gA : blockIdx.x) * 64 + o;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < j.n4) {
+        int s = g;
+        for (; s + 12 < j.splits; s += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(j.slabs + (size_t)(s + 4 * u) * j.slab_stride) + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += v[u][e];
+        }
+        for (; s < j.splits; s += 4) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(j.slabs + (size_t)s * j.slab_stride) + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+    }
+    if (g > 0) part[g - 1][o] = a;
+    __syncthreads();
+    if (g == 0 && i < j.n4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += part[k][o][e];
+        if (accumulate) {
+            const f32x4 prev = reinterpret_cast<const f32x4*>(j.out)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += prev[e];
+        }
+        reinterpret_cast<f32x4*>(j.out)[i] = a;
+    }
+}
+
 // column sums of a bf16 [M, ld] matrix (bias gradients): out[n] (+)= sum_m Y[m, n].
 // A block owns a 256-column strip and a row range: 32 threads x 16 B cover the strip, 8 row lanes run in parallel and
 // each walks its rows with 4 independent 16-B loads in flight; partial sums go to a slab per row split and are summed
@@ -328,6 +377,22 @@ int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, 
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, s, slabs, slab_stride, splits, n4, accumulate, out);
     BSI_CHECK_LAUNCH("bsi_reduce_slabs");
     return BSI_OK;
+}
+
+// both reductions of a weight-gradient launch (weights: nA floats, bias: nB floats) -- ONE launch when both take the
+// many-slabs form, two otherwise; same summation order as bsi_reduce_slabs_launch either way
+int bsi_reduce_slabs2_launch(const float* slabsA, size_t strideA, size_t nA, float* outA, const float* slabsB, size_t strideB, size_t nB,
+                             float* outB, int splits, int accumulate, hipStream_t s) {
+    const size_t a4 = nA / 4, b4 = nB / 4;
+    if (splits >= 8 && a4 <= (size_t)256 * 1024 && b4 <= (size_t)256 * 1024) {
+        const int gA = (int)((a4 + 63) / 64), gB = (int)((b4 + 63) / 64);
+        hipLaunchKernelGGL(reduce_slabs_par2_kernel, dim3(gA + gB), dim3(256), 0, s, ReduceJob{slabsA, strideA, splits, a4, outA},
+                           ReduceJob{slabsB, strideB, splits, b4, outB}, gA, accumulate);
+        BSI_CHECK_LAUNCH("bsi_reduce_slabs2");
+        return BSI_OK;
+    }
+    const int rc = bsi_reduce_slabs_launch(slabsB, strideB, splits, nB, accumulate, outB, s);
+    return rc ? rc : bsi_reduce_slabs_launch(slabsA, strideA, splits, nA, accumulate, outA, s);
 }
 
 extern "C" size_t bsi_gemm_tn_workspace_bytes(int M, int N, int K) {

@@ -8,6 +8,8 @@
 #include "unet_ops.h"
 
 int bsi_reduce_slabs_launch(const float* slabs, size_t slab_stride, int splits, size_t n, int accumulate, float* out, hipStream_t s);
+int bsi_reduce_slabs2_launch(const float* slabsA, size_t strideA, size_t nA, float* outA, const float* slabsB, size_t strideB, size_t nB,
+                             float* outB, int splits, int accumulate, hipStream_t s);
 
 namespace {
 
@@ -388,9 +390,7 @@ static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const flo
                        HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats, partials);
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
     if (partials) {  // dgamma / dbeta are WRITTEN: per-image rows summed in image order
-        int rc = bsi_reduce_slabs_launch(partials, (size_t)2 * C, B, (size_t)C, 0, dgamma, S_(stream));
-        if (rc == BSI_OK) rc = bsi_reduce_slabs_launch(partials + C, (size_t)2 * C, B, (size_t)C, 0, dbeta, S_(stream));
-        return rc;
+        return bsi_reduce_slabs2_launch(partials, (size_t)2 * C, (size_t)C, dgamma, partials + C, (size_t)2 * C, (size_t)C, dbeta, B, 0, S_(stream));
     }
     return BSI_OK;
 }

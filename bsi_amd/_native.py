@@ -67,7 +67,7 @@ class UNetWeightsT(C.Structure):
 
 
 class UNetResBlockGrads(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("gn_w", "gn_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b")]
+    _fields_ = [(k, C.c_void_p) for k in ("gn_w", "gn_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "skip_w")]
 
 
 class UNetGrads(C.Structure):

@@ -447,6 +447,67 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
     }
 }
 
+// Finishing kernel of the UNet training engine: sums the split slabs in fixed order AND writes the torch Conv2d layout directly
+//   w_out[o][c][tap] = sum_s slab[s][o][tap * cin_pad + c]   (c < Cin),   w2_out[o][c] = sum_s slab[s][o][taps * cin_pad + c],
+//   dbias[o] = sum_s colsum[s][o]
+// in one launch (the packed result + bsi_conv_wgrad_unpack + two reductions cost three launches and a pass more).  Threads walk
+// the PACKED index (coalesced slab reads, 4 columns each, 4 threads sharing the slabs of an output as in reduce_slabs_par_kernel);
+// the 4-B writes into the Conv2d layout are scattered but few.  Blocks [0, gW) weights + skip weights, the rest bias.
+__global__ __launch_bounds__(256) void reduce_slabs_conv2d_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits, int Cout,
+                                                                  int Ktot, int Cin, int cin_pad, int taps, int Cin2,
+                                                                  float* __restrict__ w_out, float* __restrict__ w2_out,
+                                                                  const float* __restrict__ cs_slabs, float* __restrict__ dbias, int gW) {
+    __shared__ f32x4 part[3][64];
+    const int o64 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const bool bias_job = (int)blockIdx.x >= gW;
+    const size_t n4 = bias_job ? (size_t)(Cout / 4) : (size_t)Cout * Ktot / 4;
+    const size_t i = (size_t)(bias_job ? blockIdx.x - gW : blockIdx.x) * 64 + o64;
+    const float* src = bias_job ? cs_slabs : slabs;
+    const size_t stride = bias_job ? (size_t)Cout : slab_stride;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = g;
+        for (; s + 12 < splits; s += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(s + 4 * u) * stride) + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += v[u][e];
+        }
+        for (; s < splits; s += 4) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)s * stride) + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+    }
+    if (g > 0) part[g - 1][o64] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += part[k][o64][e];
+        if (bias_job) {
+            reinterpret_cast<f32x4*>(dbias)[i] = a;
+        } else {
+            const int o = (int)((i * 4) / Ktot), col = (int)((i * 4) % Ktot);  // Ktot % 4 == 0: the four columns share o
+            const int conv_k = taps * cin_pad;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = col + e;
+                if (k < conv_k) {
+                    const int tap = k / cin_pad, c = k - tap * cin_pad;
+                    if (c < Cin) w_out[((size_t)o * Cin + c) * taps + tap] = a[e];
+                } else if (w2_out && k - conv_k < Cin2) {
+                    w2_out[(size_t)o * Cin2 + (k - conv_k)] = a[e];
+                }
+            }
+        }
+    }
+}
+
 int g_wg_cus = 0;
 
 void plan(WgParams& p) {
@@ -504,10 +565,16 @@ extern "C" size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int C
     return (size_t)p.splits * p.slab_stride * sizeof(float) + (size_t)p.splits * (size_t)Cout * sizeof(float);  // + bias-gradient slabs
 }
 
+struct Conv2dOut {  // optional: write the torch Conv2d layout instead of the packed one (engine-internal entry below)
+    float* w;   // [Cout][cin_logical][taps]
+    float* w2;  // [Cout][Cin2] or null
+    int cin_logical;
+};
+
 static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W, int Cin,
                            int Cin2, int Cout, int taps, float* out_packed, float* dbias, int accumulate, void* workspace,
-                           bsi_stream_t stream) {
-    BSI_CHECK_ARG(dy && x && zeros && out_packed && workspace, "bsi_conv_wgrad: null pointer");
+                           bsi_stream_t stream, const Conv2dOut* c2d = nullptr) {
+    BSI_CHECK_ARG(dy && x && zeros && (out_packed || c2d) && workspace, "bsi_conv_wgrad: null pointer");
     BSI_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 9 || taps == 1), "bsi_conv_wgrad: bad sizes");
     BSI_CHECK_ARG(Cin % 8 == 0 && Cin2 % 8 == 0 && Cout % 8 == 0 && ldy % 8 == 0 && ldy >= Cout,
                   "bsi_conv_wgrad: Cin=%d Cin2=%d Cout=%d ldy=%d must be multiples of 8", Cin, Cin2, Cout, ldy);
@@ -542,10 +609,28 @@ static int conv_wgrad_impl(const void* dy, int ldy, const void* x, const void* x
     } else if (p.units == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(512), 160 * 1024, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(512), 160 * 1024, s, p);
     BSI_CHECK_LAUNCH("bsi_conv_wgrad");
+    if (c2d) {  // slabs -> Conv2d layout (+ skip weights, + bias) in one finishing launch
+        const int gW = (int)(((size_t)Cout * p.Ktot / 4 + 63) / 64), gB = (Cout / 4 + 63) / 64;
+        hipLaunchKernelGGL(reduce_slabs_conv2d_kernel, dim3(gW + gB), dim3(256), 0, s, p.out, p.slab_stride, p.splits, Cout, p.Ktot,
+                           c2d->cin_logical, Cin, taps, Cin2, c2d->w, c2d->w2, p.colsum, dbias, gW);
+        BSI_CHECK_LAUNCH("bsi_conv_wgrad_conv2d");
+        return BSI_OK;
+    }
     if (dbias)  // weight slabs and bias slabs summed by one launch
         return bsi_reduce_slabs2_launch(p.out, p.slab_stride, p.slab_stride, out_packed, p.colsum, (size_t)Cout, (size_t)Cout, dbias, p.splits,
                                         accumulate, s);
     return bsi_reduce_slabs_launch(p.out, p.slab_stride, p.splits, p.slab_stride, accumulate, out_packed, s);
+}
+
+// engine-internal (unet_ops.h): weight + bias gradient written in the torch Conv2d layout, w [Cout][cin_logical][taps] (the kernel
+// runs on Cin >= cin_logical padded channels), w2 [Cout][Cin2] for folded 1x1 skip columns; outputs are WRITTEN
+int bsi_conv_wgrad_conv2d_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
+                                    int Cin, int cin_logical, int Cin2, int Cout, int taps, float* w, float* w2, float* dbias,
+                                    void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(w && dbias && cin_logical > 0 && cin_logical <= Cin && Cout % 4 == 0 && (Cin2 == 0 || w2),
+                  "bsi_conv_wgrad_conv2d: bad args");
+    const Conv2dOut c2d{w, w2, cin_logical};
+    return conv_wgrad_impl(dy, ldy, x, x2, zeros, B, H, W, Cin, Cin2, Cout, taps, nullptr, dbias, 0, workspace, stream, &c2d);
 }
 
 extern "C" int bsi_conv_wgrad_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B,

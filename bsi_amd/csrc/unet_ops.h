@@ -16,3 +16,6 @@ int bsi_unet_decode_bwd_det(const float* g_xhat, const float* c_out, int coef_st
                             int Cout, float* dh, float* dw, float* db, float* parts, bsi_stream_t stream);
 int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, int row_stride, int rows, int cols, void* out, int ld_out,
                            bsi_stream_t stream);
+int bsi_conv_wgrad_conv2d_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
+                                    int Cin, int cin_logical, int Cin2, int Cout, int taps, float* w, float* w2, float* dbias,
+                                    void* workspace, bsi_stream_t stream);

@@ -327,13 +327,13 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         BlockTape bt = block_tape(tp, d, blk);
         const int cin2 = x2 ? dim : 0, cx = dim + cin2;
         if (!g_ready) TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));  // bf16 copy of dOut
-        TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, bt.y, x2 ? bt.raw : nullptr, tp.zeros, B, H, W, dim, x2 ? 2 * dim : 0, dim, 9,
-                                          rg.conv2_w, rg.conv2_b, 0, ws.wg, stream));
+        TRY(bsi_conv_wgrad_conv2d_nhwc_bf16(ws.g, dim, bt.y, x2 ? bt.raw : nullptr, tp.zeros, B, H, W, dim, dim, x2 ? 2 * dim : 0, dim, 9,
+                                            rg.conv2_w, x2 ? rg.skip_w : nullptr, rg.conv2_b, ws.wg, stream));
         TRY(conv(ws.g, nullptr, rT.conv2_wT, nullptr, tp.zeros, ws.dy, nullptr, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_film_silu_bwd_drop(ws.dy, bt.h1, M, dim, d.HW, tp.film + (size_t)blk * 2 * dim, B, d.F, make_drop(dropout_p, seed, blk),
                                    ws.dh1, ws.dfilm + (size_t)blk * 2 * dim, d.F, stream, fplane));
-        TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.dh1, dim, bt.a, nullptr, tp.zeros, B, H, W, cx, 0, dim, 9, rg.conv1_w, rg.conv1_b, 0, ws.wg,
-                                          stream));
+        TRY(bsi_conv_wgrad_conv2d_nhwc_bf16(ws.dh1, dim, bt.a, nullptr, tp.zeros, B, H, W, cx, cx, 0, dim, 9, rg.conv1_w, nullptr, rg.conv1_b,
+                                            ws.wg, stream));
         TRY(conv(ws.dh1, nullptr, rT.conv1_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, dim, 0, cx, 9, BSI_CONV_BIAS_BF16, stream));
         const float* add = dOut;
         if (x2) {  // 1x1 skip conv on cat(x, x_skip) (residual_block.py:40,63): d cat = g . Wskip
@@ -363,11 +363,12 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
         const float* dOut = ws.dcur[cur];
         const float* hin = block_tape(tp, d, L).out;
         if (!g_ready) TRY(bsi_silu_bwd_bf16(dOut, nullptr, (size_t)M * dim, ws.g, stream));
-        TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, tp.ay, nullptr, tp.zeros, B, H, W, dim, 0, dim, 9, g->aout_w, g->aout_b, 0, ws.wg, stream));
+        TRY(bsi_conv_wgrad_conv2d_nhwc_bf16(ws.g, dim, tp.ay, nullptr, tp.zeros, B, H, W, dim, dim, 0, dim, 9, g->aout_w, nullptr, g->aout_b, ws.wg,
+                                            stream));
         TRY(conv(ws.g, nullptr, wT->aout_wT, nullptr, tp.zeros, ws.dy, nullptr, B, H, W, dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_attention_bwd_long(tp.qkv, 3 * dim, tp.ay, ws.dy, dim, tp.lse, B, d.HW, cfg->heads, d.dh, ws.dqkv, 3 * dim, stream));
-        TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.dqkv, 3 * dim, tp.agn, nullptr, tp.zeros, B, H, W, dim, 0, 3 * dim, 9, g->aqkv_w, g->aqkv_b, 0,
-                                          ws.wg, stream));
+        TRY(bsi_conv_wgrad_conv2d_nhwc_bf16(ws.dqkv, 3 * dim, tp.agn, nullptr, tp.zeros, B, H, W, dim, dim, 0, 3 * dim, 9, g->aqkv_w, nullptr,
+                                            g->aqkv_b, ws.wg, stream));
         TRY(conv(ws.dqkv, nullptr, wT->aqkv_wT, nullptr, tp.zeros, ws.da, nullptr, B, H, W, 3 * dim, 0, dim, 9, BSI_CONV_BIAS_BF16, stream));
         TRY(bsi_groupnorm_bwd_cast_det(ws.da, hin, dim, nullptr, 0, B, d.HW, w->agn_w, w->agn_b, 1e-5f, 0, dOut, nullptr, ws.dcur[cur ^ 1],
                                        nullptr, g->agn_w, g->agn_b, ws.g, d.HW <= 1024 ? tp.gnstats + (size_t)d.nblocks * B * 64 : nullptr,
@@ -386,7 +387,8 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
     }
     // encode convolution (vdm_unet.py:71,99)
     if (!g_ready) TRY(bsi_silu_bwd_bf16(ws.dcur[cur], nullptr, (size_t)M * dim, ws.g, stream));
-    TRY(bsi_conv_wgrad_bias_nhwc_bf16(ws.g, dim, tp.xin, nullptr, tp.zeros, B, H, W, d.cin_pad, 0, dim, 9, g->enc_w, g->enc_b, 0, ws.wg, stream));
+    TRY(bsi_conv_wgrad_conv2d_nhwc_bf16(ws.g, dim, tp.xin, nullptr, tp.zeros, B, H, W, d.cin_pad, d.cin, 0, dim, 9, g->enc_w, nullptr, g->enc_b,
+                                        ws.wg, stream));
 
     // FiLM projections and pos_map (rows = samples)
     TRY(bsi_sum_cast_rows_bf16(ws.dfilm, fplanes, fplane, d.F, B, d.F, ws.dfilm_bf, d.F, stream));

@@ -107,7 +107,6 @@ class _UNetTrainFn(torch.autograd.Function):
         dev = g_out.device
         g_out = g_out.contiguous()
         dim, cd = cfg.dim, cfg.c_dim
-        cin_pad = lib.bsi_unet_cin_pad(C.byref(cfg))
         named = dict(model.named_parameters())
         order = [n for n, _ in model.named_parameters()]
         sizes = {n: named[n].numel() for n in order}
@@ -116,20 +115,6 @@ class _UNetTrainFn(torch.autograd.Function):
         for n in order:
             views[n] = flat[off:off + sizes[n]].view_as(named[n])
             off += sizes[n]
-        keep, unpack = [], []  # (packed tensor, conv param name, cin_pad, col0, skip?)
-
-        def packed(name, cin_p=None, extra=None):
-            cout, cin, kh, kw = named[name].shape
-            taps = kh * kw
-            cin_p = cin_p or cin
-            k = taps * cin_p + (named[extra].shape[1] if extra else 0)
-            buf = torch.empty((cout, k), dtype=torch.float32, device=dev)
-            keep.append(buf)
-            unpack.append((buf, name, cout, cin, taps, cin_p, k, 0))
-            if extra:
-                unpack.append((buf, extra, cout, named[extra].shape[1], 1, named[extra].shape[1], k, taps * cin_p))
-            return buf.data_ptr()
-
         names = _block_names(model)
         blocks_m = model._blocks()
         arr = (N.UNetResBlockGrads * len(names))()
@@ -138,9 +123,11 @@ class _UNetTrainFn(torch.autograd.Function):
             last = len(rb.layers) - 1
             has_skip = isinstance(rb.skip, nn.Conv2d)
             arr[i].gn_w, arr[i].gn_b = views[pfx + "layers.0.weight"].data_ptr(), views[pfx + "layers.0.bias"].data_ptr()
-            arr[i].conv1_w, arr[i].conv1_b = packed(pfx + "layers.2.weight"), views[pfx + "layers.2.bias"].data_ptr()
-            arr[i].conv2_w = packed(pfx + f"layers.{last}.weight", extra=pfx + "skip.weight" if has_skip else None)
+            # convolution weight gradients are written straight in the nn.Conv2d layout of the flat buffer
+            arr[i].conv1_w, arr[i].conv1_b = views[pfx + "layers.2.weight"].data_ptr(), views[pfx + "layers.2.bias"].data_ptr()
+            arr[i].conv2_w = views[pfx + f"layers.{last}.weight"].data_ptr()
             arr[i].conv2_b = views[pfx + f"layers.{last}.bias"].data_ptr()
+            arr[i].skip_w = views[pfx + "skip.weight"].data_ptr() if has_skip else None
             if has_skip:
                 skip_bias.append((pfx + "skip.bias", pfx + f"layers.{last}.bias"))
         F = len(names) * 2 * dim
@@ -148,7 +135,7 @@ class _UNetTrainFn(torch.autograd.Function):
         film_b = torch.empty(F, dtype=torch.float32, device=dev)
         pm1_pad = torch.empty((cd, 64), dtype=torch.float32, device=dev)
         g = N.UNetGrads()
-        g.enc_w, g.enc_b = packed("encode.weight", cin_p=cin_pad), views["encode.bias"].data_ptr()
+        g.enc_w, g.enc_b = views["encode.weight"].data_ptr(), views["encode.bias"].data_ptr()
         g.dec_w, g.dec_b = views["decode.weight"].data_ptr(), views["decode.bias"].data_ptr()
         g.pm1_w_padded, g.pm1_b = pm1_pad.data_ptr(), views["pos_map.1.bias"].data_ptr()
         g.pm3_w, g.pm3_b = views["pos_map.3.weight"].data_ptr(), views["pos_map.3.bias"].data_ptr()
@@ -156,15 +143,12 @@ class _UNetTrainFn(torch.autograd.Function):
         g.blocks = C.cast(arr, C.POINTER(N.UNetResBlockGrads))
         apfx = "u_net.center_block.1.fn."
         g.agn_w, g.agn_b = views[apfx + "0.weight"].data_ptr(), views[apfx + "0.bias"].data_ptr()
-        g.aqkv_w, g.aqkv_b = packed(apfx + "1.to_qkv.weight"), views[apfx + "1.to_qkv.bias"].data_ptr()
-        g.aout_w, g.aout_b = packed(apfx + "1.to_out.weight"), views[apfx + "1.to_out.bias"].data_ptr()
+        g.aqkv_w, g.aqkv_b = views[apfx + "1.to_qkv.weight"].data_ptr(), views[apfx + "1.to_qkv.bias"].data_ptr()
+        g.aout_w, g.aout_b = views[apfx + "1.to_out.weight"].data_ptr(), views[apfx + "1.to_out.bias"].data_ptr()
         ws = torch.empty(lib.bsi_unet_backward_workspace_bytes(C.byref(cfg), B), dtype=torch.uint8, device=dev)
         N.check(lib.bsi_unet_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
                                       N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
         ctx.tape = None
-        # packed conv gradients -> nn.Conv2d layout inside the flat buffer
-        for buf, name, cout, cin, taps, cin_p, k, col0 in unpack:
-            N.check(lib.bsi_conv_wgrad_unpack(N.ptr(buf), cout, cin, taps, cin_p, k, col0, 0, N.ptr(views[name]), N.stream()))
         for sb, cb in skip_bias:  # out = skip(x) + layers(x): both biases receive the same gradient
             views[sb].copy_(views[cb])
         for i, pfx in enumerate(names):

@@ -500,21 +500,22 @@ typedef struct bsi_unet_weights_t {
     const void* film_wT;  /* [c_dim][nblocks*2*dim]  transpose of the stacked project_onto_scale_shift weights */
     const void* pm3_wT;   /* [c_dim][c_dim] */
 } bsi_unet_weights_t;
-typedef struct bsi_unet_resblock_grads { /* fp32; conv weights in the PACKED layout of bsi_conv_weight_pack */
+typedef struct bsi_unet_resblock_grads { /* fp32, WRITTEN; conv weights in the torch Conv2d layout [Cout][Cin][kh][kw] */
     float *gn_w, *gn_b;
-    float* conv1_w; float* conv1_b; /* [dim][9*Cin] */
-    float* conv2_w; float* conv2_b; /* [dim][9*dim (+ 2*dim skip columns)]; conv2_b is also the skip conv's bias gradient */
+    float* conv1_w; float* conv1_b; /* [dim][Cin][3][3] */
+    float* conv2_w; float* conv2_b; /* [dim][dim][3][3]; conv2_b is also the skip conv's bias gradient */
+    float* skip_w;                  /* up blocks: [dim][2*dim] (the folded 1x1 skip convolution), else NULL */
 } bsi_unet_resblock_grads;
 typedef struct bsi_unet_grads {
-    float* enc_w; float* enc_b;         /* [dim][9*cin_pad] packed */
+    float* enc_w; float* enc_b;         /* [dim][C + Fourier channels][3][3] (unpadded) */
     float *dec_w, *dec_b;
     float* pm1_w_padded; float* pm1_b;  /* [c_dim][64] */
     float* pm3_w; float* pm3_b;
     float* film_w; float* film_b;       /* stacked [nblocks*2*dim][c_dim], [nblocks*2*dim] */
     const bsi_unet_resblock_grads* blocks;
     float *agn_w, *agn_b;
-    float* aqkv_w; float* aqkv_b;       /* [3*dim][9*dim] packed */
-    float* aout_w; float* aout_b;       /* [dim][9*dim] packed */
+    float* aqkv_w; float* aqkv_b;       /* [3*dim][dim][3][3] */
+    float* aout_w; float* aout_b;       /* [dim][dim][3][3] */
 } bsi_unet_grads;
 size_t bsi_unet_tape_bytes(const bsi_unet_config* cfg, int B);
 size_t bsi_unet_backward_workspace_bytes(const bsi_unet_config* cfg, int B);

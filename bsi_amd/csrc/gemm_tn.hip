@@ -25,6 +25,7 @@ struct TnParams {
     size_t slab_stride;  // floats between slabs
     float* colsum;       // optional: [splits][colsum_stride] column sums of P (bias gradient), written by the k-tile-0 workgroups
     size_t colsum_stride;
+    int xcd_map;         // XCD-aware workgroup order (off: BSI_TN_ABL & 1)
 };
 
 constexpr int T_RB = 512;                 // bytes per LDS row (256 bf16 columns)
@@ -41,9 +42,33 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
     const int wg = wave >> 2;   // ping-pong group; also the n half (128 columns) of the tile
     const int wk = wave & 3;    // 64-wide k slice
 
+    // Workgroup -> (split, n tile, k tile).  Workgroups go to the 8 XCDs round robin (blockIdx % 8) and every XCD has its own L2,
+    // so the workgroups of ONE XCD should share operand panels: XCD x takes a contiguous range of the order (split, band, slow
+    // tile, fast tile), where `fast` is the smaller tile dimension walked in bands of <= 4 -- 32 consecutive entries are 8 x 4 tiles
+    // of one split = 12 panel streams for 32 workgroups.  (Plain blockIdx order gave an XCD one k tile, 2-8 n tiles and ALL
+    // splits: 36-48 streams, each P panel fetched by four XCDs.)
     const int tiles = p.tiles_n * p.tiles_k;
-    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
-    const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
+    int tile_n, tile_k, split;
+    if (p.xcd_map) {
+        const int L = (int)gridDim.x, b = (int)blockIdx.x;
+        const int x = b & 7, lo = L >> 3, rem = L & 7;
+        const int id = x * lo + min(x, rem) + (b >> 3);
+        split = id / tiles;
+        const int t = id - split * tiles;
+        const bool k_fast = p.tiles_k <= p.tiles_n;
+        const int F = k_fast ? p.tiles_k : p.tiles_n, S = k_fast ? p.tiles_n : p.tiles_k;
+        const int band = t / (4 * S), r = t - band * 4 * S;
+        const int w = min(4, F - 4 * band);  // the last band may be narrower
+        const int sl = r / w, f = 4 * band + (r - sl * w);
+        tile_n = k_fast ? sl : f;
+        tile_k = k_fast ? f : sl;
+    } else {
+        const int tile = blockIdx.x % tiles;
+        split = blockIdx.x / tiles;
+        tile_n = tile / p.tiles_k;
+        tile_k = tile % p.tiles_k;
+    }
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
     const int nk = (mend - mbeg + 31) / 32;
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
     bf16x8 af[4], bf[8];
     // fused bias gradient: column sums of the P tile = one extra MFMA with an all-ones A operand; wave wk takes the
     // column tiles 2wk and 2wk+1 of its P half, workgroups of k-tile 0 only
-    const bool do_colsum = p.colsum != nullptr && (tile % p.tiles_k) == 0;
+    const bool do_colsum = p.colsum != nullptr && tile_k == 0;
     f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
 #define TN_BARRIER()                             \
@@ -446,6 +471,8 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
         p.colsum = direct ? colsum_out : cs_slabs;
         p.colsum_stride = n4;
     }
+    static const int abl = [] { const char* e = getenv("BSI_TN_ABL"); return e ? atoi(e) : 0; }();
+    p.xcd_map = !(abl & 1);
     set_max_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T_R * T_SLOT);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");

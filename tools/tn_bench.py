@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Timing of the weight-gradient GEMM dW = dY^T X (+ bias gradient) on the DiT-L shapes at the training batch
+(B images x 256 tokens).  One mode per process (BSI_TN_ABL is read once); A/B = run it twice on one box."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bsi_amd import _native as N  # noqa: E402
+
+dev = "cuda"
+B = int(os.environ.get("B", "512"))
+M = B * 256
+SHAPES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
+ROUNDS, ITERS = 5, 5
+lib = N.lib()
+g = torch.Generator(device=dev).manual_seed(0)
+for name, Nn, K in SHAPES:
+    dY = torch.randn((M, Nn), device=dev, generator=g).to(torch.bfloat16)
+    X = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+    out = torch.empty((Nn, K), device=dev)
+    cs = torch.empty(Nn, device=dev)
+    ws = torch.empty(lib.bsi_gemm_tn_workspace_bytes(M, Nn, K), dtype=torch.uint8, device=dev)
+    def run():
+        N.check(lib.bsi_gemm_tn_bias_bf16(N.ptr(dY), Nn, N.ptr(X), K, M, Nn, K, N.ptr(out), K, N.ptr(cs), 0, N.ptr(ws), N.stream()))
+    run(); run()
+    torch.cuda.synchronize()
+    ref = dY[:4096].float().t() @ X[:4096].float()
+    ms = []
+    for r in range(ROUNDS):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(ITERS):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / ITERS)
+    ms.sort()
+    flops = 2.0 * M * Nn * K
+    print(f"{name:4s} M={M} N={Nn} K={K}: med {flops / ms[len(ms) // 2] / 1e9:7.0f} TF (best {flops / ms[0] / 1e9:6.0f})  {ms[len(ms) // 2] * 1e3:8.1f} us"
+          f"  checksum {float(out.double().abs().sum()):.6e}  ABL={os.environ.get('BSI_TN_ABL', '0')}", flush=True)

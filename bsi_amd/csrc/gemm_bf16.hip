@@ -328,6 +328,103 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     gemm_epilogue<TM, EPI, BIAS_IN_ACC>(p, acc, m0 + wm * TM * 16, n0 + wn * 64, lane);
 }
 
+// Training epilogues of the K = 64 kernel -- BIAS_GELU_DUAL (two outputs) and MUL_GELUGRAD (an auxiliary input) -- one 16-row block
+// at a time with a scheduling fence behind each: interleaved by the compiler, the blocks' temporaries pushed the kernel over its
+// 256 registers, it spilled the issue stream's source offsets, and their reloads (scratch loads + s_waitcnt vmcnt(0)) drained the
+// operand DMA pipeline in EVERY load phase: 840-860 TFLOP/s against the 1250 of the plain bf16 epilogue at the same shape.  The
+// auxiliary rows are fetched two blocks ahead (in front of the stores of the block in between: vmcnt retires in order, and a load
+// queued behind stores waits for them), and the pre-activation leaves as whole 128-B lines like the main output.
+template <int EPI>
+__device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane) {
+    static_assert(EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16, "training epilogues only");
+    const int rho = lane & 15, qd = lane >> 4;
+    const int nb = nw0 + 16 * qd;
+    const bool nb_ok = nb < p.N;
+    const bool odd = lane & 1;
+    const int col = nb + (odd ? 8 : 0);
+    // lanes rho and rho^1 swap one half of their 16 columns: 8 lanes then write one complete 128-B line of a row pair per store
+    auto store_pair = [&](void* outp, int j, const u32x4 w0, const u32x4 w1) {
+        u32x4 st_even, st_odd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned send = odd ? w0[e] : w1[e];
+            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+            st_even[e] = odd ? recv : w0[e];
+            st_odd[e] = odd ? w1[e] : recv;
+        }
+        const int m_even = mw0 + 16 * j + (rho & ~1);
+        if (nb_ok) {
+            __bf16* ob = reinterpret_cast<__bf16*>(outp) + col;
+            if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
+            if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
+        }
+    };
+    // The auxiliary loads are inline asm with hand-counted waits: hipcc assumes loads and stores may complete out of order with each
+    // other and would wait vmcnt(0) -- i.e. for the previous blocks' stores -- in front of every block (on this hardware they retire in
+    // issue order, MI355X_MICROARCH.md).  Counting needs every store of the wave to be issued: full blocks only, else vmcnt(0).
+    const bool full = __builtin_amdgcn_readfirstlane((mw0 + 128 <= p.M && nw0 + 64 <= p.N) ? 1 : 0) != 0;
+    u32x4 ax[2][2];
+    auto load_aux = [&](int j, u32x4 (&d)[2]) {  // rows / columns beyond the matrix are clamped: their products are never stored
+        int m = mw0 + 16 * j + rho;
+        m = m < p.M ? m : p.M - 1;
+        const __bf16* a = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + (nb_ok ? nb : 0);
+        asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off offset:16 nt"
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(a) : "memory");
+    };
+    auto wait_aux = [&](int j, u32x4 (&d)[2]) {  // operations issued after block j's loads: see the sequence in the loop
+        if (full) {
+            if (j == 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+            else if (j == 1 || j == 7) asm volatile("s_waitcnt vmcnt(4)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+        }
+    };
+    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+        load_aux(0, ax[0]);
+        load_aux(1, ax[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];  // the accumulators started at the bias
+        if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+            // issue order: L0 L1 | block 0: wait L0, compute, L2, S0 | block 1: wait L1, compute, L3, S1 | ... (L / S = 2 instructions)
+            wait_aux(j, ax[j & 1]);
+            const u32x4 x0 = ax[j & 1][0], x1 = ax[j & 1][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
+                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
+                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
+                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
+            }
+            if (j + 2 < 8) load_aux(j + 2, ax[j & 1]);
+        } else {
+            u32x4 a0, a1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            }
+            store_pair(p.out2, j, a0, a1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+        }
+        u32x4 w0, w1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+        }
+        store_pair(p.out, j, w0, w1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int EPI, int ABL, bool SCRATCH = true, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane, char* scratch) {
     constexpr int TM = 8;
@@ -342,6 +439,9 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
 #pragma unroll
                 for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
+        } else if constexpr (!SCRATCH && BIAS_IN_ACC && !(ABL & (32 | 128)) &&
+                             (EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16)) {
+            wave_tile_epilogue_train<EPI>(p, acc, mw0, nw0, lane);
         } else if constexpr (BF16_OUT) {
             const int nb = nw0 + 16 * qd;
             const bool nb_ok = nb < p.N;
@@ -844,6 +944,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     } while (0)
 
     auto epilogue = [&](int t) {
+        // training epilogues: their 24 row addresses per lane depend on the tile only; without the fence they are computed in front
+        // of the K loop (group B's epilogue sits inside it) and hold 48 registers through it -- the kernel spilled
+        if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16) asm volatile("" : "+s"(t));
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
         wave_tile_epilogue<EPI, ABL, false, BF16_OUT>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
@@ -853,6 +956,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
         if constexpr (BF16_OUT) {
             int tm_, tn_;
             tile_coords(p, t, tm_, tn_);
+            // (Scalar-cache loads of the bias -- four s_load_dwordx16, no vmcnt(0) drain of the previous tile's stores in front of the
+            // first accumulator write -- were measured: -0.7 %.  The stall only moves three phases down, to the first operand wait
+            // the in-order vmcnt cannot satisfy before the stores have left.)
             const int nb = tn_ * BN + wn * 64 + 16 * qd;
             if (p.bias && nb < p.N) {
 #pragma unroll

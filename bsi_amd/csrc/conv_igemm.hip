@@ -28,6 +28,7 @@ struct ConvParams {
     int K;                // taps*Cin + Cin2
     int tiles_m, tiles_n;
     int abl;              // experiments (bsi_conv_set_ablation): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 every pixel row out of range, 16 no fragment reads
+    int stagger;          // laboratory (BSI_CONV_STAGGER = sets * 1024 + step): workgroup set (blockIdx / 8) % sets starts set * step * 64 clocks late
     float* gn_part;       // BIAS_RESID_F32_GN: [M/128][N/4][2] = (mean, M2) of every 128-pixel x 4-channel block of the output
 };
 
@@ -102,7 +103,54 @@ __device__ __forceinline__ void film_silu_inplace(const ConvParams& p, f32x4 (&a
 // per wave (NSTORE of the kernels' vmcnt allowances).
 template <bool GN, int TM>
 __device__ __forceinline__ void store_f32_rows(const ConvParams& p, f32x4 (&acc)[4][TM], int mw0, int nb0, int rho, int qd) {
+    if constexpr (GN) asm volatile("" : "+s"(mw0), "+s"(nb0));  // row addresses depend on the tile only: keep them out of the K loop
     const int col = nb0 + 4 * qd;
+    if constexpr (GN) {
+        // The launcher guarantees whole blocks (M % 128 == 0, N % 64 == 0).  With a residual (every ResidualBlock's second
+        // convolution) its rows are fetched TWO row blocks ahead by inline-asm loads with hand-counted waits: through ordinary loads
+        // hipcc waits vmcnt(0) in front of every add (it assumes loads and stores may complete out of order with each other), i.e.
+        // for the store of the previous 64 bytes -- 32 serial memory round trips per wave and tile.  Issue order: L0 L1 | block 0:
+        // wait L0, add, L2, S0 | block 1: wait L1, add, L3, S1 | ... (L, S = 4 instructions each; vmcnt retires in issue order on
+        // this hardware, MI355X_MICROARCH.md).
+        if (mw0 >= p.M) return;
+        // (one loop for both cases, the residual steps under wave-uniform branches: as two separate loops the accumulator array was
+        // merged from two control-flow paths and the kernel spilled 190 registers)
+        const bool has_res = p.resid != nullptr;
+        f32x4 rs[2][4];
+        auto load_res = [&](int j, f32x4 (&d)[4]) {
+            const float* a = p.resid + (size_t)(mw0 + 16 * j + rho) * p.ldo + col;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(a) : "memory");
+        };
+        if (has_res) {
+            load_res(0, rs[0]);
+            load_res(1, rs[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+            transpose_lane_groups(r);
+            if (has_res) {
+                f32x4 (&d)[4] = rs[j & 1];
+                if (j == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+                else if (j == 1 || j == TM - 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[s4][e] += d[s4][e];
+                if (j + 2 < TM) load_res(j + 2, d);
+            }
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)(mw0 + 16 * j + rho) * p.ldo + col;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                *reinterpret_cast<f32x4*>(o + 16 * s4) = r[s4];
+                acc[s4][j] = r[s4];  // the stored values stay in the (dead) accumulators for the statistics below
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         f32x4 r[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
@@ -121,7 +169,6 @@ __device__ __forceinline__ void store_f32_rows(const ConvParams& p, f32x4 (&acc)
                 for (int e = 0; e < 4; ++e) v[e] += rv[e];
             }
             *reinterpret_cast<f32x4*>(o + 16 * s4) = v;
-            if constexpr (GN) acc[s4][j] = v;  // the stored values stay in the (dead) accumulators for the statistics below
         }
     }
     if constexpr (GN) {
@@ -181,6 +228,10 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + wl;
     if (tile >= hi) return;
+    if (p.stagger) {
+        const int n = ((blockIdx.x >> 3) % (p.stagger >> 10)) * (p.stagger & 1023);
+        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);
+    }
     const int nk = p.K / 32;
     const int HW = p.H * p.Wd;
 
@@ -693,6 +744,8 @@ template <int EPI>
 int launch_conv(ConvParams p, hipStream_t s) {
     p.tiles_m = (p.M + C_BM - 1) / C_BM;
     p.abl = g_conv_abl;
+    static const int stag = [] { const char* e = getenv("BSI_CONV_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = (stag >> 10) > 0 ? stag : 0;
     p.tiles_n = (p.N + C_BN - 1) / C_BN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < conv_cus() ? nwg : conv_cus();

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         issue_kv(base, 0);
         issue_q(base);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn0), "+v"(qn1)::"memory");
+    asm volatile("s_waitcnt vmcnt(0) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
     int buf = 0;
     char* scr = lds + P_SCR + wave * 2048;
     while (true) {
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         pr = next;
         buf ^= 1;
         // the next pair's K/V (4 LDS-DMA) and Q fragments (2 loads) are older than this pair's output stores: leave the stores in flight
-        if constexpr (LSE) asm volatile("s_waitcnt vmcnt(3)" : "+v"(qn0), "+v"(qn1)::"memory");
-        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(qn0), "+v"(qn1)::"memory");
+        if constexpr (LSE) asm volatile("s_waitcnt vmcnt(3) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
+        else asm volatile("s_waitcnt vmcnt(2) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
     }
 }
 

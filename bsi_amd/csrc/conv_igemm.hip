@@ -133,9 +133,9 @@ __device__ __forceinline__ void store_f32_rows(const ConvParams& p, f32x4 (&acc)
             transpose_lane_groups(r);
             if (has_res) {
                 f32x4 (&d)[4] = rs[j & 1];
-                if (j == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
-                else if (j == 1 || j == TM - 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+                if (j == 0) asm volatile("s_waitcnt vmcnt(4) ; data of %0 %1 %2 %3" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+                else if (j == 1 || j == TM - 1) asm volatile("s_waitcnt vmcnt(8) ; data of %0 %1 %2 %3" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(12) ; data of %0 %1 %2 %3" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll

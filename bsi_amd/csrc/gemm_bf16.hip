@@ -371,14 +371,15 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
         asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off offset:16 nt"
                      : "=&v"(d[0]), "=&v"(d[1]) : "v"(a) : "memory");
     };
+    // ONE wait statement carries the loaded registers ("+v": their uses cannot move in front of it); the drain of partial blocks is
+    // a separate operand-free statement.  (With the two waits in the arms of an if / else, each with the operands, hipcc merged
+    // the arms' registers by COPYING the loaded registers in front of the wait of one arm -- stale data; tools/check_asm_loads.py
+    // now scans the generated code for any read of an inline-asm load's destination before its wait.)
     auto wait_aux = [&](int j, u32x4 (&d)[2]) {  // operations issued after block j's loads: see the sequence in the loop
-        if (full) {
-            if (j == 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
-            else if (j == 1 || j == 7) asm volatile("s_waitcnt vmcnt(4)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
-        }
+        if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (j == 0) asm volatile("s_waitcnt vmcnt(2) ; data of %0 %1" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+        else if (j == 1 || j == 7) asm volatile("s_waitcnt vmcnt(4) ; data of %0 %1" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) ; data of %0 %1" : "+v"(d[0]), "+v"(d[1]) :: "memory");
     };
     if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
         load_aux(0, ax[0]);

@@ -306,6 +306,41 @@ def test_gemm_epilogues(N, M, Nn, K):
     assert rel_linf(o, ref + pos[torch.arange(M) % tokens].double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,Nn,K", [(512, 256, 256), (1000, 320, 192), (4096 + 40, 1024, 256), (65536, 768, 128), (200, 512, 64)])
+def test_gemm_training_epilogues(N, M, Nn, K):
+    """The two training epilogues of the MLP (dit.py:71-76 forward with the pre-activation saved for autograd; backward of the
+    GELU fused into the fc2 input gradient): BIAS_GELU_DUAL writes bf16(acc + bias) and bf16(gelu(acc + bias)), MUL_GELUGRAD
+    writes bf16((acc + bias) * gelu'(aux)).  Full tiles, ragged M / N tails (the counted-wait and the drain form of the
+    auxiliary-row pipeline) and many tiles per workgroup."""
+    gen = torch.Generator().manual_seed(M + 3 * Nn + K)
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Nn, generator=gen)
+    aux = bf16r(torch.randn((M, Nn), generator=gen) * 1.5)
+    ref = A.double() @ W.double().t() + bias.double()
+    dA, dW, db, dx = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias), dev(aux.to(torch.bfloat16))
+    out = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out2 = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), out2=out2.data_ptr(), M=M, N=Nn, K=K,
+                   lda=K, ldw=K, ldo=Nn, epilogue=N.EPI_BIAS_GELU_DUAL)
+    N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+    assert float(((out2.cpu().double() - ref).abs() / (ref.abs() + 1e-2)).max()) < 5e-3
+    # the activation is applied to the fp32 value, not to the rounded pre-activation
+    assert rel_linf(out.cpu().float(), do.gelu_tanh(ref)) < 5e-3
+    x = aux.double().requires_grad_(True)
+    do.gelu_tanh(x).sum().backward()
+    want = ref * x.grad
+    out.fill_(float("nan"))
+    a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), aux=dx.data_ptr(), M=M, N=Nn, K=K,
+                   lda=K, ldw=K, ldo=Nn, epilogue=N.EPI_MUL_GELUGRAD_BF16)
+    N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+    assert rel_linf(out.cpu().float(), want) < 5e-3, rel_linf(out.cpu().float(), want)
+    # and twice the same bits (no data race on the wait counts)
+    first = out.clone()
+    N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+    assert torch.equal(first.view(torch.int16), out.view(torch.int16))
+
+
 @pytest.mark.parametrize("epi_name", ["bias", "gelu"])
 def test_gemm_persistent_tile_handover_full_size(N, epi_name):
     """768 tiles on 256 CUs: every persistent workgroup walks 3 tiles, so the DMA ring, the epilogue's store allowance and the

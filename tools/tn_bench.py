@@ -23,7 +23,10 @@ for name, Nn, K in SHAPES:
     cs = torch.empty(Nn, device=dev)
     ws = torch.empty(lib.bsi_gemm_tn_workspace_bytes(M, Nn, K), dtype=torch.uint8, device=dev)
     def run():
-        N.check(lib.bsi_gemm_tn_bias_bf16(N.ptr(dY), Nn, N.ptr(X), K, M, Nn, K, N.ptr(out), K, N.ptr(cs), 0, N.ptr(ws), N.stream()))
+        if os.environ.get("NOBIAS"):
+            N.check(lib.bsi_gemm_tn_bf16(N.ptr(dY), Nn, N.ptr(X), K, M, Nn, K, N.ptr(out), K, 0, N.ptr(ws), N.stream()))
+        else:
+            N.check(lib.bsi_gemm_tn_bias_bf16(N.ptr(dY), Nn, N.ptr(X), K, M, Nn, K, N.ptr(out), K, N.ptr(cs), 0, N.ptr(ws), N.stream()))
     run(); run()
     torch.cuda.synchronize()
     ref = dY[:4096].float().t() @ X[:4096].float()
@@ -39,4 +42,4 @@ for name, Nn, K in SHAPES:
     ms.sort()
     flops = 2.0 * M * Nn * K
     print(f"{name:4s} M={M} N={Nn} K={K}: med {flops / ms[len(ms) // 2] / 1e9:7.0f} TF (best {flops / ms[0] / 1e9:6.0f})  {ms[len(ms) // 2] * 1e3:8.1f} us"
-          f"  checksum {float(out.double().abs().sum()):.6e}  ABL={os.environ.get('BSI_TN_ABL', '0')}", flush=True)
+          f"  checksum {float(out.double().abs().sum()):.6e}  ABL={os.environ.get('BSI_TN_ABL', '0')} NOBIAS={os.environ.get('NOBIAS', '')}", flush=True)

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
             for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
     };
     auto epilogue = [&](int t) {
+        asm volatile("" : "+s"(t));  // keeps the tile-dependent row addresses out of the K loop (see the slab kernel)
         const int mw0 = (t / p.tiles_n) * C_BM + (wm * 2 + wmm) * 128, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
         if (nb0 >= p.N || (p.abl & 4)) return;  // wave-uniform: the lane-group exchanges below need every lane
         if constexpr (BF16_OUT) {
@@ -572,6 +573,9 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
             for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
     };
     auto epilogue = [&](int t) {
+        // fence: the epilogue's row addresses (16 per lane) depend on the tile only; group B's epilogue sits inside the tap loop, and
+        // without the fence they are computed in front of it and live -- spilled -- through it
+        asm volatile("" : "+s"(t));
         const int mw0 = (t / p.tiles_n) * C_BM + wrow0, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
         if (nb0 >= p.N) return;
         if constexpr (BF16_OUT) {

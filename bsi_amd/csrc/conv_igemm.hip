@@ -759,15 +759,18 @@ int launch_conv(ConvParams p, hipStream_t s) {
         // lost its run-time issue bookkeeping and its spilled border masks):
         //   bias -> bf16:                 slab 89 us (128 -> 128), 133 us (256 -> 128), 208 us (128 -> 384), 175 us (384 -> 128);
         //                                 ring 102 / 175 / 235 / 252 us
-        //   FiLM + SiLU -> bf16 (conv1):  slab (the ring kernel's FiLM instance spills inside its K loop: 230 us average)
+        //   FiLM + SiLU -> bf16 (conv1):  slab (the ring kernel's FiLM instance spilled inside its K loop: 230 us average)
         //   bias + residual -> fp32 (+ GroupNorm partials, conv2): ring 141-143 us, slab 148 us (128 -> 128)
+        // Re-measured once no instance spilled any more (the tile fence of the epilogues; UNet sampling, 512 images, k = 16): fp32
+        // epilogues on the slab kernel 815 images/s against 772 on the ring kernel, FiLM on the ring kernel 670 -- everything that
+        // can runs the slab kernel now.
         // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
-        // 1024 / 2048 = ring kernel for the fp32 / FiLM epilogues, 4096 = slab kernel for the fp32 epilogues.
+        // 2048 / 4096 = ring kernel for the FiLM / fp32 epilogues.
         const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
         constexpr bool F32 = (EPI == CEPI_BIAS_RESID_F32 || EPI == CEPI_BIAS_RESID_F32_GN);
         const bool want = (g_conv_abl & 512) ? true
                           : (g_conv_abl & 256) ? false
-                          : F32 ? (g_conv_abl & 4096) != 0
+                          : F32 ? !(g_conv_abl & 4096)
                           : EPI == CEPI_FILM_SILU_BF16 ? !(g_conv_abl & 2048)
                                                        : true;
         if (can && want) return launch_conv_slab<EPI>(p, grid, s);

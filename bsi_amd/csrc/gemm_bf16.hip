@@ -674,6 +674,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     } while (0)
 
     auto epilogue = [&](int t) {
+        asm volatile("" : "+s"(t));  // the epilogue's row addresses depend on the tile only: keep them out of the K loop (spills)
         int tm_, tn_;
         if (p.splits > 1) {  // partial sums of split sp go to its slab
             const int sp = t / tiles_mn;
@@ -945,9 +946,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     } while (0)
 
     auto epilogue = [&](int t) {
-        // training epilogues: their 24 row addresses per lane depend on the tile only; without the fence they are computed in front
-        // of the K loop (group B's epilogue sits inside it) and hold 48 registers through it -- the kernel spilled
-        if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16) asm volatile("" : "+s"(t));
+        // the epilogue's row addresses (16-24 per lane) depend on the tile only; without the fence they are computed in front of the K
+        // loop (group B's epilogue sits inside it) and hold up to 48 registers through it -- the training instances spilled
+        asm volatile("" : "+s"(t));
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
         wave_tile_epilogue<EPI, ABL, false, BF16_OUT>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);

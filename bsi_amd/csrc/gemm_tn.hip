@@ -26,6 +26,7 @@ struct TnParams {
     float* colsum;       // optional: [splits][colsum_stride] column sums of P (bias gradient), written by the k-tile-0 workgroups
     size_t colsum_stride;
     int xcd_map;         // XCD-aware workgroup order (off: BSI_TN_ABL & 1)
+    int abl;             // laboratory (BSI_TN_ABL): 2 = no operand DMA after the prologue, 4 = fragment reads only in the first stage, 8 = no MFMAs
 };
 
 constexpr int T_RB = 512;                 // bytes per LDS row (256 bf16 columns)
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 
     int slot = 0, pslot = T_D;
     for (int v = 0; v < nk; ++v) {
-        load_frags(lds + slot * T_SLOT);
-        if (v + T_D < nk) {
+        if (!(p.abl & 4) || v == 0) load_frags(lds + slot * T_SLOT);
+        if (v + T_D < nk && !(p.abl & 2)) {
             stage(v + T_D, pslot);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T_D - 1)) : "memory");
         } else {
@@ -194,11 +195,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
         }
         TN_BARRIER();
         __builtin_amdgcn_s_setprio(1);
+        if (!(p.abl & 8)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         if (do_colsum) {
             const bf16x8 b0 = wk == 0 ? bf[0] : wk == 1 ? bf[2] : wk == 2 ? bf[4] : bf[6];
             const bf16x8 b1 = wk == 0 ? bf[1] : wk == 1 ? bf[3] : wk == 2 ? bf[5] : bf[7];
@@ -475,6 +478,7 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
     }
     static const int abl = [] { const char* e = getenv("BSI_TN_ABL"); return e ? atoi(e) : 0; }();
     p.xcd_map = !(abl & 1);
+    p.abl = abl;
     set_max_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T_R * T_SLOT);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");

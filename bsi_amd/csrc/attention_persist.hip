@@ -187,8 +187,8 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
                     pf[4 + r] = (__bf16)s[2 * kb + 1][r];
                 }
                 // in-order LDS returns: this block's 8 reads are complete once at most the 8 younger ones are outstanding
-                if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(va[slot][0]), "+v"(va[slot][1]), "+v"(va[slot][2]), "+v"(va[slot][3]), "+v"(vb[slot][0]), "+v"(vb[slot][1]), "+v"(vb[slot][2]), "+v"(vb[slot][3]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[slot][0]), "+v"(va[slot][1]), "+v"(va[slot][2]), "+v"(va[slot][3]), "+v"(vb[slot][0]), "+v"(vb[slot][1]), "+v"(vb[slot][2]), "+v"(vb[slot][3]));
+                if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(8) ; data of %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(va[slot][0]), "+v"(va[slot][1]), "+v"(va[slot][2]), "+v"(va[slot][3]), "+v"(vb[slot][0]), "+v"(vb[slot][1]), "+v"(vb[slot][2]), "+v"(vb[slot][3]));
+                else asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(va[slot][0]), "+v"(va[slot][1]), "+v"(va[slot][2]), "+v"(va[slot][3]), "+v"(vb[slot][0]), "+v"(vb[slot][1]), "+v"(vb[slot][2]), "+v"(vb[slot][3]));
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     union { bf16x8 v; s16x4 hh[2]; } vf;

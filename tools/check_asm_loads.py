@@ -53,11 +53,20 @@ def blocks_of(func):
             continue
         if in_asm:
             if code.startswith(("global_load", "buffer_load")) and " lds" not in code:
-                cur[1].append((ln, "load", regs_of(code.split(",")[0])))
+                cur[1].append((ln, "load", (regs_of(code.split(",")[0]), "vm")))
+            elif code.startswith("ds_read"):  # inline-asm LDS reads (transposed reads the compiler must not wait vmcnt(0) for)
+                cur[1].append((ln, "load", (regs_of(code.split(",")[0]), "lgkm")))
             elif code.startswith("s_waitcnt") and "; data of" in code:
                 cur[1].append((ln, "wait", (regs_of(code.split("; data of")[1]), code)))
+            elif code.startswith("s_waitcnt") and ("vmcnt(0)" in code or "lgkmcnt(0)" in code):
+                cur[1].append((ln, "drain", "vm" if "vmcnt(0)" in code else "lgkm"))
             continue
         body = code.split(";")[0].strip()
+        if body.startswith("s_waitcnt"):  # a full drain the compiler wrote is as good as one of ours
+            for cnt, kind in (("vmcnt(0)", "vm"), ("lgkmcnt(0)", "lgkm")):
+                if cnt in body:
+                    cur[1].append((ln, "drain", kind))
+            continue
         m = BRANCH.match(body)
         if m:
             cur[1].append((ln, "branch", (m.group(1), m.group(2))))
@@ -98,16 +107,20 @@ def check(asm_text):
         # Two forward analyses over the blocks.  MUST (intersection at joins): registers an inline-asm load is still writing on
         # EVERY path into a block -- an instruction that touches one of them is a bug (the conditions of `if (has_res) load` ...
         # `if (has_res) wait` are correlated, a union at the joins would report the infeasible load-without-wait path).  MAY (union):
-        # only to check that a wait statement names registers some load actually wrote (hipcc copied them otherwise).
+        # kept for symmetry; a wait statement must name registers that SOME inline-asm load of the function writes (hipcc copied them
+        # otherwise).
         def transfer(i, pend, report, may):
             pend = dict(pend)
             for ln, kind, payload in blocks[i][1]:
                 if kind == "load":
-                    for r in payload:
-                        pend[r] = ln
+                    for r in payload[0]:
+                        pend[r] = (ln, payload[1])
+                elif kind == "drain":
+                    for r in [r for r, (_, k) in pend.items() if k == payload]:
+                        del pend[r]
                 elif kind == "wait":
                     named, code = payload
-                    if report and may and any(r not in pend for r in named):
+                    if report and may and any(r not in ever_loaded for r in named):
                         problems.append(f"{name}: line {ln}: wait names registers no inline-asm load writes (copied?): {code}")
                     for r in named:
                         pend.pop(r, None)
@@ -115,9 +128,14 @@ def check(asm_text):
                     hit = payload[0] & set(pend)
                     if hit:
                         r = sorted(hit)[0]
-                        problems.append(f"{name}: line {ln}: `{payload[1]}` touches v{r} (inline-asm load at line {pend[r]}) before its wait")
+                        problems.append(f"{name}: line {ln}: `{payload[1]}` touches v{r} (inline-asm load at line {pend[r][0]}) before its wait")
             return pend
 
+        ever_loaded = set()
+        for b in blocks:
+            for _, kind, payload in b[1]:
+                if kind == "load":
+                    ever_loaded |= payload[0]
         pred = [set() for _ in blocks]
         for i in range(len(blocks)):
             for j in succ[i]:
@@ -139,7 +157,7 @@ def check(asm_text):
                         for o in known:
                             new_in.update(o)
                     else:
-                        new_in = {r: ln for r, ln in known[0].items() if all(r in o for o in known[1:])}
+                        new_in = {r: v for r, v in known[0].items() if all(r in o for o in known[1:])}
                     new_out = transfer(i, new_in, False, may)
                     if out[i] is None or set(new_out) != set(out[i]) or set(new_in) != set(inn[i]):
                         out[i], inn[i] = new_out, new_in

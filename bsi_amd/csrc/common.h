@@ -124,8 +124,20 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2*sqrt(2/pi)*log2(e)
     const float b = a * 0.044715f;
     const float x2 = x * x;
-    const float e = __builtin_amdgcn_exp2f(x * (a + b * x2));
+    const float e = __builtin_amdgcn_exp2f(x * __fmaf_rn(b, x2, a));
     return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// The same arithmetic on two values at once (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: five packed instructions per pair instead
+// of six scalar ones per value; the two transcendentals stay scalar).  Bit-identical to gelu_tanh_f per element.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ gelu_tanh_f2(f32x2_ x) {
+    const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float b = a * 0.044715f;
+    const f32x2_ x2 = x * x;
+    const f32x2_ t = __builtin_elementwise_fma(x2, f32x2_{b, b}, f32x2_{a, a});
+    const f32x2_ arg = x * t;
+    const f32x2_ d = f32x2_{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + f32x2_{1.0f, 1.0f};
+    return x * f32x2_{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
 // d/dx of the tanh-GELU: with s = sigmoid(2u), u = k0*(x + k1 x^3):  gelu = x*s,  gelu' = s + x*s*(1-s)*2*k0*(1+3*k1*x^2)
@@ -133,9 +145,20 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     const float a = -2.0f * k0 * 1.4426950408889634f;
     const float x2 = x * x;
-    const float e = __builtin_amdgcn_exp2f(x * (a + a * k1 * x2));
+    const float e = __builtin_amdgcn_exp2f(x * __fmaf_rn(a * k1, x2, a));
     const float s = __builtin_amdgcn_rcpf(1.0f + e);
-    return s + x * s * (1.0f - s) * (2.0f * k0) * (1.0f + 3.0f * k1 * x2);
+    return __fmaf_rn((x * s) * (1.0f - s), __fmaf_rn(6.0f * k0 * k1, x2, 2.0f * k0), s);
+}
+// two values at once, bit-identical per element (see gelu_tanh_f2)
+__device__ __forceinline__ f32x2_ gelu_tanh_grad_f2(f32x2_ x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float a = -2.0f * k0 * 1.4426950408889634f;
+    const f32x2_ x2 = x * x;
+    const f32x2_ arg = x * __builtin_elementwise_fma(x2, f32x2_{a * k1, a * k1}, f32x2_{a, a});
+    const f32x2_ d = f32x2_{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + f32x2_{1.0f, 1.0f};
+    const f32x2_ s = f32x2_{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2_ w = __builtin_elementwise_fma(x2, f32x2_{6.0f * k0 * k1, 6.0f * k0 * k1}, f32x2_{2.0f * k0, 2.0f * k0});
+    return __builtin_elementwise_fma((x * s) * (f32x2_{1.0f, 1.0f} - s), w, s);
 }
 
 // 4 x 4 transpose of r[0..3] across the four 16-lane groups of a wave: afterwards lane group g holds in r[s] what lane group s

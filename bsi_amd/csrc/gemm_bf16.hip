@@ -397,11 +397,12 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
             wait_aux(j, ax[j & 1]);
             const u32x4 x0 = ax[j & 1][0], x1 = ax[j & 1][1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
-                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
-                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
-                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
+            for (int e = 0; e < 4; ++e) {  // packed arithmetic: a dword of the auxiliary row = two neighbouring columns
+                const f32x2_ g0 = gelu_tanh_grad_f2(f32x2_{__uint_as_float(x0[e] << 16), __uint_as_float(x0[e] & 0xffff0000u)});
+                const f32x2_ g1 = gelu_tanh_grad_f2(f32x2_{__uint_as_float(x1[e] << 16), __uint_as_float(x1[e] & 0xffff0000u)});
+                const f32x2_ p0 = f32x2_{v[2 * e], v[2 * e + 1]} * g0, p1 = f32x2_{v[8 + 2 * e], v[8 + 2 * e + 1]} * g1;
+                v[2 * e] = p0[0]; v[2 * e + 1] = p0[1];
+                v[8 + 2 * e] = p1[0]; v[8 + 2 * e + 1] = p1[1];
             }
             if (j + 2 < 8) load_aux(j + 2, ax[j & 1]);
         } else {
@@ -413,7 +414,11 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
             }
             store_pair(p.out2, j, a0, a1);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2_ g = gelu_tanh_f2(f32x2_{v[e], v[e + 1]});
+                v[e] = g[0];
+                v[e + 1] = g[1];
+            }
         }
         u32x4 w0, w1;
 #pragma unroll
@@ -495,7 +500,11 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
                     }
                     if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+                        for (int e = 0; e < 16; e += 2) {  // packed: 2.5 instead of 6 vector-ALU instructions per value
+                            const f32x2_ g = gelu_tanh_f2(f32x2_{v[e], v[e + 1]});
+                            v[e] = g[0];
+                            v[e + 1] = g[1];
+                        }
                     } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);

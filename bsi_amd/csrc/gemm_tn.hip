@@ -122,11 +122,23 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4], bf[8];
-    // fused bias gradient: column sums of the P tile = one extra MFMA with an all-ones A operand; wave wk takes the
-    // column tiles 2wk and 2wk+1 of its P half, workgroups of k-tile 0 only.  (These workgroups run 34 MFMAs per stage instead of
-    // 32 and the launch waits for them: fc1 1068 -> 978 us without the bias gradient.  Adding the fragments on the vector ALU
-    // instead -- 32 unpack + 32 add instructions per stage -- was measured: 1055 us, no better; a separate pass over dY costs more.)
-    const bool do_colsum = p.colsum != nullptr && tile_k == 0;
+    // fused bias gradient: column sums of the P tile = one extra MFMA with an all-ones A operand per 16-column unit.  The 16 units of
+    // an n tile are dealt out over the workgroups that share it (k tiles 0 .. min(tiles_k, 16) - 1) and, inside a workgroup, over the
+    // four waves of the group that holds the unit's fragments: at most one extra MFMA per wave and stage for tiles_k >= 2 (two when a
+    // single workgroup owns the n tile).  With all 16 units in the k-tile-0 workgroups those ran 34 MFMAs per stage against 32
+    // everywhere else, and the launch waits for its slowest workgroup: fc1 1068 -> 978 us without the bias gradient.  (Adding the
+    // fragments on the vector ALU instead -- 32 unpack + 32 add instructions per stage -- was measured: 1055 us, no better.)
+    int cs_j[2] = {-1, -1};  // this wave's units (fragment index j of its P half), wave-uniform
+    if (p.colsum != nullptr) {
+        const int cs = p.tiles_k < 16 ? p.tiles_k : 16;
+        int seen = 0;
+        for (int j = 0; j < 8; ++j) {
+            if ((8 * wg + j) % cs != tile_k) continue;
+            if ((seen & 3) == wk) cs_j[seen >> 2] = j;
+            ++seen;
+        }
+    }
+    const bool do_colsum = cs_j[0] >= 0;
     f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
 #define TN_BARRIER()                             \
@@ -202,11 +214,14 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
             for (int i = 0; i < 4; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (do_colsum) {
-            const bf16x8 b0 = wk == 0 ? bf[0] : wk == 1 ? bf[2] : wk == 2 ? bf[4] : bf[6];
-            const bf16x8 b1 = wk == 0 ? bf[1] : wk == 1 ? bf[3] : wk == 2 ? bf[5] : bf[7];
-            accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, b0, accb[0], 0, 0, 0);
-            accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, b1, accb[1], 0, 0, 0);
+        if (do_colsum) {  // wave-uniform unit indices: branches, not register selects
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (cs_j[u] < 0) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cs_j[u] == j) accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bf[j], accb[u], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         TN_BARRIER();
@@ -219,9 +234,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 
     if (do_colsum && lane < 16) {  // D row 0 (lanes 0..15, register 0) holds the column sums
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int n = n0 + 128 * wg + 16 * (2 * wk + jj) + lane;
-            if (n < p.N) p.colsum[(size_t)split * p.colsum_stride + n] = accb[jj][0];
+        for (int u = 0; u < 2; ++u) {
+            if (cs_j[u] < 0) continue;
+            const int n = n0 + 128 * wg + 16 * cs_j[u] + lane;
+            if (n < p.N) p.colsum[(size_t)split * p.colsum_stride + n] = accb[u][0];
         }
     }
     // D rows = k (4*(lane>>4) + reg inside A tile i), D cols = n (lane & 15 inside B tile j)

@@ -135,6 +135,8 @@ _PROTOS = {
     "bsi_refine_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_refine_step_philox": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_philox_normal": (_i, [_vp, C.c_uint, _sz, _vp, _vp]),
+    "bsi_philox4x32_10": (_i, [_vp, _sz, _vp, _vp]),
+    "bsi_philox_uint32": (_i, [_vp, C.c_uint, _sz, _vp, _vp]),
     "bsi_sqerr_rows": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "bsi_sqerr_rows_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "bsi_recon_nll": (_i, [_vp, _vp, _f, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp]),

@@ -203,6 +203,27 @@ __global__ void philox_normal_kernel(const unsigned long long* __restrict__ seed
         reinterpret_cast<f32x4*>(out)[i] = philox_normal4(sd, i, stream_id);
 }
 
+// Known-answer access to the generator: raw Philox4x32-10 blocks for caller-given (counter, key) pairs, and the integer stream
+// (before Box-Muller) in the library's counter / key layout.  Both run the device function the fused step uses.
+__global__ void philox_blocks_kernel(const unsigned* __restrict__ ctr_key, size_t nblocks, unsigned* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned* c = ctr_key + 6 * i;
+        unsigned x[4];
+        philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5], x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = x[k];
+    }
+}
+__global__ void philox_uint32_kernel(const unsigned long long* __restrict__ seed, unsigned stream_id, size_t n4,
+                                     unsigned* __restrict__ out) {
+    const unsigned long long sd = seed[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x[4];
+        philox4x32_10((unsigned)i, (unsigned)(i >> 32), stream_id, 0x42534931u, (unsigned)sd, (unsigned)(sd >> 32), x);
+        reinterpret_cast<u32x4*>(out)[i] = u32x4{x[0], x[1], x[2], x[3]};
+    }
+}
+
 // bsi.py:331-335: the fused measure/refine step.  Algorithmic traffic: read mu, f, eps + write mu' = 16 B/elt (12 with PHILOX).
 template <bool PHILOX>
 __global__ void refine_step_kernel(const float* __restrict__ mu, const float* __restrict__ f,
@@ -463,6 +484,24 @@ extern "C" int bsi_philox_normal(const unsigned long long* seed, unsigned stream
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(TPB), 0, S(stream), seed, stream_id, n / 4, out);
     BSI_CHECK_LAUNCH("bsi_philox_normal");
+    return BSI_OK;
+}
+
+extern "C" int bsi_philox4x32_10(const unsigned* ctr_key, size_t nblocks, unsigned* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(ctr_key && out && nblocks > 0, "bsi_philox4x32_10: bad args");
+    int grid = blocks_for(nblocks);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(philox_blocks_kernel, dim3(grid), dim3(TPB), 0, S(stream), ctr_key, nblocks, out);
+    BSI_CHECK_LAUNCH("bsi_philox4x32_10");
+    return BSI_OK;
+}
+
+extern "C" int bsi_philox_uint32(const unsigned long long* seed, unsigned stream_id, size_t n, unsigned* out, bsi_stream_t stream) {
+    BSI_CHECK_ARG(seed && out && n > 0 && n % 4 == 0, "bsi_philox_uint32: bad args (n must be a multiple of 4)");
+    int grid = blocks_for(n / 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(philox_uint32_kernel, dim3(grid), dim3(TPB), 0, S(stream), seed, stream_id, n / 4, out);
+    BSI_CHECK_LAUNCH("bsi_philox_uint32");
     return BSI_OK;
 }
 

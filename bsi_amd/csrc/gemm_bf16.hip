@@ -47,21 +47,32 @@ struct GemmParams {
     int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
     int groups, group_delay;  // k64r kernel: phase groups per XCD and their start offset (units of 64 clocks), see the kernel
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
+    int ng;       // n-tiles per group of the tile order (0: all), see tile_coords
     // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
     // split s multiplies the K range [s*kslice, (s+1)*kslice) and writes its partial sums to out + s*slab_stride floats
     int splits, kslice;
     size_t slab_stride;
 };
 
-// tile index (n-fastest order when gm == 1) -> (tm, tn).  Inside an XCD 32 consecutive tiles run together; with
-// bands of gm m-tiles they form a gm x (32/gm) block, so an A panel is shared by 32/gm CUs and a W panel by gm.
+// tile index -> (tm, tn).  The n-tiles are cut into groups of p.ng (0 = one group of all tiles_n); inside a group the tiles are
+// walked in bands of gm m-tiles, m fastest inside a band.  An XCD runs 32 consecutive tiles together: with one group (ng = 0)
+// they form a gm x (32/gm) block that moves along n and then down the bands; with ng = 32/gm they form one band, the XCD keeps
+// its ng weight panels from round to round (n-stationary) and only the activation panels stream.
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm, int& tn) {
-    const int band_tiles = p.gm * p.tiles_n;
+    int ncols = p.tiles_n, n_first = 0;
+    if (p.ng > 0 && p.ng < p.tiles_n) {
+        const int group_tiles = p.tiles_m * p.ng;
+        const int gidx = t / group_tiles;  // the last group may be narrower
+        n_first = gidx * p.ng;
+        t -= gidx * group_tiles;
+        ncols = min(p.ng, p.tiles_n - n_first);
+    }
+    const int band_tiles = p.gm * ncols;
     const int band = t / band_tiles;
     const int r = t - band * band_tiles;
     const int rows = min(p.gm, p.tiles_m - band * p.gm);  // last band may be short
     tm = band * p.gm + r % rows;
-    tn = r / rows;
+    tn = n_first + r / rows;
 }
 
 template <int EPI>
@@ -879,6 +890,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     int tile = lo + wl;
     if (tile >= hi) return;
     const int nk = p.K / 64;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (ABL & 64) {  // laboratory builds: shader clock over the kernel = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        clk0 = __builtin_readcyclecounter();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // laboratory (ABL & 131072): static priority for the second-dispatched wave group instead of a flip around every MFMA phase
+    constexpr bool STATIC_PRIO = (ABL & 131072) != 0;
+    if constexpr (STATIC_PRIO) {
+        if (wm == 1) __builtin_amdgcn_s_setprio(1);
+    }
 
     // ---- issue stream: half-stages in the order A(0) W(0) A(1) W(1) ... over this workgroup's tiles
     const int srow = lane >> 3, spos = lane & 7;
@@ -1048,13 +1069,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
                 // ---- C(v, ks)
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr (!STATIC_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (!STATIC_PRIO) __builtin_amdgcn_s_setprio(0);
                 if (ks == 1 && v == nk - 1 && wm == 1) {  // group B: before the barrier that ends its last C phase
                     if constexpr (!(ABL & 1)) { pre_status = issue_next(); pre = true; }
                     epilogue(tile);
@@ -1078,6 +1099,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     }
     if constexpr (REGULAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus loads land before the LDS is released
     if (wm == 0) PHASE_BARRIER();
+    if constexpr (ABL & 64) {
+        if (tid == 0) {  // one (cycles, 100 MHz ticks) pair per workgroup
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out2) + 2 * blockIdx.x;
+            o[0] = __builtin_readcyclecounter() - clk0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+    }
 #undef PHASE_BARRIER
 }
 

@@ -105,6 +105,14 @@ int bsi_refine_step_philox(const float* mu, const float* f, const unsigned long 
                            const float* alpha, const float* c_skip, const float* c_out, int i, int f_is_xhat, int rows, int D,
                            float* x_hat_out, float* y_out, float* mu_next, bsi_stream_t stream);
 int bsi_philox_normal(const unsigned long long* seed, unsigned stream_id, size_t n, float* out, bsi_stream_t stream);
+/* Known-answer access to that generator (it replaces ATen's generator behind torch.randn, bsi.py:325,332-334, so the reference
+ * holds no vectors for it; the published ones are Random123's, tests/golden/philox_kat.json).
+ * bsi_philox4x32_10: out[4b .. 4b+3] = Philox4x32-10(counter = ctr_key[6b .. 6b+3], key = ctr_key[6b+4 .. 6b+5]).
+ * bsi_philox_uint32: the integer stream behind bsi_philox_normal: out[4g .. 4g+3] = Philox4x32-10(counter = (g & 0xffffffff,
+ * g >> 32, stream_id, 0x42534931), key = (seed & 0xffffffff, seed >> 32)); the normals are Box-Muller on the top 24 bits:
+ * u1 = ((x0 >> 8) + 1) / 2^24, u2 = (x1 >> 8) / 2^24 -> sqrt(-2 ln u1) * (cos, sin)(2 pi u2), likewise (x2, x3). */
+int bsi_philox4x32_10(const unsigned* ctr_key, size_t nblocks, unsigned* out, bsi_stream_t stream);
+int bsi_philox_uint32(const unsigned long long* seed, unsigned stream_id, size_t n, unsigned* out, bsi_stream_t stream);
 
 /* bsi.py:309-310, 273-274, 288-289: out[r] = w[r] * scale * reduce_D((x[r % B] - x_hat[r])^2),
  * reduce = mean if mean != 0 else sum.  diff_out (nullable) receives x - x_hat for the backward. */

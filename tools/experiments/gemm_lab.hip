@@ -128,8 +128,8 @@ static void dma_bench() {
 }
 
 template <int EPI, int ABL>
-float time_k64r(GemmParams p, int iters, int gm = 4, int grid = 256, int groups = 0, int group_delay = 0) {
-    p.groups = groups; p.group_delay = group_delay;
+float time_k64r(GemmParams p, int iters, int gm = 4, int grid = 256, int groups = 0, int group_delay = 0, int ng = 0) {
+    p.groups = groups; p.group_delay = group_delay; p.ng = ng;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = gm;
@@ -194,6 +194,53 @@ int main() {
                            fl / ms / 1e9, 100.0 * hc[0] / hc[1]);
                 }
             }
+            continue;
+        }
+        if (getenv("LAB_NS")) {
+            // round 3: n-stationary tile order (an XCD keeps ng weight panels across rounds) x band height x skewed phase groups
+            // that share those panels, static priority, and the shader clock of the production schedule on 256 / 64 CUs
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            const int tiles_per_wg = ((M + 255) / 256) * ((sh.N + 255) / 256) / 256;
+            unsigned long long* dC; hipMalloc(&dC, 2 * 256 * 8);
+            for (int r = 0; r < 2; ++r) {
+                const float t1 = time_k64r<E, 0>(p, 20);
+                rep("band order gm 4 (production)", t1);
+                const double period64 = (double)t1 * 1e-3 / tiles_per_wg * 1.7e9 / 64.0;  // tile period, units of 64 clocks at ~1.7 GHz
+                rep("static priority for waves 4-7", time_k64r<E, 131072>(p, 20));
+                rep("ns ng 4 gm 8", time_k64r<E, 0>(p, 20, 8, 256, 0, 0, 4));
+                rep("ns ng 4 gm 8, wb stores", time_k64r<E, 32>(p, 20, 8, 256, 0, 0, 4));
+                rep("ns ng 4 gm 8, A nt", time_k64r<E, 2048>(p, 20, 8, 256, 0, 0, 4));
+                rep("ns ng 2 gm 16", time_k64r<E, 0>(p, 20, 16, 256, 0, 0, 2));
+                rep("ns ng 8 gm 4", time_k64r<E, 0>(p, 20, 4, 256, 0, 0, 8));
+                for (int ngr : {2, 4})
+                    for (double frac : {0.0, 1.0}) {
+                        const int d = (int)(frac * period64 / ngr);
+                        char nm[96];
+                        snprintf(nm, sizeof nm, "ns ng 4 gm %d, %d groups, delay %.1f", 8 / ngr, ngr, frac);
+                        rep(nm, time_k64r<E, 0>(p, 20, 8 / ngr, 256, ngr, d, 4));
+                    }
+                if (sh.N == 4096) {
+                    rep("gelu band order (production)", time_k64r<G, 0>(p, 20));
+                    rep("gelu static priority", time_k64r<G, 131072>(p, 20));
+                    rep("gelu ns ng 4 gm 8", time_k64r<G, 0>(p, 20, 8, 256, 0, 0, 4));
+                    rep("gelu ns ng 4 gm 2, 4 groups, delay 1.0", time_k64r<G, 0>(p, 20, 2, 256, 4, (int)(period64 / 4), 4));
+                    rep("gelu ns ng 4 gm 4, 2 groups, delay 1.0", time_k64r<G, 0>(p, 20, 4, 256, 2, (int)(period64 / 2), 4));
+                }
+            }
+            for (int ncu : {256, 64}) {  // shader clock of the production schedule (stamps in a laboratory instance only)
+                GemmParams q = p;
+                q.M = 256 * ncu; q.out2 = dC;
+                for (int abl : {0, 1}) {
+                    const float ms = abl ? time_k64r<E, 64 | 1 | 4>(q, 50, 4, ncu) : time_k64r<E, 64>(q, 50, 4, ncu);
+                    unsigned long long hc[512];
+                    hipMemcpy(hc, dC, 2 * ncu * 8, hipMemcpyDeviceToHost);
+                    double mn = 1e9, mx = 0, sum = 0;
+                    for (int i = 0; i < ncu; ++i) { const double c = 100.0 * hc[2 * i] / hc[2 * i + 1]; mn = c < mn ? c : mn; mx = c > mx ? c : mx; sum += c; }
+                    printf("%s %3d CUs %-22s %8.3f ms %8.0f TF-equivalent of 256 CUs, shader clock %.0f MHz (min %.0f, max %.0f)\n", sh.name, ncu,
+                           abl ? "MFMA + fragment reads" : "full kernel", ms, 2.0 * q.M * sh.N * sh.K / ms / 1e9 * 256 / ncu, sum / ncu, mn, mx);
+                }
+            }
+            hipFree(dC);
             continue;
         }
         if (getenv("LAB_GROUPS")) {

@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="images per GPU per sample() call (512 = eval_batch_size of the reference's configs, SURVEY section 8(d); "
+                         "256 and 64 are reported under `secondary`)")
     ap.add_argument("--k", type=int, default=128, help="sampling steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class time breakdown to stderr")
@@ -60,6 +62,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (UNet, DiT-L/4, ELBO)")
     ap.add_argument("--secondary-budget", type=float, default=150.0,
                     help="seconds the secondary block may use; entries that would not fit are reported as skipped")
+    ap.add_argument("--secondary-only", action="store_true",
+                    help="(internal) run only the secondary block and print its JSON: the main process starts this as a fresh child "
+                         "so that a hang or a GPU fault in a secondary kernel cannot take the measured headline with it")
+    ap.add_argument("--launch-timeout", type=int, default=3600, help="seconds before a self-launched multi-rank run is abandoned")
     return ap.parse_args()
 
 
@@ -106,15 +112,15 @@ def cpu_model():
 
 def cpu_baseline(k, reps=3):
     """CPU oracle (a port of the reference's algorithm, oracle/) on the host cores: 2 complete sampling steps
-    (denoiser evaluation + measure/refine update) + the final prediction at B=4, extrapolated to k+1 evaluations per
+    (denoiser evaluation + measure/refine update) + the final prediction at B=8, extrapolated to k+1 evaluations per
     image.  Protocol of BASELINE.md §4: 1 warm-up run + `reps` timed repetitions, the MEDIAN is reported, with the CPU
-    model and the thread count.  Bounded: (1 + reps) x 3 DiT-L/2 evaluations of 4 images (about 2 TFLOP of fp32 each)."""
+    model and the thread count.  Bounded: (1 + reps) x 3 DiT-L/2 evaluations of 8 images (about 3.9 TFLOP of fp32 each)."""
     from oracle import bsi_oracle as bo
     from oracle import dit_oracle as do
 
     threads = host_threads()
     torch.set_num_threads(threads)
-    shape, B = (3, 32, 32), 4
+    shape, B = (3, 32, 32), 8
     W = do.dit_random_weights(shape, 2, 1024, 24, ff=(6, 8), seed=0)
     f = lambda m, t: do.dit_forward(W, m, t, patch_size=2, dim=1024, depth=24, heads=16, ff=(6, 8))  # noqa: E731
     o = bo.BSIOracle(f, data_shape=shape, k=k)
@@ -166,9 +172,29 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
         torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
         dt = float(tm.item())
     assert torch.isfinite(loss)
+    comm = None
+    if world > 1:
+        # communication breakdown (so that a multi-GPU number comes with a diagnosis): the same steps WITHOUT the gradient
+        # exchange (ranks then train on their shards alone -- measured last, the losses above are from the exchanged steps)
+        n2 = max(1, min(3, a.train_steps))
+        tr.exchange = False
+        tr.train_step(x, g)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            tr.train_step(x, g)
+        barrier()
+        d2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(d2, op=torch.distributed.ReduceOp.MAX)
+        ms_no = 1e3 * float(d2.item()) / n2
+        nbytes = 4 * tr.fp.flat.numel()
+        comm = {"allreduce_bytes": nbytes, "buckets": len(tr.xchg.plan), "ms_per_step_without_exchange": ms_no,
+                "exposed_comm_ms": 1e3 * dt / a.train_steps - ms_no,
+                "ring_busbw_GBps_if_fully_exposed": (2 * (world - 1) / world * nbytes / 1e9) /
+                                                    max(1e-9, (1e3 * dt / a.train_steps - ms_no) * 1e-3)}
     model.eval()
     steps_per_s = a.train_steps / dt
-    return {"metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+all-reduce+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
+    return {"comm": comm, "metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+all-reduce+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
             "value": steps_per_s, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.train_steps, "global_batch": a.train_batch,
             "per_gpu_batch": nb, "images_per_s": steps_per_s * a.train_batch, "scaling": "strong",
             "model_tflops_per_gpu": steps_per_s * a.train_batch * 3 * FWD_GFLOP_PER_IMG / 1e3 / world,
@@ -268,11 +294,48 @@ def secondary_bench(a, bsi, dev, budget_s):
         return {"workload": "ImageNet64 DiT-L/4 (3x64x64) BSI.sample k=256", "images_per_call": b, "value": b / dt,
                 "unit": "images/s", "model_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS}
 
+    def dit_batch(b, **kw):
+        def run():
+            with torch.no_grad():
+                dt, s = timed(lambda: bsi.sample(b, g, **kw), lambda: bsi.sample(b, g, t=t4(b), **kw))
+            assert torch.isfinite(s).all()
+            tf = b / dt * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3
+            return {"workload": f"DiT-L/2 32x32 BSI.sample k={a.k}" + (", Gaussian noise generated in the refine kernel (Philox4x32-10)"
+                                                                       if kw.get("device_noise") else ""),
+                    "images_per_call": b, "value": b / dt, "unit": "images/s", "model_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS}
+        return run
+
     entry("dit_l2_elbo", 10, elbo)
+    entry("dit_l2_sample_256", 12, dit_batch(256))
+    entry("dit_l2_sample_64", 6, dit_batch(64))
+    entry("dit_l2_sample_256_device_noise", 12, dit_batch(256, device_noise=True))
     entry("vdm_unet", 25, unet)
     entry("dit_l4_64x64_k256", 40, dit64)
     out["seconds"] = time.perf_counter() - t_start
     return out
+
+
+def secondary_in_child(a):
+    """Run the secondary block in a FRESH child process (started with subprocess, never an exec of this GPU-initialised
+    process) and return its JSON; a crash, GPU fault or hang of a secondary kernel leaves {"error": ...} in the line while the
+    headline and train results, measured before, are still printed."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-only", "--k", str(a.k), "--secondary-budget", str(a.secondary_budget)]
+    limit = a.secondary_budget + 180.0  # model builds + first-call compilation of the child on top of its own budget
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        try:
+            out, err = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"error": f"secondary block did not finish within {limit:.0f} s (child killed)"}
+        if p.returncode != 0:
+            return {"error": f"secondary child exited with status {p.returncode}", "stderr_tail": err.decode(errors="replace")[-400:]}
+        return json.loads(out.decode().strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def launch_ranks(a):
@@ -293,18 +356,55 @@ def launch_ranks(a):
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # a user's setting wins
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout is drained by a thread while all children are POLLED: when one exits non-zero (bad device, out of memory)
+    # the others would sit in init_process_group / a collective until the RCCL timeout -- terminate them and return its status
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline = time.monotonic() + a.launch_timeout
+    rc = None
+    while rc is None:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = max(abs(c) for c in bad)
+        elif all(c == 0 for c in codes):
+            rc = 0
+        elif time.monotonic() > deadline:
+            print(f"bench.py: ranks did not finish within {a.launch_timeout} s; terminating them", file=sys.stderr)
+            rc = 5
+        else:
+            time.sleep(0.2)
+    for p in procs:  # exact PIDs of the children this process started
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    rd.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return rc
 
 
 def main():
     a = parse()
+    if a.secondary_only:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        from bsi_amd import BSI, Discretization
+        model, shape = build_model(dev)
+        bsi = BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=a.k, preconditioning="edm",
+                  discretization=Discretization.image_8bit()).to(dev)
+        print(json.dumps(secondary_bench(a, bsi, dev, a.secondary_budget)), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -423,7 +523,7 @@ def main():
             line["train"] = train
             rc = 4 if "error" in train else 0
         if world == 1 and not a.no_secondary:
-            line["secondary"] = secondary_bench(a, bsi, dev, a.secondary_budget)
+            line["secondary"] = secondary_in_child(a)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.k)
         print(json.dumps(line), flush=True)

@@ -224,6 +224,9 @@ inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
     if (c.thr < 65536u) c.thr = 65536u;            // dropout ON means at least 2^-16
     c.s0 = bsi_mix32((unsigned)s);
     c.s1 = bsi_mix32((unsigned)(s >> 32) ^ 0x85ebca6bu);
-    c.scale = 1.0f / (1.0f - p);
+    // the survivors' scale follows the QUANTISED probability the kernels apply (thr >> 16 of 65536), so that E[dropout(x)] = x
+    // exactly; p >= 1 is rejected at the entry points (a scale of 1 / 0)
+    if ((c.thr >> 16) > 65535u) c.thr = 65535u << 16;
+    c.scale = 65536.0f / (float)(65536u - (c.thr >> 16));
     return c;
 }

@@ -176,6 +176,7 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
                                      float* out, void* tape_mem, float dropout_p, unsigned long long seed,
                                      bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && mu && t && out && tape_mem && B > 0, "bsi_dit_train_forward: bad args");
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_dit_train_forward: dropout probability %g outside [0, 1)", (double)dropout_p);
     BSI_CHECK_ARG((c_in == nullptr) == (c_skip == nullptr) && (c_in == nullptr) == (c_out == nullptr),
                   "bsi_dit_train_forward: c_in/c_skip/c_out must be given together");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -235,6 +236,7 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
                                 void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && wT && wT->blocks && g && g->blocks && g_out && tape_mem && workspace && B > 0,
                   "bsi_dit_backward: bad args");
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_dit_backward: dropout probability %g outside [0, 1)", (double)dropout_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Dims d = dims_of(cfg, B);
     const int dim = d.dim, M = (int)d.M;

@@ -368,12 +368,14 @@ int bsi_film_silu_bwd_drop(const void* dy, const void* h1, int M, int N, int HW,
 
 extern "C" int bsi_film_silu(const void* h1, int M, int N, int HW, const float* film, int film_rows, int film_stride,
                              float dropout_p, unsigned long long seed, unsigned site, void* y, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_film_silu: dropout probability %g outside [0, 1)", (double)dropout_p);
     return bsi_film_silu_drop(h1, M, N, HW, film, film_rows, film_stride, make_drop(dropout_p, seed, site), y, stream);
 }
 
 extern "C" int bsi_film_silu_bwd(const void* dy, const void* h1, int M, int N, int HW, const float* film, int film_rows,
                                  int film_stride, float dropout_p, unsigned long long seed, unsigned site, void* dh1,
                                  float* dfilm, int dfilm_stride, bsi_stream_t stream) {
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_film_silu_bwd: dropout probability %g outside [0, 1)", (double)dropout_p);
     return bsi_film_silu_bwd_drop(dy, h1, M, N, HW, film, film_rows, film_stride, make_drop(dropout_p, seed, site), dh1, dfilm,
                                   dfilm_stride, stream, 0);
 }

@@ -220,6 +220,7 @@ extern "C" int bsi_unet_train_forward(const bsi_unet_config* cfg, const bsi_unet
                                       const float* c_in, const float* c_skip, const float* c_out, float* out, void* tape_mem,
                                       float dropout_p, unsigned long long seed, bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && mu && t && out && tape_mem && B > 0, "bsi_unet_train_forward: bad args");
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_unet_train_forward: dropout probability %g outside [0, 1)", (double)dropout_p);
     BSI_CHECK_ARG((c_in == nullptr) == (c_skip == nullptr) && (c_in == nullptr) == (c_out == nullptr),
                   "bsi_unet_train_forward: c_in/c_skip/c_out must be given together");
     const UD d = ud(cfg, B);
@@ -303,6 +304,7 @@ extern "C" int bsi_unet_backward(const bsi_unet_config* cfg, const bsi_unet_weig
                                  void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream) {
     BSI_CHECK_ARG(cfg && w && w->blocks && wT && wT->blocks && g && g->blocks && g_out && tape_mem && workspace && B > 0,
                   "bsi_unet_backward: bad args");
+    BSI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bsi_unet_backward: dropout probability %g outside [0, 1)", (double)dropout_p);
     const UD d = ud(cfg, B);
     TRY(check_geometry(cfg, d, "bsi_unet_backward"));
     const int dim = d.dim, H = cfg->H, W = cfg->W, L = d.L, M = (int)d.M, cd = cfg->c_dim;

@@ -152,7 +152,10 @@ class DPTrainer:
         self.ema_beta, self.ema_after = ema_beta, ema_update_after_step
         self._invalidate(self.model)
         self.model._ws = None
-        self.model._flat_grad_only = True  # the HIP backward leaves its flat gradient in _last_flat_grad; no per-parameter .grad copies
+        # (`_flat_grad_only` -- the HIP backward leaves its flat gradient in `_last_flat_grad` and hands autograd no per-parameter
+        # gradients -- is set only INSIDE `_backward`: a sticky attribute would silently turn every ordinary `loss.backward()` on
+        # this model, and on the deep-copied EMA model, into a no-op for `p.grad`)
+        self.model._flat_grad_only = False
         for attr in ("_plan", "_plan_t"):  # persistent shadow buffers + ctypes tables (rebuilt on demand; not deep-copyable)
             if hasattr(self.model, attr):
                 setattr(self.model, attr, None)
@@ -194,10 +197,14 @@ class DPTrainer:
         self.model._last_flat_grad = None
         if self.exchange and self.bucketed:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
-        loss = self.bsi.train_loss(x, generator).mean()
-        loss.backward()
-        if self.exchange and self.bucketed:
-            N.check(lib.bsi_dit_backward_set_events(None, 0))
+        self.model._flat_grad_only = True
+        try:
+            loss = self.bsi.train_loss(x, generator).mean()
+            loss.backward()
+        finally:
+            self.model._flat_grad_only = False
+            if self.exchange and self.bucketed:
+                N.check(lib.bsi_dit_backward_set_events(None, 0))
         flat_g = self.model._last_flat_grad
         assert flat_g is not None, "the HIP training engine did not run (model is not a native denoiser?)"
         return loss, flat_g

@@ -132,8 +132,11 @@ class DenoisingVDMUNet(nn.Module):
                 [b[0] for b in u.upsampling_blocks])
 
     def _storage_key(self):
+        """Identity of the parameters' STORAGE: the pack plan bakes every parameter's raw pointer into device-side descriptor
+        tables, so the key names every one of them (330 integers; a re-pack costs far more) -- replacing the storage of an
+        interior parameter (`p.data = ...`, `load_state_dict(assign=True)`, a per-module `.to()`) must rebuild the plan."""
         ps = list(self.parameters())
-        return (ps[0].device, len(ps), ps[0].data_ptr(), ps[-1].data_ptr())
+        return (ps[0].device, len(ps), hash(tuple(p.data_ptr() for p in ps)))
 
     def native_pack(self):
         """(config, weight table, block array, keep-alive) for the HIP engines.  The bf16 shadows live in PERSISTENT buffers described

@@ -22,3 +22,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Achieved parity errors (tests.util.report) as the last lines of the run, one compact line per record, so that a
+    `pytest -q` tail shows the numbers behind the green assertions (bounds are in the tests)."""
+    try:
+        from tests.util import RECORDS
+    except Exception:  # noqa: BLE001
+        return
+    if not RECORDS:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "PARITY (achieved errors; stated tolerances: train_loss mean 1e-4, per sample 1e-3, x_hat 1e-2, gradients 1e-2)")
+
+    def fmt(v):
+        if isinstance(v, float):
+            return f"{v:.2e}"
+        if isinstance(v, list):
+            return "[" + ",".join(fmt(x) for x in v[:4]) + (",..]" if len(v) > 4 else "]")
+        if isinstance(v, dict):
+            return "{" + ",".join(f"{k}={fmt(x)}" for k, x in list(v.items())[:4]) + "}"
+        return str(v)
+
+    for rec in RECORDS:
+        body = " ".join(f"{k}={fmt(v)}" for k, v in rec.items() if k != "test")
+        tr.write_line(f"PARITY {rec['test']}: {body}"[:400])

@@ -50,17 +50,37 @@ def native_dit(W, shape, ps, dim, depth, heads, dropout=None):
     return m.to(DEV)
 
 
-def grad_errors(model, ref_grads):
-    """Per-tensor relative L2 error of the parameter gradients and the error of the global norm."""
-    worst, sq, sqr = (0.0, None), 0.0, 0.0
+def grad_errors(model, ref_grads, floor_grads=None, top=6):
+    """Per-tensor relative L2 error of the parameter gradients and the error of the global norm.  Returns (worst, norm_err, table):
+    `table` lists the `top` worst tensors as (err, name, |ref|, floor) where floor = rel. L2 distance of `floor_grads` (the oracle
+    evaluated with bf16-rounded GEMM / convolution operands, `md=torch.bfloat16`) from the fp32 oracle for that tensor -- what
+    rounding the operands alone costs, before any kernel is involved."""
+    rows, sq, sqr = [], 0.0, 0.0
     for name, p in model.named_parameters():
         r = ref_grads[name].double()
         got = p.grad.detach().cpu().double()
         sq += float((got ** 2).sum())
         sqr += float((r ** 2).sum())
         err = float((got - r).norm() / r.norm().clamp_min(1e-30))
-        worst = max(worst, (err, name))
-    return worst, abs((sq / sqr) ** 0.5 - 1)
+        fl = None
+        if floor_grads is not None:
+            fl = float((floor_grads[name].double() - r).norm() / r.norm().clamp_min(1e-30))
+        rows.append((err, name, float(r.norm()), fl))
+    rows.sort(reverse=True)
+    return rows[0][:2], abs((sq / sqr) ** 0.5 - 1), rows[:top]
+
+
+GRAD_TOL = 1e-2  # stated bound on the relative L2 error of every parameter-gradient tensor (VERDICT r2 item 5)
+
+
+def assert_grad_table(table, tol=GRAD_TOL):
+    """Every gradient tensor within `tol` of the fp32 oracle -- or, where rounding the operands to bf16 ALONE moves the oracle's
+    own gradient by more than tol / 2 (floor column), within 1.5 x that floor: the kernel may not add to what the operand
+    precision the north_star prescribes (bf16 MFMA) costs by itself."""
+    for err, name, _, fl in table:
+        if err <= tol:
+            continue
+        assert fl is not None and fl > tol / 2 and err <= 1.5 * fl, (name, err, fl)
 
 
 def test_calibration_point_train_loss_at_stated_tolerance():
@@ -106,14 +126,14 @@ def test_calibration_point_gradients():
                                      heads=c["heads"], ff=c["ff"])
     ref = bo.BSIOracle(f, data_shape=c["shape"], k=128).train_loss(g["x"], g["offset"], g["perm"], g["eps"])
     ref.mean().backward()
-    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    worst, norm_err, table = grad_errors(model, {k: v.grad for k, v in Wr.items()})
     gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters()) ** 0.5
     norm_vs_ref = abs(gn / float(g["grad_norm"]) - 1)
     report("calibration_gradients", train_mode_mean_rel=mean_err, train_mode_per_sample_max=per,
            worst_tensor_rel_l2=worst[0], worst_tensor=worst[1], grad_norm_rel=norm_err, grad_norm_rel_vs_reference=norm_vs_ref)
     assert mean_err <= 1e-4 and per <= 1e-3, (mean_err, per)
-    assert worst[0] < 2e-2, worst
-    assert norm_vs_ref < 5e-3, norm_vs_ref
+    assert_grad_table(table)
+    assert norm_vs_ref < 1e-3, norm_vs_ref
 
 
 def test_full_size_dit_l2_train_loss_and_gradients_vs_oracle():
@@ -138,12 +158,12 @@ def test_full_size_dit_l2_train_loss_and_gradients_vs_oracle():
     lc = loss.detach().cpu()
     per = float(max_rel(lc, ref.detach()))
     mean_err = abs(float(lc.double().mean()) / float(ref.detach().double().mean()) - 1)
-    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    worst, norm_err, table = grad_errors(model, {k: v.grad for k, v in Wr.items()})
     report("dit_l2_full_size_train", B=B, mean_rel=mean_err, per_sample_max=per, worst_tensor_rel_l2=worst[0],
            worst_tensor=worst[1], grad_norm_rel=norm_err)
-    assert per <= 1e-3 and mean_err <= 5e-4, (per, mean_err)   # 4 samples: the mean is not yet averaged down
-    assert worst[0] < 3e-2, worst
-    assert norm_err < 1e-2, norm_err
+    assert per <= 1e-3 and mean_err <= 1e-4, (per, mean_err)   # the stated tolerances
+    assert_grad_table(table)
+    assert norm_err < 1e-3, norm_err
 
 
 def test_config5_dit_l4_imagenet64_geometry():
@@ -187,8 +207,8 @@ def test_config5_dit_l4_imagenet64_geometry():
     report("config5_dit_l4_64x64", forward_rel_linf=e_fwd, elbo_bpd_max_rel=e_bpd, l_measure_max_rel=e_lm, l_recon_max_rel=e_lr,
            schedule_len=len(bsi.default_schedule))
     assert len(bsi.default_schedule) == 257
-    assert e_fwd < 2e-2, e_fwd
-    assert e_lm < 1e-2 and e_lr < 1e-2 and e_bpd < 1e-2, (e_lm, e_lr, e_bpd)
+    assert e_fwd < 2e-3, e_fwd   # x_hat of one evaluation, rel. L-inf (stated 1e-2 for trajectories)
+    assert e_lm < 1e-3 and e_lr < 1e-3 and e_bpd < 1e-4, (e_lm, e_lr, e_bpd)   # per-sample loss terms 1e-3, the bpd mean 1e-4
     assert torch.equal(a, b) and torch.isfinite(a).all() and a.shape == (2, *shape)
 
 
@@ -257,7 +277,7 @@ def test_unet_calibration_point_at_stated_tolerance():
     f = lambda mu, t: uo.unet_forward(Wr, mu, t, levels=c["levels"], ff=c["ff"], has_dropout_slot=True)  # noqa: E731
     ref = bo.BSIOracle(f, data_shape=c["shape"], k=128).train_loss(g["x"], g["offset"], g["perm"], g["eps"])
     ref.mean().backward()
-    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    worst, norm_err, table = grad_errors(model, {k: v.grad for k, v in Wr.items()})
     gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters()) ** 0.5
     report("unet_calibration", mean_rel=mean_err, per_sample_max=per.max(), per_sample_median=per.median(),
            teacher_forced_xhat_max=max(tf), worst_tensor_rel_l2=worst[0], worst_tensor=worst[1],
@@ -265,8 +285,8 @@ def test_unet_calibration_point_at_stated_tolerance():
     assert mean_err <= 1e-4, mean_err
     assert float(per.max()) <= 1e-3, float(per.max())
     assert max(tf) <= 1e-2, tf
-    assert worst[0] < 3e-2, worst
-    assert abs(gn / float(g["grad_norm"]) - 1) < 5e-3
+    assert_grad_table(table)
+    assert abs(gn / float(g["grad_norm"]) - 1) < 1e-3
 
 
 def test_full_size_unet_train_loss_and_gradients_vs_oracle():
@@ -291,9 +311,15 @@ def test_full_size_unet_train_loss_and_gradients_vs_oracle():
     lc = loss.detach().cpu()
     per = float(max_rel(lc, ref.detach()))
     mean_err = abs(float(lc.double().mean()) / float(ref.detach().double().mean()) - 1)
-    worst, norm_err = grad_errors(model, {k: v.grad for k, v in Wr.items()})
+    # what rounding the convolution / GEMM operands to bf16 costs by itself: the SAME oracle with md = bf16 (operands rounded,
+    # fp32 accumulation, everything else fp32) against the fp32 oracle, per gradient tensor
+    Wb = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    fb = lambda mu, t: uo.unet_forward(Wb, mu, t, levels=levels, ff=(6, 8), has_dropout_slot=True, md=torch.bfloat16)  # noqa: E731
+    bo.BSIOracle(fb, data_shape=shape, k=128).train_loss(x, off, perm, eps).mean().backward()
+    worst, norm_err, table = grad_errors(model, {k: v.grad for k, v in Wr.items()}, {k: v.grad for k, v in Wb.items()}, top=8)
     report("unet_full_size_train", B=B, mean_rel=mean_err, per_sample_max=per, worst_tensor_rel_l2=worst[0],
-           worst_tensor=worst[1], grad_norm_rel=norm_err)
-    assert per <= 2e-3 and mean_err <= 2e-3, (per, mean_err)   # 67 residual blocks of bf16 convolutions, two samples
-    assert worst[0] < 5e-2, worst
-    assert norm_err < 2e-2, norm_err
+           worst_tensor=worst[1], grad_norm_rel=norm_err,
+           worst_tensors=[{"name": n, "rel_l2": e, "ref_norm": rn, "bf16_operand_floor": fl} for e, n, rn, fl in table])
+    assert per <= 1e-3 and mean_err <= 1e-4, (per, mean_err)   # the stated tolerances
+    assert_grad_table(table)
+    assert norm_err < 1e-3, norm_err

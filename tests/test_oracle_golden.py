@@ -314,3 +314,49 @@ def test_g8_ema_and_adamw():
     a = g["lerp_tgt"].clone()
     a = a + (g["lerp_src"] - a) * (1.0 - 0.9)
     assert rel_linf(a, g["lerp_out_0.9"]) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------
+# G14: BASELINE.json configs[0] at its stated size (README denoiser, 3x32x32, batch 32, k = 16)
+# ----------------------------------------------------------------------------------------
+def config1_noise(g):
+    """Re-draw the Gaussian noise of g14_config1 from its seeds (same generator calls as the reference made, bsi.py:232-247,
+    325-334) and check the fingerprints the generator script stored."""
+    B, shape, k = 32, (3, 32, 32), int(g["k"])
+
+    def fp(t):
+        d = t.double()
+        return torch.stack((d.sum(), d.abs().sum(), d.flatten()[0], d.flatten()[-1], (d * d).sum()))
+
+    gen = torch.Generator().manual_seed(int(g["seed_train"]))
+    off, perm = torch.rand((), generator=gen), torch.randperm(B, generator=gen)
+    eps = torch.randn((B, *shape), generator=gen)
+    def same(a, b):  # sums are taken in a thread-count dependent order: 1e-12 relative; first / last element exact
+        return torch.allclose(a, b, rtol=1e-12, atol=0) and torch.equal(a[2:4], b[2:4])
+
+    assert torch.equal(off, g["offset"]) and torch.equal(perm, g["perm"]) and same(fp(eps), g["eps_fp"]), \
+        "torch CPU generator stream differs from the one the golden was drawn with"
+    gen = torch.Generator().manual_seed(int(g["seed_sample"]))
+    eps0 = torch.randn((B, *shape), generator=gen)
+    eps_s = torch.stack([torch.randn((B, *shape), generator=gen) for _ in range(k)])
+    assert same(fp(eps0), g["eps0_fp"]) and same(fp(eps_s), g["eps_steps_fp"])
+    return off, perm, eps, eps0, eps_s
+
+
+def test_g14_config1_at_stated_size():
+    g = golden("g14_config1")
+    off, perm, eps, eps0, eps_s = config1_noise(g)
+    W = {k: v.clone().requires_grad_(True) for k, v in sub(g, "W.").items()}
+    o = make(tiny_conv(W), (3, 32, 32), k=int(g["k"]))
+    loss = o.train_loss(g["x"], off, perm, eps)
+    assert max_rel(loss, g["loss"]) < 1e-5 and abs(float(loss.mean()) / float(g["loss_mean"]) - 1) < 1e-6
+    loss.mean().backward()
+    for k, ref in sub(g, "G.").items():
+        assert rel_linf(W[k].grad, ref) < 1e-4, (k, rel_linf(W[k].grad, ref))
+    with torch.no_grad():
+        mus, xh, ys = o.sample_history(eps0, eps_s)
+    # free-running fp32, no Fourier features: 1e-5 per step (BASELINE.md section 5)
+    assert rel_linf(xh[-1], g["sample"]) < 1e-5 and rel_linf(mus[-1], g["mu_last"]) < 1e-5
+    for a, b in [(mus[:, :4], g["mus_first4"]), (xh[:, :4], g["x_hats_first4"]), (ys[:, :4], g["ys_first4"])]:
+        for i in range(a.shape[0]):
+            assert rel_linf(a[i], b[i]) < 1e-5, (i, rel_linf(a[i], b[i]))

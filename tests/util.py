@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RECORDS = []  # parity records of this pytest process (report())
 
 
 def golden(name):
@@ -59,6 +60,7 @@ def report(name, **values):
     import json
     rec = {"test": name, **{k: (float(v) if not isinstance(v, (str, int, list, dict)) else v) for k, v in values.items()}}
     line = json.dumps(rec)
+    RECORDS.append(rec)  # printed again by conftest.pytest_terminal_summary: the -q tail of a run carries the achieved errors
     print("PARITY " + line)
     try:
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -83,3 +85,32 @@ def calib_unet_weights():
     ref = golden("g13_calib_unet")["weight_fingerprint"]
     assert torch.allclose(fp, ref, rtol=1e-12, atol=0), "seeded weight stream differs from the one the golden was made with"
     return W
+
+
+import contextlib
+from unittest import mock
+
+
+@contextlib.contextmanager
+def replay_draws(device, **queues):
+    """Feed recorded draws to torch.rand / randn / randperm / randint calls made inside the block, in order, moved to `device`
+    (the goldens and the multi-process tests draw from seeded CPU generators; the device generator has another stream)."""
+    qs = {k: list(v) for k, v in queues.items()}
+
+    def pop(name):
+        def f(*a, **kw):
+            return qs[name].pop(0).to(kw.get("device", device))
+        return f
+
+    with contextlib.ExitStack() as st:
+        for name in qs:
+            st.enter_context(mock.patch.object(torch, name, side_effect=pop(name)))
+        yield
+    assert all(len(v) == 0 for v in qs.values()), "not all recorded draws were consumed"
+
+
+def shard_draws(rank, step, nb, shape):
+    """The (offset, perm, eps) a rank's train_loss consumes at optimizer step `step` in the two-process tests: a seeded CPU
+    stream per (rank, step), so that a single process can restate both ranks' work."""
+    g = torch.Generator().manual_seed(1000 + 17 * rank + step)
+    return torch.rand((), generator=g), torch.randperm(nb, generator=g), torch.randn((nb, *shape), generator=g)

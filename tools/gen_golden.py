@@ -216,6 +216,45 @@ def g5_history():
     history_case("g5_hist_unet_noff", small_unet(ff=False, seed=6), (3, 8, 8), 2, 16, 54, "unet_noff")
 
 
+def fingerprint(t):
+    d = t.double()
+    return torch.stack((d.sum(), d.abs().sum(), d.flatten()[0], d.flatten()[-1], (d * d).sum()))
+
+
+def g14_config1():
+    """BASELINE.json configs[0] at its stated size: the README denoiser on 3x32x32, batch 32, train_loss + sample k = 16
+    (README.md:21-35).  The Gaussian noise (2 + 16 draws of [32, 3, 32, 32]) is NOT stored: the tests re-draw it from the seeds
+    below with the same generator calls and check the stored fingerprints (torch CPU generator, same image on the GPU box)."""
+    torch.manual_seed(14)
+    model = TinyConv()
+    shape, B, k, seed_t, seed_s = (3, 32, 32), 32, 16, 140, 141
+    b = make_bsi(model, shape, k=k)
+    x = data(B, shape, 142)
+    g = torch.Generator().manual_seed(seed_t)
+    loss = b.train_loss(x, g)
+    model.zero_grad()
+    loss.mean().backward()
+    grads = {"G." + kk: p.grad.clone() for kk, p in model.named_parameters()}
+    g = torch.Generator().manual_seed(seed_t)
+    off = torch.rand((), generator=g)
+    perm = torch.randperm(B, generator=g)
+    eps = torch.randn((B, *shape), generator=g)
+    g = torch.Generator().manual_seed(seed_s)
+    with torch.no_grad():
+        mus, x_hats, ys = b.sample_history(B, g)
+    g = torch.Generator().manual_seed(seed_s)
+    with torch.no_grad():
+        smp = b.sample(B, g)
+    assert torch.equal(smp, x_hats[-1])
+    g = torch.Generator().manual_seed(seed_s)
+    eps0 = torch.randn((B, *shape), generator=g)
+    eps_s = torch.stack([torch.randn((B, *shape), generator=g) for _ in range(k)])
+    save("g14_config1", x=x, seed_train=np.int64(seed_t), seed_sample=np.int64(seed_s), k=np.int64(k),
+         offset=off, perm=perm, eps_fp=fingerprint(eps), eps0_fp=fingerprint(eps0), eps_steps_fp=fingerprint(eps_s),
+         loss=loss.detach(), loss_mean=loss.detach().mean(), sample=smp, mu_last=mus[-1],
+         x_hats_first4=x_hats[:, :4], mus_first4=mus[:, :4], ys_first4=ys[:, :4], **sd(model), **grads)
+
+
 def g6_elbo():
     torch.manual_seed(4)
     model = TinyConv()
@@ -512,4 +551,5 @@ if __name__ == "__main__":
     g8_optimizer()
     g11_calibration()
     g13_calibration_unet()
+    g14_config1()
     kat_reference_tests()

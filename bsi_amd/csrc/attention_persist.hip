@@ -121,12 +121,6 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         const unsigned va0 = vbase + ((0 ^ vkey) << 5), va1 = vbase + ((1 ^ vkey) << 5), va2 = vbase + ((2 ^ vkey) << 5),
                        va3 = vbase + ((3 ^ vkey) << 5);                               // + 4096 kb + 2048 (second 16 keys) + 16384 chunk
         f32x4 o[4];
-        // Inference instances (no dropout, no log-sum-exp output): the softmax normaliser comes from the matrix pipe -- one more
-        // MFMA per 32-key block with an all-ones A operand gives sum_k P[k][q] (of the bf16 P the products use, so the weights of a
-        // row sum to one exactly) in every row of a fifth output tile: no 64 vector adds per lane and pair, no lane-group sum.
-        // The kernel is vector-ALU bound (6.8 vector instructions per MFMA); the matrix pipe has three quarters of its time free.
-        constexpr bool MFMA_SUM = !DROP && !LSE;
-        f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
         float m_run = 0.f, l_run = 0.f;
         unsigned rowh = 0u;
         if constexpr (DROP) rowh = drop_row(dc, (unsigned)pr * PT + q0 + c16);
@@ -156,8 +150,7 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
             if constexpr (ch > 0) {
                 m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-                if constexpr (MFMA_SUM) lacc[0] *= alpha;  // the four rows of the tile are equal: row 0 is the one that is read
-                else l_run *= alpha;
+                l_run *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -171,13 +164,11 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][r], scale_log2e, -mb));
-                    if constexpr (!MFMA_SUM) {
-                        if (r & 1) ps1 += pv; else ps0 += pv;  // the normaliser uses the undropped probabilities
-                    }
+                    if (r & 1) ps1 += pv; else ps0 += pv;  // the normaliser uses the undropped probabilities
                     if constexpr (DROP) pv = drop_keep_rc(dc, rowh, ch * 128 + 16 * kt + 4 * g + r) ? pv * dc.scale : 0.0f;
                     s[kt][r] = pv;
                 }
-            if constexpr (!MFMA_SUM) l_run += ps0 + ps1;
+            l_run += ps0 + ps1;
             // ---- O^T += V^T . P^T over 32-key blocks.  The transposed reads go out as inline asm: behind the builtin hipcc waits
             //      vmcnt(0) -- for the NEXT pair's LDS-DMA, which it cannot tell apart from this buffer -- and the pipeline is gone.
             s16x4 va[2][4], vb[2][4];
@@ -206,11 +197,6 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
                     if (ch == 0 && kb == 0) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     else o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, o[dt], 0, 0, 0);
                 }
-                if constexpr (MFMA_SUM) {
-                    union { u32x4 u; bf16x8 v; } ones;
-                    ones.u = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pf, lacc, 0, 0, 0);
-                }
             };
             reads(std::integral_constant<int, 0>{}, 0);
             reads(std::integral_constant<int, 1>{}, 1);
@@ -227,14 +213,10 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         {
             typedef unsigned u2v __attribute__((ext_vector_type(2)));
             float l = l_run;
-            if constexpr (MFMA_SUM) {
-                l = lacc[0];  // sum over all 256 keys for this lane's query, the same in every lane group
-            } else {
-                u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-                l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-                t = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-                l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-            }
+            u2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+            l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            t = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+            l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
             const float inv = 1.0f / l;
             if constexpr (LSE) {  // log-sum-exp of the scaled scores (natural log), saved for the backward pass
                 if (g == 0) lse[(size_t)pr * PT + q0 + c16] = (m_run * scale_log2e + __log2f(l)) * 0.6931471805599453f;

@@ -44,8 +44,6 @@ struct GemmParams {
     const void* aux;  // MUL_GELUGRAD: pre-activation (bf16, layout of out)
     void* out2;       // BIAS_GELU_DUAL: pre-activation output (bf16, layout of out)
     int tiles_m, tiles_n;
-    int stagger;  // experiment: first-wave workgroups sleep (blockIdx % 16) * stagger * 64 clocks
-    int groups, group_delay;  // k64r kernel: phase groups per XCD and their start offset (units of 64 clocks), see the kernel
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
     int ng;       // n-tiles per group of the tile order (0: all), see tile_coords
     // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
@@ -442,150 +440,128 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
     }
 }
 
-template <int EPI, int ABL, bool SCRATCH = true, bool BIAS_IN_ACC = false>
+template <int EPI, bool SCRATCH = true, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], int mw0, int nw0, int lane, char* scratch) {
     constexpr int TM = 8;
     constexpr bool BF16_OUT = EpiTraits<EPI>::out_bf16;
     const int rho = lane & 15, qd = lane >> 4;
 
-
-        if constexpr (ABL & 4) {
-            float sacc = 0.f;
+    if constexpr (!SCRATCH && BIAS_IN_ACC && (EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16)) {
+        wave_tile_epilogue_train<EPI>(p, acc, mw0, nw0, lane);
+    } else if constexpr (BF16_OUT) {
+        const int nb = nw0 + 16 * qd;
+        const bool nb_ok = nb < p.N;
+        float bias[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; e += 4) {
+            f32x4 bv = (!BIAS_IN_ACC && p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
+        }
+        const int rr = lane >> 3, ch = lane & 7;
+        const bool cols_ok = nw0 + 8 * ch < p.N;
 #pragma unroll
-                for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-            if (sacc == 123.456f) reinterpret_cast<float*>(p.out)[0] = sacc;
-        } else if constexpr (!SCRATCH && BIAS_IN_ACC && !(ABL & (32 | 128)) &&
-                             (EPI == BSI_EPI_BIAS_GELU_DUAL || EPI == BSI_EPI_MUL_GELUGRAD_BF16)) {
-            wave_tile_epilogue_train<EPI>(p, acc, mw0, nw0, lane);
-        } else if constexpr (BF16_OUT) {
-            const int nb = nw0 + 16 * qd;
-            const bool nb_ok = nb < p.N;
-            float bias[16];
+        for (int rnd = 0; rnd < TM / 2; ++rnd) {
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                f32x4 bv = (!BIAS_IN_ACC && p.bias && nb_ok) ? *reinterpret_cast<const f32x4*>(p.bias + nb + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-                bias[e] = bv[0]; bias[e + 1] = bv[1]; bias[e + 2] = bv[2]; bias[e + 3] = bv[3];
-            }
-            const int rr = lane >> 3, ch = lane & 7;
-            const bool cols_ok = nw0 + 8 * ch < p.N;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * rnd + jj;
+                float v[16];
 #pragma unroll
-            for (int rnd = 0; rnd < TM / 2; ++rnd) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = 2 * rnd + jj;
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * i + r] = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bias[4 * i + r];
-                    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
-                        const int m = mw0 + 16 * j + rho;
-                        if (m < p.M && nb_ok) {
-                            const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
-                            const u32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax));
-                            const u32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + 8));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
-                                v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
-                                v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
-                                v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
-                            }
-                        }
-                    }
-                    if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // pre-activation: direct 32-B stores (training only)
-                        const int m = mw0 + 16 * j + rho;
-                        if (m < p.M && nb_ok) {
-                            u32x4 a0, a1;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                                a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-                            }
-                            __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
-                            __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
-                            __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
-                        }
-                    }
-                    if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
-#pragma unroll
-                        for (int e = 0; e < 16; e += 2) {  // packed: 2.5 instead of 6 vector-ALU instructions per value
-                            const f32x2_ g = gelu_tanh_f2(f32x2_{v[e], v[e + 1]});
-                            v[e] = g[0];
-                            v[e + 1] = g[1];
-                        }
-                    } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
-                    }
-                    u32x4 w0, w1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                        w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-                    }
-                    if constexpr (!SCRATCH) {
-                        const bool odd = lane & 1;
-                        u32x4 st_even, st_odd;
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bias[4 * i + r];
+                if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+                    const int m = mw0 + 16 * j + rho;
+                    if (m < p.M && nb_ok) {
+                        const __bf16* ax = reinterpret_cast<const __bf16*>(p.aux) + (size_t)m * p.ldo + nb;
+                        const u32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax));
+                        const u32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + 8));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const unsigned send = odd ? w0[e] : w1[e];
-                            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);  // lane ^ 1
-                            st_even[e] = odd ? recv : w0[e];
-                            st_odd[e] = odd ? w1[e] : recv;
+                            v[2 * e] *= gelu_tanh_grad_f(__uint_as_float(x0[e] << 16));
+                            v[2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x0[e] & 0xffff0000u));
+                            v[8 + 2 * e] *= gelu_tanh_grad_f(__uint_as_float(x1[e] << 16));
+                            v[8 + 2 * e + 1] *= gelu_tanh_grad_f(__uint_as_float(x1[e] & 0xffff0000u));
                         }
-                        const int m_even = mw0 + 16 * j + (rho & ~1);
-                        const int col = nb + (odd ? 8 : 0);
-                        if (nb_ok) {
-                            __bf16* ob = reinterpret_cast<__bf16*>(p.out) + col;
-                            if constexpr (ABL & 128) {  // laboratory: everything but the global stores
-                                if ((st_even[0] ^ st_odd[1] ^ st_even[2] ^ st_odd[3]) == 0x12345678u) *reinterpret_cast<u32x4*>(ob) = st_even;
-                            } else if constexpr (ABL & 32) {  // laboratory: ordinary (write-back) stores
-                                if (m_even < p.M) *reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo) = st_even;
-                                if (m_even + 1 < p.M) *reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo) = st_odd;
-                            } else {
-                                if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
-                                if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
-                            }
-                        }
-                        continue;
-                    }
-                    const int r = 16 * jj + rho;  // row within this round's 32-row image
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
-                    *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
-                }
-                if constexpr (!SCRATCH) continue;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4 d[4];
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int r = 8 * t4 + rr;
-                    d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int m = mw0 + 32 * rnd + 8 * t4 + rr;
-                    if (m < p.M && cols_ok) {
-                        const int m_dst = (ABL & 256) ? (m & 255) : m;  // laboratory: all tiles write the same 256 rows
-                        if ((ABL & 512) && rnd != 0) continue;           // laboratory: a quarter of the stores
-                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m_dst * p.ldo + nw0 + 8 * ch);
-                        // non-temporal: the output is consumed by the NEXT kernel; a normal store write-allocates in
-                        // this XCD's L2 and evicts the A/W panels the other CUs are re-reading (+32 % on qkv)
-                        if constexpr (ABL & 32) *dst = d[t4];
-                        else if constexpr (ABL & 128) {  // laboratory: everything but the global stores
-                            if (d[t4][0] == 0x12345678u && d[t4][3] == 0x9abcdef0u) *dst = d[t4];
-                        } else __builtin_nontemporal_store(d[t4], dst);
                     }
                 }
+                if constexpr (EPI == BSI_EPI_BIAS_GELU_DUAL) {  // pre-activation: direct 32-B stores (training only)
+                    const int m = mw0 + 16 * j + rho;
+                    if (m < p.M && nb_ok) {
+                        u32x4 a0, a1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                            a1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                        }
+                        __bf16* o2 = reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.ldo + nb;
+                        __builtin_nontemporal_store(a0, reinterpret_cast<u32x4*>(o2));
+                        __builtin_nontemporal_store(a1, reinterpret_cast<u32x4*>(o2 + 8));
+                    }
+                }
+                if constexpr (EPI == BSI_EPI_BIAS_GELU_BF16 || EPI == BSI_EPI_BIAS_GELU_DUAL) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {  // packed: 2.5 instead of 6 vector-ALU instructions per value
+                        const f32x2_ g = gelu_tanh_f2(f32x2_{v[e], v[e + 1]});
+                        v[e] = g[0];
+                        v[e + 1] = g[1];
+                    }
+                } else if constexpr (EPI == BSI_EPI_BIAS_SILU_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
+                }
+                u32x4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                    w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                }
+                if constexpr (!SCRATCH) {
+                    // lanes rho and rho^1 (rows m, m+1) swap one half of their 16 columns: 8 lanes then write one complete 128-B line
+                    const bool odd = lane & 1;
+                    u32x4 st_even, st_odd;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned send = odd ? w0[e] : w1[e];
+                        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+                        st_even[e] = odd ? recv : w0[e];
+                        st_odd[e] = odd ? w1[e] : recv;
+                    }
+                    const int m_even = mw0 + 16 * j + (rho & ~1);
+                    const int col = nb + (odd ? 8 : 0);
+                    if (nb_ok) {
+                        // non-temporal: the output is consumed by the NEXT kernel; a write-back store allocates in this XCD's L2 and
+                        // evicts the A / W panels the other CUs are re-reading
+                        __bf16* ob = reinterpret_cast<__bf16*>(p.out) + col;
+                        if (m_even < p.M) __builtin_nontemporal_store(st_even, reinterpret_cast<u32x4*>(ob + (size_t)m_even * p.ldo));
+                        if (m_even + 1 < p.M) __builtin_nontemporal_store(st_odd, reinterpret_cast<u32x4*>(ob + (size_t)(m_even + 1) * p.ldo));
+                    }
+                    continue;
+                }
+                const int r = 16 * jj + rho;  // row within this round's 32-row image
+                *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd) ^ (r & 7)) << 4)) = w0;
+                *reinterpret_cast<u32x4*>(scratch + r * 128 + (((2 * qd + 1) ^ (r & 7)) << 4)) = w1;
             }
-        } else {
-            gemm_epilogue<TM, EPI>(p, acc, mw0, nw0, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fp32 read-modify-write paths: simple drain
+            if constexpr (!SCRATCH) continue;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            u32x4 d[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int r = 8 * t4 + rr;
+                d[t4] = *reinterpret_cast<const u32x4*>(scratch + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int m = mw0 + 32 * rnd + 8 * t4 + rr;
+                if (m < p.M && cols_ok)
+                    __builtin_nontemporal_store(d[t4], reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldo + nw0 + 8 * ch));
+            }
         }
+    } else {
+        gemm_epilogue<TM, EPI>(p, acc, mw0, nw0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fp32 read-modify-write paths: simple drain
     }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Variant 6: PERSISTENT deep-ring ping-pong (the production schedule).
@@ -601,15 +577,9 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, f32x4 (&
 //     per tile instead of prologue + two epilogues + store drain;
 //   * bf16 outputs leave through the LDS scratch in 4 rounds of 32 rows so that every store instruction writes
 //     whole 128-B lines.
-template <int EPI, int ABL = 0, bool ROLL = false, int RING = 4, bool CDMA = false>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p) {
-    // CDMA: the four DMA instructions of a stage are issued INSIDE the MFMA phase, one behind every second group of four
-    // MFMAs (the matrix pipe keeps executing queued MFMAs while the wave's DMA issue stalls), instead of in the load phase,
-    // whose length then is just the twelve fragment reads.
-    // ROLL: the activation fragments of step v+1 are fetched DURING the MFMA phase of step v (fragment register j is
-    // re-loaded right after the four MFMAs that consume it), so the load phase shrinks to the weight fragments + the DMA
-    // issue and stops being longer than the partner group's MFMA phase.
-    constexpr int TM = 8, NW = 8, R = RING, D = R - 1;
+    constexpr int TM = 8, NW = 8, R = 4, D = R - 1;
     constexpr int BM = 256, BN = 256;
     constexpr int RB = 64;
     constexpr int SLOT_BYTES = (BM + BN) * RB;
@@ -634,11 +604,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + wl;
     if (tile >= hi) return;
-    unsigned long long clk0 = 0, rt0 = 0;
-    if constexpr (ABL & 64) {  // laboratory builds: shader clock over the kernel = d(s_memtime) / d(s_memrealtime) * 100 MHz
-        clk0 = __builtin_readcyclecounter();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
 
     const int srow = lane >> 2, spos = lane & 3;
     const char* gsrc[4];
@@ -701,11 +666,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             tile_coords(p, t - sp * tiles_mn, tm_, tn_);
             GemmParams q = p;
             q.out = reinterpret_cast<float*>(p.out) + (size_t)sp * p.slab_stride;
-            wave_tile_epilogue<EPI, ABL>(q, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
+            wave_tile_epilogue<EPI>(q, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
             return;
         }
         tile_coords(p, t, tm_, tn_);
-        wave_tile_epilogue<EPI, ABL>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
+        wave_tile_epilogue<EPI>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
     };
 
     const int nk = (p.splits > 1 ? p.kslice : p.K) / 32;  // launcher guarantees nk >= D
@@ -715,13 +680,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
     PHASE_BARRIER();
     if (wm == 1) PHASE_BARRIER();  // group B runs one phase behind
-    if constexpr (ROLL) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(lds + xoff + j * 16 * RB);
-    }
 
     int slot = 0, pslot = D;
-    bool issued_prev = true;  // CDMA: the prologue issued stages 0 .. D-1
     int after_e = 0;  // L phases since the last epilogue whose stores may still be in flight
     while (true) {
         const int next = tile + wpx;
@@ -734,47 +694,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             // ---- L(v)
             {
                 const char* b = lds + slot * SLOT_BYTES;
-                if constexpr (!(ABL & 2)) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
-                    if constexpr (!ROLL) {
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
 #pragma unroll
-                        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
-                    }
-                } else if (v == 0) {  // laboratory: fragments read once per tile only
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * RB);
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
-                }
+                for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(b + xoff + j * 16 * RB);
             }
             bool issued = false;
-            int kissue = -1;  // CDMA: K step (of this or the next tile) whose stage is issued during C(v)
-            if constexpr (!(ABL & 1)) {
-                if (v + D < nk) {
-                    if constexpr (CDMA) kissue = v + D;
-                    else stage(v + D, pslot);
-                    issued = true;
-                } else if (has_next) {
-                    if (v + D == nk) set_sources(next);
-                    if constexpr (CDMA) kissue = v + D - nk;
-                    else stage(v + D - nk, pslot);
-                    issued = true;
-                }
+            if (v + D < nk) {
+                stage(v + D, pslot);
+                issued = true;
+            } else if (has_next) {
+                if (v + D == nk) set_sources(next);
+                stage(v + D - nk, pslot);
+                issued = true;
             }
             // the stage of step v+1 must have landed; younger stages (and, right after an epilogue, its 16
             // stores) may stay in flight
-            if constexpr (CDMA) {
-                // outstanding here: stages v+1 .. v+D-1 (stage v+D follows in C(v)); `issued_prev` = stage v+D-1 exists
-                if (issued_prev) {
-                    if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0)
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2) + 16) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2)) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                issued_prev = issued;
-            } else if (issued) {
+            if (issued) {
                 if (BF16_OUT && EPI != BSI_EPI_BIAS_GELU_DUAL && after_e > 0)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1) + 16) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
@@ -786,36 +722,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             PHASE_BARRIER();
             // ---- C(v)
             __builtin_amdgcn_s_setprio(1);
-            if constexpr (ROLL) {
-                const char* bnx = lds + ((slot == R - 1) ? 0 : slot + 1) * SLOT_BYTES;  // stage v+1 (landed before this phase)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) {
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    xf[j] = *reinterpret_cast<const bf16x8*>(bnx + xoff + j * 16 * RB);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else if constexpr (CDMA) {
-                char* pbase = lds + pslot * SLOT_BYTES + wave * 1024;
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    if ((j & 1) && kissue >= 0) {
-                        const int q = j >> 1;
-                        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc[q] + (size_t)kissue * KSB), LDS_PTR(pbase + q * NW * 1024), 16, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-            }
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
             PHASE_BARRIER();
@@ -832,13 +743,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
         tile = next;
     }
     if (wm == 0) PHASE_BARRIER();
-    if constexpr (ABL & 64) {
-        if (blockIdx.x == 0 && tid == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out2);
-            o[0] = __builtin_readcyclecounter() - clk0;
-            o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-        }
-    }
 #undef PHASE_BARRIER
 }
 
@@ -854,7 +758,7 @@ int num_cus();
 // A(G+2) at ks = 1; everything needed at P+1 has then been in flight for at least two phases (the cover that a 3-slot
 // K = 32 ring has and that costs nothing).  The issue stream runs ahead of the compute across tile boundaries with its
 // own tile pointer.
-template <int EPI, int ABL = 0>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p) {
     constexpr int TM = 8, NW = 8;
     constexpr int BM = 256, BN = 256, RB = 128;
@@ -867,39 +771,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     const int wm = wave >> 2, wn = wave & 3;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int xcd = blockIdx.x & 7, wl0 = blockIdx.x >> 3;
-    const int wpx0 = (gridDim.x + 7 - xcd) >> 3;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo0 = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi0 = lo0 + q8 + (xcd < r8 ? 1 : 0);
-    // Phase groups (p.groups = 2 or 4; 1 = off): the XCD's workgroups split into groups that walk their own contiguous share of
-    // its tiles (a 4 x 32/(4 groups) block per round instead of 4 x 8) and START a fraction of a tile period apart, so that the
-    // XCD's output bursts -- 32 epilogues at once saturate its ~0.55 TB/s write path for 7.6 us per tile, 8 of them take 2 us --
-    // fall under the other groups' main loops.  Workgroups of one group stay in lockstep, which the L2 sharing of their A / W
-    // panels needs (a per-workgroup stagger loses it).
-    int wl = wl0, wpx = wpx0, lo = lo0, hi = hi0, group = 0;
-    if (p.groups > 1 && wpx0 % p.groups == 0) {
-        const int per = wpx0 / p.groups;
-        group = wl0 / per;
-        wl = wl0 - group * per;
-        wpx = per;
-        const int span = hi0 - lo0, qg = span / p.groups, rg = span % p.groups;
-        lo = lo0 + group * qg + min(group, rg);
-        hi = lo + qg + (group < rg ? 1 : 0);
-    }
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + wl;
     if (tile >= hi) return;
     const int nk = p.K / 64;
-    unsigned long long clk0 = 0, rt0 = 0;
-    if constexpr (ABL & 64) {  // laboratory builds: shader clock over the kernel = d(s_memtime) / d(s_memrealtime) * 100 MHz
-        clk0 = __builtin_readcyclecounter();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-    // laboratory (ABL & 131072): static priority for the second-dispatched wave group instead of a flip around every MFMA phase
-    constexpr bool STATIC_PRIO = (ABL & 131072) != 0;
-    if constexpr (STATIC_PRIO) {
-        if (wm == 1) __builtin_amdgcn_s_setprio(1);
-    }
 
     // ---- issue stream: half-stages in the order A(0) W(0) A(1) W(1) ... over this workgroup's tiles
     const int srow = lane >> 3, spos = lane & 7;
@@ -921,31 +800,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             gW[q] = (unsigned)n * (unsigned)(p.ldw * 2) + ((spos ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1))) << 4);
         }
     };
-    // ABL & 65536 (laboratory): the issue stream never ends -- past the last tile it re-reads that tile's panels into ring slots that
-    // are free -- so every phase issues and every vmcnt allowance is an immediate.  +2-4 % per kernel in the laboratory loop
-    // (LAB_REGULAR), +0.25 % on the sampling loop (A/B of two builds on one box): not worth surplus loads in the product.
-    constexpr bool REGULAR = (ABL & 65536) != 0;
     auto issue_next = [&]() -> bool {  // issues one half-stage; false when the stream is exhausted
-        if (!REGULAR && itile >= hi) return false;
+        if (itile >= hi) return false;
         char* base = lds + islot * HALF + wave * 1024;
         const size_t koff = (size_t)iv * 128;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* src = ihalf ? Wb + koff + gW[q] : Ab + koff + gA[q];
-            // laboratory: cache-policy bits of the LDS-DMA loads (ABL 2048 / 4096: nt on the A / W half-stages, 8192 / 16384: sc1)
-            if constexpr ((ABL & (2048 | 4096 | 8192 | 16384)) != 0) {
-                if (ihalf) {
-                    if constexpr (ABL & 4096) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 2);
-                    else if constexpr (ABL & 16384) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 16);
-                    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
-                } else {
-                    if constexpr (ABL & 2048) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 2);
-                    else if constexpr (ABL & 8192) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 16);
-                    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
-                }
-            } else {
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + q * NW * 1024), 16, 0, 0);
         }
         islot = islot == 4 ? 0 : islot + 1;
         if (ihalf) {
@@ -981,7 +843,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
         asm volatile("" : "+s"(t));
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
-        wave_tile_epilogue<EPI, ABL, false, BF16_OUT>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
+        wave_tile_epilogue<EPI, false, BF16_OUT>(p, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, nullptr);
     };
     auto init_acc = [&](int t) {  // bf16 epilogues: accumulators start at the bias of their column (lane owns n = nb .. nb+15)
         f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1003,16 +865,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
     };
 
-    // start stagger: workgroups begin (and so reach their epilogues) spread over `stagger` * 16 * 64 clocks, so that the output
-    // tiles of all CUs do not hit the memory system in one burst
-    if (p.stagger > 0) {
-        const int n = ((blockIdx.x >> 3) & 15) * p.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    if (group > 0) {  // group g starts g / groups of a tile period late: group_delay = that fraction in units of 64 clocks
-        const int n = group * p.group_delay;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase
     set_sources(tile);
     issue_next();
@@ -1042,11 +894,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 // ---- L(v, ks): DMA issue (unless it went out in front of an epilogue), fragment reads
-                bool issued = false;
-                if constexpr (!(ABL & 1)) {
-                    if (pre) { issued = pre_status; pre = false; }
-                    else issued = issue_next();
-                }
+                bool issued;
+                if (pre) { issued = pre_status; pre = false; }
+                else issued = issue_next();
                 {
                     const int cx = ((ks * 4 + qd) ^ xkey) << 4, cw = ((ks * 4 + qd) ^ wkey) << 4;
 #pragma unroll
@@ -1069,15 +919,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
                 // ---- C(v, ks)
-                if constexpr (!STATIC_PRIO) __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                if constexpr (!STATIC_PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 if (ks == 1 && v == nk - 1 && wm == 1) {  // group B: before the barrier that ends its last C phase
-                    if constexpr (!(ABL & 1)) { pre_status = issue_next(); pre = true; }
+                    pre_status = issue_next();
+                    pre = true;
                     epilogue(tile);
                 }
                 PHASE_BARRIER();
@@ -1086,26 +937,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             sw = sw >= 3 ? sw - 3 : sw + 2;
         }
         if (wm == 0) {  // group A: after that barrier, i.e. at the start of its next load phase
-            if constexpr (!(ABL & 1)) { pre_status = issue_next(); pre = true; }
+            pre_status = issue_next();
+            pre = true;
             epilogue(tile);
         }
         {   // the store allowance of the next phases is valid only if every store of the epilogue is issued (no M / N tail)
             int tm_, tn_;
             tile_coords(p, tile, tm_, tn_);
-            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N && !(ABL & (4 | 128))) ? 3 : 0;
+            after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 3 : 0;
         }
         if (!has_next) break;
         tile = next;
     }
-    if constexpr (REGULAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus loads land before the LDS is released
     if (wm == 0) PHASE_BARRIER();
-    if constexpr (ABL & 64) {
-        if (tid == 0) {  // one (cycles, 100 MHz ticks) pair per workgroup
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out2) + 2 * blockIdx.x;
-            o[0] = __builtin_readcyclecounter() - clk0;
-            o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-        }
-    }
 #undef PHASE_BARRIER
 }
 
@@ -1124,7 +968,6 @@ int launch_cfg(const GemmParams& p0, hipStream_t s) {
 }
 
 int g_variant = 12;  // 12: production (K = 64 half-stage ring + K = 32 ring), 6: K = 32 ring only
-int g_stagger = 0;   // laboratory: start stagger of the persistent kernels, units of 16 x 64 clocks
 int g_gm = 4;  // band height: 4 m-tiles x 8 n-tiles per XCD round minimises L2 misses (PMC: fc1 605 -> 403 MB per launch)
 int g_num_cus[64] = {};
 
@@ -1149,7 +992,6 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 5 * (size_t)256 * 128;
-    p.stagger = g_stagger;
     auto kern = gemm_bf16_k64r_kernel<EPI>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
@@ -1157,18 +999,17 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     return BSI_OK;
 }
 
-template <int EPI, bool ROLL = false, bool CDMA = false>
+template <int EPI>
 int launch_pring(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
-    p.stagger = g_stagger;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
-    auto kern = gemm_bf16_pring_kernel<EPI, 0, ROLL, 4, CDMA>;
+    auto kern = gemm_bf16_pring_kernel<EPI>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16");
@@ -1248,7 +1089,7 @@ int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t
     const int nwg = p.tiles_m * p.tiles_n * splits;
     const int grid = nwg < num_cus() ? nwg : num_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
-    auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32, 0, false, 4, false>;
+    auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
     BSI_CHECK_LAUNCH("bsi_gemm_bf16_ws");
@@ -1268,7 +1109,6 @@ extern "C" int bsi_gemm_set_variant(int v) {
                   "bsi_gemm_set_variant: unknown variant %d (12 = production, 6 = K = 32 ring; the other round-1 schedules live in "
                   "tools/experiments/gemm_variants.inc)", v & 0xff);
     g_variant = v & 0xff;
-    g_stagger = (v >> 8) & 0xff;  // bits 8..15: start stagger, in units of 64 clocks per step
     g_gm = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) : 4;  // bits 16..23: band height of the tile walk
     return BSI_OK;
 }

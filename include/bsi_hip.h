@@ -243,8 +243,8 @@ int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumul
                     bsi_stream_t stream);
 
 /* Testing hook: schedule of the large-tile GEMM.  12 (default) = bf16-output epilogues on the K = 64 half-stage ring, fp32-output
- * ones on the K = 32 ring; 6 = the K = 32 ring for every epilogue (A/B partner of the full-size tests).  Bits 8..15: start
- * stagger (laboratory), bits 16..23: band height of the tile walk.  The two schedules agree to one bf16 ulp. */
+ * ones on the K = 32 ring; 6 = the K = 32 ring for every epilogue (A/B partner of the full-size tests).  Bits 16..23: band
+ * height of the tile walk (0 = the default 4).  The two schedules agree to one bf16 ulp. */
 int bsi_gemm_set_variant(int variant);
 
 /* dit.py:50-55,66,96: out_bf16[m,:] = LayerNorm(x[m,:]; eps, no affine) * (1 + scale[row]) + shift[row]

@@ -12,7 +12,7 @@
 #include "../../bsi_amd/csrc/bsi_ops.hip"  // bsi_set_error
 
 template <int EPI, int ABL>
-float time_pp(GemmParams p, int iters) {
+float time_pp(LabParams p, int iters) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     const size_t lds = 2 * 512 * ROW_BYTES;
@@ -31,12 +31,12 @@ float time_pp(GemmParams p, int iters) {
 }
 
 template <int EPI, int ABL, int RING = 4>
-float time_pring(GemmParams p, int iters) {
+float time_pring(LabParams p, int iters) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = 4;
     const size_t lds = RING == 4 ? 4 * 512 * 64 + 32768 : RING * 512 * 64;  // RING 5: no epilogue scratch (ABL & 4 only)
-    auto kern = gemm_bf16_pring_kernel<EPI, ABL, false, RING>;
+    auto kern = lab_pring_kernel<EPI, ABL, false, RING>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -52,7 +52,7 @@ float time_pring(GemmParams p, int iters) {
 }
 
 template <int EPI, int ABL>
-float time_w1(GemmParams p, int iters) {
+float time_w1(LabParams p, int iters) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = 4;
@@ -128,13 +128,13 @@ static void dma_bench() {
 }
 
 template <int EPI, int ABL>
-float time_k64r(GemmParams p, int iters, int gm = 4, int grid = 256, int groups = 0, int group_delay = 0, int ng = 0) {
+float time_k64r(LabParams p, int iters, int gm = 4, int grid = 256, int groups = 0, int group_delay = 0, int ng = 0) {
     p.groups = groups; p.group_delay = group_delay; p.ng = ng;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.gm = gm;
     const size_t lds = 5 * 256 * 128;
-    auto kern = gemm_bf16_k64r_kernel<EPI, ABL>;
+    auto kern = lab_k64r_kernel<EPI, ABL>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -164,7 +164,7 @@ int main() {
         hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
         hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
         hipMemset(dB, 0, sh.N * 4);
-        GemmParams p{};
+        LabParams p{};
         p.A = (const __bf16*)dA; p.W = (const __bf16*)dW; p.bias = dB; p.out = dO;
         p.M = M; p.N = sh.N; p.K = sh.K; p.lda = sh.K; p.ldw = sh.K; p.ldo = sh.N; p.tokens = 256;
         const double fl = 2.0 * M * sh.N * sh.K;
@@ -174,7 +174,7 @@ int main() {
             // shader clock under load for two operand distributions: the narrow-exponent lab data above, and N(0,1)
             // activations x U(-1/sqrt(K), 1/sqrt(K)) weights (what the model feeds the kernel)
             unsigned long long* dC; hipMalloc(&dC, 64);
-            GemmParams q = p; q.out2 = dC;
+            LabParams q = p; q.out2 = dC;
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) {
                     auto f2b = [](float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
@@ -228,7 +228,7 @@ int main() {
                 }
             }
             for (int ncu : {256, 64}) {  // shader clock of the production schedule (stamps in a laboratory instance only)
-                GemmParams q = p;
+                LabParams q = p;
                 q.M = 256 * ncu; q.out2 = dC;
                 for (int abl : {0, 1}) {
                     const float ms = abl ? time_k64r<E, 64 | 1 | 4>(q, 50, 4, ncu) : time_k64r<E, 64>(q, 50, 4, ncu);
@@ -294,7 +294,7 @@ int main() {
             // number of tiles per workgroup (M = 256 rows per workgroup) on 256 / 64 / 16 / 8 CUs: time per tile with the stores,
             // without them, without the epilogue.
             for (int ncu : {256, 64, 16, 8}) {
-                GemmParams q = p;
+                LabParams q = p;
                 q.M = 256 * ncu;
                 const int tiles_per_wg = (sh.N + 255) / 256;
                 const float f = time_k64r<E, 0>(q, 20, 4, ncu), ns = time_k64r<E, 128>(q, 20, 4, ncu), ne = time_k64r<E, 4>(q, 20, 4, ncu);
@@ -375,7 +375,7 @@ int main() {
         rep("full + L2 prefetch", time_pp<E, 16>(p, 20));
         rep("no epi + L2 prefetch", time_pp<E, 20>(p, 20));
         for (int st : {8, 16, 32, 64, 128}) {
-            GemmParams q = p; q.stagger = st;
+            LabParams q = p; q.stagger = st;
             char nm[64]; snprintf(nm, sizeof nm, "full stagger %d", st);
             rep(nm, time_pp<E, 0>(q, 20));
         }

@@ -40,9 +40,12 @@ def pmc_traffic(batch):
     try:
         with open(path) as f:
             rec = json.load(f)
-        return rec["traffic_bytes_per_launch"] if rec.get("images_per_gpu") == batch else None
+        if rec.get("images_per_gpu") != batch:
+            return None, None
+        m = rec.get("measured", {})
+        return rec["traffic_bytes_per_launch"], f"profiles/fc1_traffic.json ({m.get('date', '?')}, commit {m.get('commit', '?')}; rocprofv3 PMC passes, not this run)"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def parse():
@@ -478,7 +481,7 @@ def main():
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
             "model_frac_of_peak": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.batch),
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(a.batch)[0], "traffic_source": pmc_traffic(a.batch)[1],
                          "kernel": N.fc1_kernel_name(),
                          "launches": cnt, "avg_launch_ms": avg_ms, "flops_per_launch": flops_per_launch},
         }

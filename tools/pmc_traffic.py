@@ -41,6 +41,8 @@ def main():
         "write_bytes": wr["mean_kib"] * 1024.0,
         "traffic_bytes_per_launch": 2.0 * fe["mean_kib"] * 1024.0 + wr["mean_kib"] * 1024.0,
         "correction": "FETCH_SIZE x2 (gfx950 wide-stream undercount), KiB -> bytes; WRITE_SIZE KiB -> bytes",
+        "measured": {"date": __import__("datetime").date.today().isoformat(), "commit": os.environ.get("BSI_COMMIT", "unknown"),
+                     "how": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --k 4 --steps 1 --warmup 1`"},
     }
     with open(out, "w") as f:
         json.dump(res, f, indent=1)

@@ -11,6 +11,8 @@
 // Schedule = the persistent deep-ring ping-pong of gemm_bf16.hip variant 6 with tile 512 (pixels) x 128 (C_out):
 // C_out is 128 everywhere in the UNet, so the tile is made tall instead of wide; waves keep the 128 x 64 sub-tile.
 // LDS: a ring of 4 stages of (512 + 128) rows x 64 B = 160 KB; the epilogue needs no scratch (DPP row-pair exchange).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -448,9 +450,13 @@ constexpr int S_WSLOTS = 8, S_WD = 6, S_WSTAGE = C_BN * C_RB;                   
 constexpr int S_WRING = 2 * S_SLAB, S_ZERO = S_WRING + S_WSLOTS * S_WSTAGE, S_LDS = S_ZERO + 256;  // S_ZERO is 256-B aligned
 static_assert(S_ZERO % 256 == 0, "the zero region mirrors the bank position of the address it replaces");
 
-template <int EPI>
+// WD = image width (16 or 32: a template parameter, so that which fragments of a wave end at a row end is known to the compiler):
+// a fragment is 16 pixels of one image row; at WD = 32 the even fragments of a wave start a row and the odd ones end it, at
+// WD = 16 every fragment does both.
+template <int EPI, int WD>
 __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     constexpr int TM = 8, NW = 8;
+    constexpr unsigned XL = WD == 32 ? 0x55u : 0xffu, XR = WD == 32 ? 0xaau : 0xffu;  // fragments with a pixel in column 0 / WD-1
     constexpr bool BF16_OUT = (EPI < CEPI_BIAS_RESID_F32 || EPI == CEPI_FILM_ROWS_SILU_BF16);
     constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM + (EPI == CEPI_BIAS_RESID_F32_GN ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     int tile = lo + wl;
     if (tile >= hi) return;
     const int nc = p.Cin / 32;
-    const int HW = p.H * p.Wd;
+    const int HW = p.H * WD;
 
     if (tid < 64) reinterpret_cast<float*>(lds + S_ZERO)[tid] = 0.f;  // 256 B of zeros, visible after the prologue's barrier
 
@@ -550,6 +556,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
     const int wcc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
     const int woff = S_WRING + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * C_RB + wcc;
     const int xrow0 = S_HALO + wrow0 + rho;  // slab row of this lane's pixel in fragment 0, before the tap shift
+    const bool edge_lane[2] = {rho == 0, rho == 15};  // the lane of a fragment that looks past the row end under dx = -1 / +1
 
     f32x4 acc[4][TM];
     bf16x8 wf[4], xf[TM];
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         // without the fence they are computed in front of it and live -- spilled -- through it
         asm volatile("" : "+s"(t));
         const int mw0 = (t / p.tiles_n) * C_BM + wrow0, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
-        if (nb0 >= p.N) return;
+        if (nb0 >= p.N || (p.abl & 4)) return;
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
             // FiLM + SiLU per (image, channel); the wave's 128 rows lie in ONE image (launcher: H*W % 128 == 0)
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 
     // the vmcnt allowance may count an epilogue's stores only when every one of them is issued (no row / column tail)
     auto full_tile = [&](int t) {
-        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N;
+        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N && !(p.abl & 4);
     };
     // prologue: slab 0 and weight stages 0 .. S_WD-1; slab 0 and stage 0 must have landed before the first load phase
 #pragma unroll
@@ -627,46 +634,57 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         const bool has_next = next < hi;
         init_acc(tile);
         // border masks of this wave's 8 fragments (16 pixels of one image row each): lane j < 8 evaluates fragment j
-        unsigned ytop, ybot, xl, xr;
+        unsigned ytop, ybot;
         {
             const int R = (tile / p.tiles_n) * C_BM + wrow0 + 16 * (lane & 7);
-            const int rem = R % HW, y = rem / p.Wd, x0 = rem % p.Wd;
+            const int rem = R % HW, y = rem / WD;
             ytop = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == 0) & 0xff));
             ybot = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == p.H - 1) & 0xff));
-            xl = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(x0 == 0) & 0xff));
-            xr = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(x0 + 16 == p.Wd) & 0xff));
         }
         for (int c = 0; c < nc; ++c) {
             const int slab_off = (cg & 1) * S_SLAB;
             const char* slab = lds + slab_off;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+            auto tap = [&](auto T_) {
+                constexpr int t = decltype(T_)::value;
+                constexpr int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                constexpr unsigned ZL = dx < 0 ? XL : dx > 0 ? XR : 0u;  // fragments whose lane 0 (dx < 0) / lane 15 (dx > 0) falls outside
                 // ---- L phase: fragments of (chunk c, tap t)
-                {
+                if (!(p.abl & 16) || (c == 0 && t == 0)) {
                     const char* wb = lds + (P & (S_WSLOTS - 1)) * S_WSTAGE;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + woff + i * 4 * C_RB);
-                    int row = xrow0 + dy * p.Wd + dx;
+                    int row = xrow0 + dy * WD + dx;
                     asm volatile("" : "+v"(row));  // recompute per phase: hoisting the 9 taps' addresses out of the chunk loop costs 20+ VGPRs
                     const int xaddr = row * C_RB + ((qd ^ ((row >> 1) & 3)) << 4);
-                    // the four border words are re-materialised per phase: left to itself the compiler derives a 64-bit lane mask
-                    // for every (tap, fragment) once per tile -- 144 scalar registers, all spilled and read back lane by lane in
-                    // every phase; per phase they are 8 short-lived masks
-                    asm volatile("" : "+s"(ytop), "+s"(ybot), "+s"(xl), "+s"(xr));
+                    // the two row-border words are re-materialised per phase: left to itself the compiler derives a 64-bit lane mask
+                    // for every (tap, fragment) once per tile -- scalar registers that are all spilled and read back in every phase
+                    asm volatile("" : "+s"(ytop), "+s"(ybot));
                     const unsigned zall = dy < 0 ? ytop : dy > 0 ? ybot : 0u;
-                    const unsigned zlane = dx < 0 ? xl : dx > 0 ? xr : 0u;
-                    if ((zall | zlane) == 0) {  // no fragment of this wave touches a border under this tap
+                    if (zall == 0) {  // no fragment of this wave lies in an image row whose tap row is outside (three quarters of the waves)
+                        if constexpr (ZL == 0) {
 #pragma unroll
-                        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(slab + xaddr + j * 16 * C_RB);
+                            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(slab + xaddr + j * 16 * C_RB);
+                        } else {
+                            // column border: WHICH fragments have their edge lane outside is a constant of the tap (ZL), so only that
+                            // lane's address is selected -- the zero region at the bank position of the address it replaces (the
+                            // other 15 rows of its group leave exactly that slot free; j * 1 KB does not move the low 8 bits)
+                            const int a0 = slab_off + xaddr;
+                            const int za = edge_lane[dx < 0 ? 0 : 1] ? S_ZERO + (a0 & 255) : -1;
+#pragma unroll
+                            for (int j = 0; j < TM; ++j) {
+                                if ((ZL >> j) & 1) {  // a constant once the loop is unrolled
+                                    const int a = za >= 0 ? za : a0 + j * 16 * C_RB;
+                                    xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
+                                } else {
+                                    xf[j] = *reinterpret_cast<const bf16x8*>(slab + xaddr + j * 16 * C_RB);
+                                }
+                            }
+                        }
                     } else {
-                        const bool edge_lane = rho == (dx < 0 ? 0 : 15);
+                        const bool el = dx == 0 ? false : edge_lane[dx < 0 ? 0 : 1];
 #pragma unroll
                         for (int j = 0; j < TM; ++j) {
-                            const bool z = ((zall >> j) & 1) || (((zlane >> j) & 1) && edge_lane);
-                            // a zeroed lane reads the zero region at the bank position of the address it replaces: the other
-                            // 15 rows of its group leave exactly that slot free (a fixed zero address cost a 2-way conflict on
-                            // a third of the fragment reads: SQ_LDS_BANK_CONFLICT = 30 % of the LDS cycles)
+                            const bool z = ((zall >> j) & 1) || (((ZL >> j) & 1) && el);
                             const int a0 = slab_off + xaddr + j * 16 * C_RB;
                             const int a = z ? S_ZERO + (a0 & 255) : a0;
                             xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
@@ -674,40 +692,52 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                     }
                 }
                 // ---- issue: next slab piece (taps 0..4), weight stage P + S_WD
-                if (t < 5) {
-                    issue_slab_piece(t);
-                    if (t == 4) advance_slab();
+                if (!(p.abl & 1)) {
+                    if constexpr (t < 5) {
+                        issue_slab_piece(t);
+                        if constexpr (t == 4) advance_slab();
+                    }
+                    issue_w();
+                    if constexpr ((t + S_WD) % 9 == 8) advance_w_chunk();
                 }
-                issue_w();
-                if ((t + S_WD) % 9 == 8) advance_w_chunk();
                 // must have landed: weight stage P+1 (issued in phase P-5) and, at the last tap, the whole next slab (its last
                 // piece was the first instruction of phase P-4): everything issued after those may stay in flight -- a constant
                 // of the tap, plus the stores of an epilogue issued in that window
                 {
                     constexpr int pieces[9] = {1, 2, 3, 4, 5, 4, 3, 2, 0};
+                    constexpr int allow = t == 8 ? 4 : 5 + pieces[t];
                     if (after_e > 0) {
-                        if (t == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NSTORE) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + pieces[t < 9 ? t : 0] + NSTORE) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow + NSTORE) : "memory");
                         --after_e;
                     } else {
-                        if (t == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + pieces[t < 9 ? t : 0]) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
                 // ---- C phase
                 __builtin_amdgcn_s_setprio(1);
+                if (!(p.abl & 2)) {  // (bsi_conv_set_ablation: kernel experiments)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
+                    for (int j = 0; j < TM; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if (t == 8 && c == nc - 1 && wm == 1) { epilogue(tile); after_e = full_tile(tile) ? 5 : 0; }  // group B: before its last barrier
                 PHASE_BARRIER();
                 ++P;
-            }
+            };
+            tap(std::integral_constant<int, 0>{});
+            tap(std::integral_constant<int, 1>{});
+            tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 3>{});
+            tap(std::integral_constant<int, 4>{});
+            tap(std::integral_constant<int, 5>{});
+            tap(std::integral_constant<int, 6>{});
+            tap(std::integral_constant<int, 7>{});
+            tap(std::integral_constant<int, 8>{});
             ++cg;
         }
         if (wm == 0) { epilogue(tile); after_e = full_tile(tile) ? 5 : 0; }  // group A: merged with its next L phase
@@ -737,9 +767,15 @@ int conv_cus() {
 
 template <int EPI>
 int launch_conv_slab(const ConvParams& p, int grid, hipStream_t s) {
-    auto kern = conv_slab_kernel<EPI>;
-    set_max_lds(reinterpret_cast<const void*>(kern), (int)S_LDS);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_LDS, s, p);
+    if (p.Wd == 32) {
+        auto kern = conv_slab_kernel<EPI, 32>;
+        set_max_lds(reinterpret_cast<const void*>(kern), (int)S_LDS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_LDS, s, p);
+    } else {
+        auto kern = conv_slab_kernel<EPI, 16>;
+        set_max_lds(reinterpret_cast<const void*>(kern), (int)S_LDS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_LDS, s, p);
+    }
     BSI_CHECK_LAUNCH("bsi_conv_nhwc_bf16");
     return BSI_OK;
 }
@@ -766,7 +802,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
         // can runs the slab kernel now.
         // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
         // 2048 / 4096 = ring kernel for the FiLM / fp32 epilogues.
-        const bool can = p.taps == 9 && p.Cin2 == 0 && p.Wd % 16 == 0 && p.Wd <= 32 && p.N % C_BN == 0;
+        const bool can = p.taps == 9 && p.Cin2 == 0 && (p.Wd == 16 || p.Wd == 32) && p.N % C_BN == 0;
         constexpr bool F32 = (EPI == CEPI_BIAS_RESID_F32 || EPI == CEPI_BIAS_RESID_F32_GN);
         const bool want = (g_conv_abl & 512) ? true
                           : (g_conv_abl & 256) ? false

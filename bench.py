@@ -48,6 +48,12 @@ def pmc_traffic(batch):
         return None, None
 
 
+# Test hook (tests/test_hip_multigpu.py, one-GPU boxes): BSI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses the gloo backend
+# over device tensors, so that the WHOLE multi-rank code path of this file (self-launch, barriers, max-over-ranks timing, the
+# DPTrainer exchange, the comm breakdown) runs where only one GPU is visible.  Never set by the driver; the line says so in `config`.
+ONE_DEVICE = os.environ.get("BSI_BENCH_ONE_DEVICE") == "1"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -349,7 +355,7 @@ def launch_ranks(a):
     import subprocess
 
     n_dev = torch.cuda.device_count()
-    if n_dev < a.gpus:
+    if n_dev < a.gpus and not ONE_DEVICE:
         print(f"bench.py: --gpus {a.gpus} requested but only {n_dev} GPU(s) are visible; refusing to measure fewer ranks "
               "than asked for", file=sys.stderr)
         return 2
@@ -420,8 +426,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if ONE_DEVICE:
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -477,7 +487,8 @@ def main():
             "config": {"workload": "ImageNet32 DiT-L/2 (dim 1024, depth 24, heads 16, patch 2, Fourier features 6..8), "
                                    f"BSI.sample k={a.k}, EDM preconditioning, {a.batch} images per GPU per call, "
                                    "random-init weights",
-                       "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}"},
+                       "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}",
+                       **({"test_hook": "BSI_BENCH_ONE_DEVICE: all ranks on one GPU over gloo -- not a multi-GPU measurement"} if ONE_DEVICE else {})},
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
             "model_frac_of_peak": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -50,3 +50,20 @@ def test_bench_self_launch_two_ranks():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["train"]["per_gpu_batch"] == 8
+
+
+def test_bench_multi_rank_code_path_on_one_device():
+    """The whole N > 1 path of bench.py (self-launch and supervision, barriers, max-over-ranks timing, DPTrainer exchange with
+    per-block events on the side stream, the communication breakdown of the train record) with two ranks on the ONE GPU of the test
+    box: BSI_BENCH_ONE_DEVICE=1 swaps RCCL for gloo over device tensors and puts both ranks on cuda:0.  Not a measurement."""
+    env = dict(os.environ, BSI_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--k", "4", "--train-steps", "2", "--train-batch", "16"],
+                       capture_output=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "test_hook" in line["config"]
+    tr = line["train"]
+    assert tr["per_gpu_batch"] == 8 and tr["comm"]["buckets"] == 24 + 2 and tr["comm"]["allreduce_bytes"] > 1.9e9
+    assert tr["comm"]["ms_per_step_without_exchange"] > 0 and "exposed_comm_ms" in tr["comm"]
+    assert "secondary" not in line and "cpu_baseline" not in line

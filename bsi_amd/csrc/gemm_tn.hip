@@ -254,6 +254,263 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same GEMM on an LDS image that needs NO swizzle and whose fragment addresses are one per-lane register + immediates.
+// The kernel above reads its fragments through the ds_read_tr builtin, in front of which hipcc puts `s_waitcnt vmcnt(0)` whenever
+// LDS-DMA is in flight: every load phase began by draining the whole operand pipeline (the four-stage look-ahead was a one-stage one),
+// and the XOR swizzle made the 24 fragment addresses 24 registers plus a slot add each per phase.  Here:
+//   * a DMA instruction writes ONE contraction row of each operand: lanes 0-31 the 512 B of the Q row, lanes 32-63 those of the P row
+//     (contiguous in LDS, as the hardware requires); rows sit at a pitch of 1024 + 32 B, so eight consecutive row positions start in
+//     eight disjoint 8-bank windows and the transposed reads (4 rows x 32 B per 16-lane group, two groups per LDS cycle) are conflict
+//     free without any XOR;
+//   * contraction row m of a stage sits at position (m with bits 2 and 3 swapped): the two 16-lane groups of an LDS cycle read rows
+//     8q .. 8q+3 of q = 0, 1 -- positions 0..7 -- and the second read of a fragment (rows + 4) is 8 positions = an immediate further;
+//   * fragment i / j of a wave is 32 B further in the row: the 24 reads of a stage are two per-lane base registers (Q side, P side)
+//     + immediates, as inline asm, behind ONE counted wait; the operand DMA keeps its look-ahead (ring of 4 slots, 3 in flight).
+constexpr int T2_PITCH = 1024 + 32, T2_SLOT = 32 * T2_PITCH, T2_R = 4, T2_D = T2_R - 1;  // 33,792 B per stage, 135 KB
+
+template <int OFF>
+__device__ __forceinline__ s16x4 tn_tr(unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
+// VAR (DMA placement): 0 = all four instructions of a stage in the load phase; otherwise NL = VAR & 3 of them in the load phase and the
+// others inside the MFMA phase, behind the MFMA groups j = (VAR >> 4) & 7 and (VAR >> 8) & 7 (both behind the first when VAR & 0x1000)
+template <int VAR>
+__global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
+    constexpr int NL = VAR == 0 ? 4 : (VAR & 3), JA = (VAR >> 4) & 7, JB = (VAR >> 8) & 7;
+    constexpr bool TOGETHER = (VAR & 0x1000) != 0;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave >> 2;   // ping-pong group; also the n half (128 columns) of the tile
+    const int wk = wave & 3;    // 64-wide k slice
+
+    const int tiles = p.tiles_n * p.tiles_k;
+    int tile_n, tile_k, split;
+    if (p.xcd_map) {  // XCD-aware order, as gemm_tn_kernel
+        const int L = (int)gridDim.x, b = (int)blockIdx.x;
+        const int x = b & 7, lo = L >> 3, rem = L & 7;
+        const int id = x * lo + min(x, rem) + (b >> 3);
+        split = id / tiles;
+        const int t = id - split * tiles;
+        const bool k_fast = p.tiles_k <= p.tiles_n;
+        const int F = k_fast ? p.tiles_k : p.tiles_n, S = k_fast ? p.tiles_n : p.tiles_k;
+        const int band = t / (4 * S), r = t - band * 4 * S;
+        const int w = min(4, F - 4 * band);
+        const int sl = r / w, f = 4 * band + (r - sl * w);
+        tile_n = k_fast ? sl : f;
+        tile_k = k_fast ? f : sl;
+    } else {
+        const int tile = blockIdx.x % tiles;
+        split = blockIdx.x / tiles;
+        tile_n = tile / p.tiles_k;
+        tile_k = tile % p.tiles_k;
+    }
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int nk = (mend - mbeg + 31) / 32;
+
+    // ---- staging: instruction t = q * 8 + wave (q < 4) fills position t; lanes 0-31: Q row, lanes 32-63: P row, 16 B per lane
+    const bool pside = lane >= 32;
+    const int c16 = lane & 31;
+    const char* gbase;  // this lane's column of its operand
+    unsigned ldb;       // row pitch in bytes of its operand
+    {
+        int col = (pside ? n0 : k0) + c16 * 8;
+        col = col < (pside ? p.N : p.K) ? col : 0;  // columns beyond the matrix are never stored
+        gbase = reinterpret_cast<const char*>((pside ? p.P : p.Q) + col);
+        ldb = (unsigned)(pside ? p.ldp : p.ldq) * 2u;
+    }
+    int mrow[4];  // contraction row (within the stage) of instruction q: position t holds row (t with bits 2 and 3 swapped)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = q * 8 + wave;
+        mrow[q] = (t & 19) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3);
+    }
+    auto stage_one = [&](int v, int slot_i, int q) {  // instruction q of a stage
+        char* base = lds + slot_i * T2_SLOT;
+        int m = mbeg + v * 32 + mrow[q];
+        m = m < mend ? m : mend - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)m * ldb), LDS_PTR(base + (q * 8 + wave) * T2_PITCH), 16, 0, 0);
+    };
+
+    auto stage = [&](int v, int slot_i) {
+        char* base = lds + slot_i * T2_SLOT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int m = mbeg + v * 32 + mrow[q];
+            m = m < mend ? m : mend - 1;  // tail rows are masked to zero contribution below (nk rounds up)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)m * ldb), LDS_PTR(base + (q * 8 + wave) * T2_PITCH), 16, 0, 0);
+        }
+    };
+
+    // ---- fragments: lane = (q, q', pp): rows 8q + q' (+4), 4-column quad pp; position of row 8q + q' = q' + 4 (q & 1) + 16 (q >> 1)
+    const int q = lane >> 4, qp = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned posb = (unsigned)(qp + 4 * (q & 1) + 16 * (q >> 1)) * T2_PITCH + 8u * pp;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const unsigned aq0 = lds0 + posb + 128u * wk, ap0 = lds0 + posb + 512u + 256u * wg;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    union U { bf16x8 v; s16x4 h[2]; };
+    U af[4], bf[8];
+    int cs_j[2] = {-1, -1};  // fused bias gradient: this wave's column units, as in gemm_tn_kernel
+    if (p.colsum != nullptr) {
+        const int cs = p.tiles_k < 16 ? p.tiles_k : 16;
+        int seen = 0;
+        for (int j = 0; j < 8; ++j) {
+            if ((8 * wg + j) % cs != tile_k) continue;
+            if ((seen & 3) == wk) cs_j[seen >> 2] = j;
+            ++seen;
+        }
+    }
+    const bool do_colsum = cs_j[0] >= 0;
+    f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+#define TN_BARRIER()                             \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+#pragma unroll
+    for (int d = 0; d < T2_D; ++d)
+        if (d < nk) stage(d, d);
+    if (nk >= T2_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T2_D - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TN_BARRIER();
+    if (wg == 1) TN_BARRIER();
+
+    int slot = 0, pslot = T2_D;
+    for (int v = 0; v < nk; ++v) {
+        if (!(p.abl & 4) || v == 0) {  // (BSI_TN_ABL: laboratory flags, as in gemm_tn_kernel)
+            const unsigned so = (unsigned)slot * T2_SLOT;
+            const unsigned aq = aq0 + so, ap = ap0 + so;
+            constexpr int HB = 8 * T2_PITCH;  // rows + 4 = 8 positions further
+            af[0].h[0] = tn_tr<0>(aq);   af[0].h[1] = tn_tr<HB>(aq);
+            af[1].h[0] = tn_tr<32>(aq);  af[1].h[1] = tn_tr<HB + 32>(aq);
+            af[2].h[0] = tn_tr<64>(aq);  af[2].h[1] = tn_tr<HB + 64>(aq);
+            af[3].h[0] = tn_tr<96>(aq);  af[3].h[1] = tn_tr<HB + 96>(aq);
+            bf[0].h[0] = tn_tr<0>(ap);   bf[0].h[1] = tn_tr<HB>(ap);
+            bf[1].h[0] = tn_tr<32>(ap);  bf[1].h[1] = tn_tr<HB + 32>(ap);
+            bf[2].h[0] = tn_tr<64>(ap);  bf[2].h[1] = tn_tr<HB + 64>(ap);
+            bf[3].h[0] = tn_tr<96>(ap);  bf[3].h[1] = tn_tr<HB + 96>(ap);
+            bf[4].h[0] = tn_tr<128>(ap); bf[4].h[1] = tn_tr<HB + 128>(ap);
+            bf[5].h[0] = tn_tr<160>(ap); bf[5].h[1] = tn_tr<HB + 160>(ap);
+            bf[6].h[0] = tn_tr<192>(ap); bf[6].h[1] = tn_tr<HB + 192>(ap);
+            bf[7].h[0] = tn_tr<224>(ap); bf[7].h[1] = tn_tr<HB + 224>(ap);
+        }
+        const bool split_issue = NL < 4 && v + T2_D < nk;
+        if (split_issue) {
+            // NL instructions now; outstanding then: stages v+1, v+2 (8) + NL -> stage v+1 has landed when at most 4 + NL are left
+#pragma unroll
+            for (int qq = 0; qq < NL; ++qq) stage_one(v + T2_D, pslot, qq);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + (NL < 4 ? NL : 0)) : "memory");
+        } else if (v + T2_D < nk && !(p.abl & 2)) {
+            stage(v + T2_D, pslot);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T2_D - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15 %16 %17 %18 %19 %20 %21 %22 %23"
+                     : "+v"(af[0].h[0]), "+v"(af[0].h[1]), "+v"(af[1].h[0]), "+v"(af[1].h[1]), "+v"(af[2].h[0]), "+v"(af[2].h[1]),
+                       "+v"(af[3].h[0]), "+v"(af[3].h[1]), "+v"(bf[0].h[0]), "+v"(bf[0].h[1]), "+v"(bf[1].h[0]), "+v"(bf[1].h[1]),
+                       "+v"(bf[2].h[0]), "+v"(bf[2].h[1]), "+v"(bf[3].h[0]), "+v"(bf[3].h[1]), "+v"(bf[4].h[0]), "+v"(bf[4].h[1]),
+                       "+v"(bf[5].h[0]), "+v"(bf[5].h[1]), "+v"(bf[6].h[0]), "+v"(bf[6].h[1]), "+v"(bf[7].h[0]), "+v"(bf[7].h[1]));
+        if (mbeg + v * 32 + 32 > mend) {
+            // ragged tail: rows >= mend were clamped to a valid address; zero their contribution (element e of a fragment
+            // is contraction row 8q + e)
+            const int valid = mend - (mbeg + v * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (8 * q + e >= valid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i].v[e] = (__bf16)0.0f;
+                }
+            }
+        }
+        bf16x8 onesf;
+        {
+            const int valid = mend - (mbeg + v * 32);  // >= 32 except in the ragged tail stage
+#pragma unroll
+            for (int e = 0; e < 8; ++e) onesf[e] = (8 * q + e < valid) ? (__bf16)1.0f : (__bf16)0.0f;
+        }
+        // priority goes to the LOAD phase (the phase that sets the interval: 24 transposed reads + its share of the DMA issue), not to
+        // the MFMA phase as in the forward GEMM: +1.5-2.5 % (tools/tn_bench.py, profiles/r3/tn_ab.txt)
+        __builtin_amdgcn_s_setprio(0);
+        TN_BARRIER();
+        if (!(p.abl & 8)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i].v, bf[j].v, acc[i][j], 0, 0, 0);
+                if (NL < 4 && split_issue) {  // the other 4 - NL instructions, inside the MFMA phase (placement: template parameter)
+                    if (j == JA) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_one(v + T2_D, pslot, NL);
+                        if constexpr (TOGETHER) {
+#pragma unroll
+                            for (int qq = NL + 1; qq < 4; ++qq) stage_one(v + T2_D, pslot, qq);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!TOGETHER && NL < 3 && j == JB) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int qq = NL + 1; qq < 4; ++qq) stage_one(v + T2_D, pslot, qq);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        if (do_colsum) {  // wave-uniform unit indices: branches, not register selects (selecting the fragment with 28
+                                            // scalar-condition vector selects instead of the compare-and-branch chain measured 2-4 % SLOWER)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (cs_j[u] < 0) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cs_j[u] == j) accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, bf[j].v, accb[u], 0, 0, 0);
+            }
+        }
+        TN_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        slot = (slot == T2_R - 1) ? 0 : slot + 1;
+        pslot = (pslot == T2_R - 1) ? 0 : pslot + 1;
+    }
+    if (wg == 0) TN_BARRIER();
+#undef TN_BARRIER
+
+    if (do_colsum && lane < 16) {  // D row 0 (lanes 0..15, register 0) holds the column sums
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (cs_j[u] < 0) continue;
+            const int n = n0 + 128 * wg + 16 * cs_j[u] + lane;
+            if (n < p.N) p.colsum[(size_t)split * p.colsum_stride + n] = accb[u][0];
+        }
+    }
+    float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 128 * wg + 16 * j + (lane & 15);
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 64 * wk + 16 * i + 4 * q;
+            if (k < p.K) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(out + (size_t)n * p.ldc + k));
+        }
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits, size_t n4,
                                     int accumulate, float* __restrict__ out) {
@@ -495,8 +752,26 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
     static const int abl = [] { const char* e = getenv("BSI_TN_ABL"); return e ? atoi(e) : 0; }();
     p.xcd_map = !(abl & 1);
     p.abl = abl;
-    set_max_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T_R * T_SLOT);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
+    if (abl & 16) {  // BSI_TN_ABL & 16: the round-2 kernel (A/B partner)
+        set_max_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T_R * T_SLOT);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T_R * T_SLOT, s, p);
+    } else {
+        auto go = [&](auto kern) {
+            set_max_lds(reinterpret_cast<const void*>(kern), T2_R * T2_SLOT);
+            hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T2_R * T2_SLOT, s, p);
+        };
+        // DMA placement.  Without the fused bias gradient: two of a stage's four instructions per wave in the load phase, two behind
+        // the second group of four MFMAs -- with all four in the load phase a wave sits in four back-to-back issues while the
+        // addresser queue is full (the memory system delivers about 30 B/clk per CU to this stream: a DMA-only run takes 594 us for
+        // fc1's 8.6 GB) before it can start its 24 fragment reads: +4-10 % (qkv 970 -> 1010, out 820 -> 880, fc1 1134 -> 1169, fc2
+        // 1123 -> 1220 TFLOP/s on one box).  WITH the bias gradient (every Linear of the DiT) the MFMA phase carries the unit MFMAs and
+        // their compare chain and the split measured 3-6 % SLOWER than all four in the load phase on three boxes of the pool and 8 %
+        // faster on a fourth (a slower one): no clear winner, those launches keep all four in the load phase.  (The unit MFMAs moved
+        // into the load phase instead: 10-12 % slower.)
+        // Placements tried: behind groups 1 / 3 / 5 / 7, one behind 2 and one behind 6, 3 + 1, 1 + 3, 1 + 1 + 2 (profiles/r3/tn_ab.txt).
+        if ((abl & 32) || (p.colsum != nullptr && !(abl & 64))) go(gemm_tn2_kernel<0>);  // BSI_TN_ABL & 64: split also with the bias gradient
+        else go(gemm_tn2_kernel<0x1012>);
+    }
     BSI_CHECK_LAUNCH("bsi_gemm_tn_bf16");
     if (!direct) {
         if (colsum_out) {

@@ -196,6 +196,19 @@ int main() {
             }
             continue;
         }
+        if (getenv("LAB_SPLIT")) {
+            // round 3: A half-stages' DMA issue split between the load phase and the MFMA phase (ABL 262144)
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            for (int r = 0; r < 3; ++r) {
+                rep("production issue", time_k64r<E, 0>(p, 20));
+                rep("split A half-stages", time_k64r<E, 262144>(p, 20));
+                if (sh.N == 4096) {
+                    rep("gelu production issue", time_k64r<G, 0>(p, 20));
+                    rep("gelu split A half-stages", time_k64r<G, 262144>(p, 20));
+                }
+            }
+            continue;
+        }
         if (getenv("LAB_NS")) {
             // round 3: n-stationary tile order (an XCD keeps ng weight panels across rounds) x band height x skewed phase groups
             // that share those panels, static priority, and the shader clock of the production schedule on 256 / 64 CUs

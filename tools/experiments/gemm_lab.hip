@@ -196,6 +196,21 @@ int main() {
             }
             continue;
         }
+        if (getenv("LAB_DMAONLY")) {
+            // round 3: how long does the operand DMA stream take by itself (no MFMAs, fragments read once, no epilogue), on 256 and on 64 CUs?
+            for (int ncu : {256, 64}) {
+                LabParams q = p;
+                q.M = (M / 256) * ncu;
+                for (int r = 0; r < 2; ++r) {
+                    const float full = time_k64r<E, 0>(q, 20, 4, ncu), dma = time_k64r<E, 2 | 4 | 8>(q, 20, 4, ncu), none = time_k64r<E, 1 | 2 | 4 | 8>(q, 20, 4, ncu),
+                                mf = time_k64r<E, 1 | 4>(q, 20, 4, ncu);
+                    const double bytes = (double)((q.M + 255) / 256) * ((sh.N + 255) / 256) * (512.0 * sh.K * 2.0);
+                    printf("%s %3d CUs: full %.1f us | DMA stream alone %.1f us = %.1f GB/s per CU | barriers alone %.1f us | MFMA + reads, no DMA, no epilogue %.1f us\n", sh.name, ncu,
+                           1e3 * full, 1e3 * dma, bytes / (dma * 1e-3) / 1e9 / ncu, 1e3 * none, 1e3 * mf);
+                }
+            }
+            continue;
+        }
         if (getenv("LAB_SPLIT")) {
             // round 3: A half-stages' DMA issue split between the load phase and the MFMA phase (ABL 262144)
             constexpr int G = BSI_EPI_BIAS_GELU_BF16;

@@ -196,6 +196,20 @@ int main() {
             }
             continue;
         }
+        if (getenv("LAB_EARLYBAR")) {
+            // round 3: the barrier that ends an MFMA phase taken 8 / 16 MFMAs early
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            for (int r = 0; r < 3; ++r) {
+                rep("production", time_k64r<E, 0>(p, 20));
+                rep("barrier 8 MFMAs early", time_k64r<E, 524288>(p, 20));
+                rep("barrier 16 MFMAs early", time_k64r<E, 1048576>(p, 20));
+                if (sh.N == 4096) {
+                    rep("gelu production", time_k64r<G, 0>(p, 20));
+                    rep("gelu barrier 8 MFMAs early", time_k64r<G, 524288>(p, 20));
+                }
+            }
+            continue;
+        }
         if (getenv("LAB_DMAONLY")) {
             // round 3: how long does the operand DMA stream take by itself (no MFMAs, fragments read once, no epilogue), on 256 and on 64 CUs?
             for (int ncu : {256, 64}) {

@@ -28,12 +28,16 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """Achieved parity errors (tests.util.report) as the last lines of the run, one compact line per record, so that a
     `pytest -q` tail shows the numbers behind the green assertions (bounds are in the tests)."""
     try:
-        from tests.util import RECORDS
+        from tests.util import BOUNDS, RECORDS
     except Exception:  # noqa: BLE001
         return
+    tr = terminalreporter
+    if BOUNDS:
+        tr.write_sep("-", "BOUNDS (worst achieved value / asserted limit per check)")
+        for tag, (v, lim) in sorted(BOUNDS.items()):
+            tr.write_line(f"BOUND {tag}: {v:.2e} / {lim:.0e}")
     if not RECORDS:
         return
-    tr = terminalreporter
     tr.write_sep("-", "PARITY (achieved errors; stated tolerances: train_loss mean 1e-4, per sample 1e-3, x_hat 1e-2, gradients 1e-2)")
 
     def fmt(v):

@@ -1,12 +1,12 @@
 """GPU parity tests of the VDM and BFN wrappers (bsi_amd/vdm.py, bsi_amd/bfn.py) on the HIP path against the golden vectors
 generated from the reference's own classes (tests/golden/g9_vdm_*, g10_bfn_*) and the CPU oracles.  The wrapper arithmetic is
 fp32 (tolerances 1e-5..1e-4 where the denoiser is not involved); everything that goes through the bf16 denoiser uses the
-tolerances of tests/test_hip_dit.py (1e-2 on losses and one-step predictions, 3e-2 relative L2 on gradients)."""
+tolerances of tests/test_hip_dit.py (1e-3 on losses, 1e-2 on one-step predictions and on the relative L2 error of every gradient tensor)."""
 import pytest
 import torch
 
 from tests.test_hip_dit import make_model, replay_noise
-from tests.util import golden, max_rel, rel_linf
+from tests.util import bound, golden, max_rel, rel_linf
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -24,12 +24,12 @@ def make_bfn(model, k=8):
     return BFN(model, data_shape=SHAPE, sigma_1=1e-3, k=k, discretization=Discretization.image_8bit()).to(DEV)
 
 
-def _check_grads(model, g, tol=3e-2):
+def _check_grads(model, g, tol=1e-2, tag="grads"):
     for name, p in model.named_parameters():
         ref = g["G." + name]
         assert p.grad is not None, name
         err = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
-        assert err < tol, (name, err)
+        bound(tag, err, tol)
 
 
 def test_vdm_schedule_functions_and_coefficients():
@@ -37,8 +37,8 @@ def test_vdm_schedule_functions_and_coefficients():
     g = golden("g9_vdm_tables")
     t = g["t"].to(DEV)
     for name in ("sigma2", "alpha", "snr"):
-        assert max_rel(getattr(v, name)(t), g[name]) < 2e-6, name
-    assert max_rel(v.gamma(t), g["gamma"]) < 1e-6
+        bound("test_vdm_schedule_functions_and_coefficients:40", max_rel(getattr(v, name)(t), g[name]), 2e-6)
+    bound("test_vdm_schedule_functions_and_coefficients:41", max_rel(v.gamma(t), g["gamma"]), 1e-6)
     with pytest.raises(NotImplementedError):
         v.diffusion_loss(t, 1)
 
@@ -56,16 +56,16 @@ def test_vdm_losses_vs_golden():
     v = make_vdm(make_model())
     with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps_recon"], g["eps_diff"]]):
         elbo, bpd, extra = v.elbo(g["x"].to(DEV), 2, 2, estimate_var=True)
-    assert max_rel(extra["l_prior"], g["l_prior"]) < 1e-5
+    bound("test_vdm_losses_vs_golden:59", max_rel(extra["l_prior"], g["l_prior"]), 1e-5)
     assert max_rel(extra["l_recon"], g["l_recon"]) < 1e-4   # no denoiser involved: fp32 wrapper arithmetic only
-    assert max_rel(extra["l_diff"], g["l_diff"]) < 1e-2
-    assert max_rel(bpd, g["bpd"]) < 1e-3 and max_rel(elbo, g["elbo"]) < 1e-3
-    assert rel_linf(extra["bpd_var"], g["bpd_var"]) < 5e-2
+    bound("test_vdm_losses_vs_golden:61", max_rel(extra["l_diff"], g["l_diff"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:62", max_rel(bpd, g["bpd"]) < 1e-3 and max_rel(elbo, g["elbo"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:63", rel_linf(extra["bpd_var"], g["bpd_var"]), 1e-2)
     g = golden("g9_vdm_finite_elbo")
     with torch.no_grad(), replay_noise(randint=[g["i"]], randn=[g["eps_recon"], g["eps_diff"]]):
         elbo, bpd, extra = v.finite_elbo(g["x"].to(DEV), 2, 2)
-    assert max_rel(extra["l_recon"], g["l_recon"]) < 1e-4 and max_rel(extra["l_diff"], g["l_diff"]) < 1e-2
-    assert max_rel(bpd, g["bpd"]) < 1e-3
+    bound("test_vdm_losses_vs_golden:67", max_rel(extra["l_recon"], g["l_recon"]) < 1e-4 and max_rel(extra["l_diff"], g["l_diff"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:68", max_rel(bpd, g["bpd"]), 1e-3)
     with pytest.raises(AssertionError):
         v.elbo(g["x"].to(DEV), 1, 2, estimate_var=True)
 
@@ -79,17 +79,17 @@ def test_vdm_sampler_teacher_forced_and_free_running():
         for i in range(k):  # one ancestral step from the reference's z_t: x_hat and z_s
             z = g["zs"][i].to(DEV)
             xh = v._predict_x(z, ts[i].repeat(len(z)))
-            assert rel_linf(xh, g["x_hats"][i]) < 2e-2, (i, rel_linf(xh, g["x_hats"][i]))
+            bound("test_vdm_sampler_teacher_forced_and_free_running:82", rel_linf(xh, g["x_hats"][i]), 1e-2)
             with replay_noise(randn=[g["eps"][i]]):
                 zs = v._sample_zs_given_zt_x(ts[i + 1].repeat(len(z)), z, ts[i].repeat(len(z)), g["x_hats"][i].to(DEV))
-            assert rel_linf(zs, g["zs"][i + 1]) < 1e-5, i
+            bound("test_vdm_sampler_teacher_forced_and_free_running:85", rel_linf(zs, g["zs"][i + 1]), 1e-5)
         with replay_noise(randn=[g["eps0"], *g["eps"]]):
             x_hats = v.sample_history(2)
         with replay_noise(randn=[g["eps0"], *g["eps"]]):
             smp = v.sample(2)
     assert torch.equal(smp, x_hats[-1]) and torch.isfinite(smp).all()
     assert rel_linf(x_hats[0], g["x_hats"][0]) < 2e-2   # first step identical inputs; later steps amplify bf16 differences
-    assert rel_linf(x_hats, g["x_hats"]) < 0.25
+    bound("test_vdm_sampler_teacher_forced_and_free_running:92", rel_linf(x_hats, g["x_hats"]), 0.25)
 
 
 def test_bfn_losses_vs_golden():
@@ -105,12 +105,12 @@ def test_bfn_losses_vs_golden():
     b = make_bfn(make_model())
     with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps_recon"], g["eps_latent"]]):
         elbo, bpd, extra = b.elbo(g["x"].to(DEV), 2, 2, estimate_var=True)
-    assert max_rel(extra["l_recon"], g["l_recon"]) < 1e-2 and max_rel(extra["l_latent"], g["l_latent"]) < 1e-2
-    assert max_rel(bpd, g["bpd"]) < 1e-2 and rel_linf(extra["bpd_var"], g["bpd_var"]) < 5e-2
+    bound("test_bfn_losses_vs_golden:108", max_rel(extra["l_recon"], g["l_recon"]) < 1e-2 and max_rel(extra["l_latent"], g["l_latent"]), 1e-3)
+    bound("test_bfn_losses_vs_golden:109", max_rel(bpd, g["bpd"]) < 1e-2 and rel_linf(extra["bpd_var"], g["bpd_var"]), 1e-2)
     g = golden("g10_bfn_finite_elbo")
     with torch.no_grad(), replay_noise(randint=[g["i"]], randn=[g["eps_recon"], g["eps_latent"]]):
         elbo, bpd, extra = b.finite_elbo(g["x"].to(DEV), 2, 2, t=g["t"].to(DEV))
-    assert max_rel(extra["l_latent"], g["l_latent"]) < 1e-2 and max_rel(bpd, g["bpd"]) < 1e-2
+    bound("test_bfn_losses_vs_golden:113", max_rel(extra["l_latent"], g["l_latent"]) < 1e-2 and max_rel(bpd, g["bpd"]), 1e-3)
     with pytest.raises(AttributeError):   # the reference's `self.linspace` quirk
         b.finite_elbo(g["x"].to(DEV), 2, 2)
 
@@ -122,7 +122,7 @@ def test_bfn_predict_and_sampler():
         xh = b._predict_x(g["mu"].to(DEV), g["t"].to(DEV))
     assert float(xh[:2].abs().max()) == 0.0 and float(xh.abs().max()) <= 1.0   # t < t_min -> 0; clipped to [x_min, x_max]
     # row 2 (t = 1e-3): gamma = 0.0137, the bf16 denoiser's error enters multiplied by sqrt((1 - gamma) / gamma) = 8.5
-    assert rel_linf(xh[3], g["x_hat"][3]) < 2e-2 and rel_linf(xh, g["x_hat"]) < 5e-2
+    bound("test_bfn_predict_and_sampler:125", rel_linf(xh[3], g["x_hat"][3]) < 2e-2 and rel_linf(xh, g["x_hat"]), 5e-2)
     g = golden("g10_bfn_hist")
     k = int(g["k"])
     b = make_bfn(make_model(), k=k)
@@ -133,7 +133,7 @@ def test_bfn_predict_and_sampler():
             mu = g["mus"][i].to(DEV)
             ti = t[i] if i < k else t.new_ones(())
             xh = b._predict_x(mu, ti.repeat(len(mu)))
-            assert rel_linf(xh, g["x_hats"][i]) < 2e-2, (i, rel_linf(xh, g["x_hats"][i]))
+            bound("test_bfn_predict_and_sampler:136", rel_linf(xh, g["x_hats"][i]), 1e-2)
         with replay_noise(randn=list(g["eps"])):
             mus, x_hats, ys = b.sample_history(2)
         with replay_noise(randn=list(g["eps"])):
@@ -141,5 +141,5 @@ def test_bfn_predict_and_sampler():
     assert torch.equal(smp, x_hats[-1]) and torch.isfinite(mus).all()
     # rho_{i+1} = rho_i + alpha_i, rho_0 = 1: posterior precision of the refine update
     assert abs(float(rho[0]) - 1) < 1e-7 and rel_linf(rho[1:] - rho[:-1], alpha) < 1e-5
-    assert rel_linf(x_hats[:2], g["x_hats"][:2]) < 2e-2 and rel_linf(mus[:2], g["mus"][:2]) < 2e-2
-    assert rel_linf(x_hats, g["x_hats"]) < 0.3
+    bound("test_bfn_predict_and_sampler:144", rel_linf(x_hats[:2], g["x_hats"][:2]) < 2e-2 and rel_linf(mus[:2], g["mus"][:2]), 1e-5)
+    bound("test_bfn_predict_and_sampler:145", rel_linf(x_hats, g["x_hats"]), 0.3)

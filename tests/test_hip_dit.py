@@ -16,7 +16,7 @@ import torch
 
 from oracle import bsi_oracle as bo
 from oracle import dit_oracle as do
-from tests.util import golden, max_rel, rel_linf, report, weights
+from tests.util import bound, golden, max_rel, rel_linf, report, weights
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -70,9 +70,9 @@ def test_dit_forward_vs_golden_and_bf16_oracle():
         yb = oracle_dit("dit_ff", True, md=torch.bfloat16)(g["mu"], g["t"])
     # vs the fp32 reference: bf16 operand rounding through 2 blocks
     report("tiny_dit_forward", vs_fp32_reference=rel_linf(y, g["out"]), vs_bf16_operand_oracle=rel_linf(y, yb))
-    assert rel_linf(y, g["out"]) < 1e-2, rel_linf(y, g["out"])
+    bound("test_dit_forward_vs_golden_and_bf16_oracle:73", rel_linf(y, g["out"]), 1e-2)
     # vs the oracle with the same rounding points: only accumulation order / transcendental ulp remain
-    assert rel_linf(y, yb) < 4e-3, rel_linf(y, yb)
+    bound("test_dit_forward_vs_golden_and_bf16_oracle:75", rel_linf(y, yb), 4e-3)
 
 
 def test_dit_tokens_blockwise():
@@ -85,7 +85,7 @@ def test_dit_tokens_blockwise():
         W = weights("dit_ff")
         ref = do.dit_forward(W, g["mu"], g["t"], patch_size=2, dim=128, depth=2, heads=2, ff=(6, 8),
                              md=torch.bfloat16, return_tokens=True)
-    assert rel_linf(tok.cpu().reshape(ref.shape), ref) < 4e-3
+    bound("test_dit_tokens_blockwise:88", rel_linf(tok.cpu().reshape(ref.shape), ref), 1e-3)
 
 
 def test_train_loss_value_vs_golden():
@@ -114,7 +114,7 @@ def test_sample_history_teacher_forced_and_free_running():
         for i in range(k + 1):
             mu_i = g["mus"][i].to(DEV)
             xh = bsi._predict_x(mu_i, t_eval[i].repeat(mu_i.shape[0]))
-            assert rel_linf(xh, g["x_hats"][i]) < 1e-2, (i, rel_linf(xh, g["x_hats"][i]))
+            bound("test_sample_history_teacher_forced_and_free_running:117", rel_linf(xh, g["x_hats"][i]), 1e-2)
             if i < k:
                 mu_n = torch.empty_like(mu_i)
                 y = torch.empty_like(mu_i)
@@ -122,8 +122,8 @@ def test_sample_history_teacher_forced_and_free_running():
                 N.check(N.lib().bsi_refine_step(N.ptr(mu_i), N.ptr(xh.contiguous()), N.ptr(eps_i),
                                                 N.ptr(lam), N.ptr(alpha), None, None, i, 1, mu_i.shape[0],
                                                 mu_i[0].numel(), None, N.ptr(y), N.ptr(mu_n), N.stream()))
-                assert rel_linf(mu_n, g["mus"][i + 1]) < 1e-2
-                assert rel_linf(y, g["ys"][i]) < 1e-2
+                bound("test_sample_history_teacher_forced_and_free_running:125", rel_linf(mu_n, g["mus"][i + 1]), 1e-2)
+                bound("test_sample_history_teacher_forced_and_free_running:126", rel_linf(y, g["ys"][i]), 1e-2)
     # --- free-running without Fourier features through the public API
     g = golden("g5_hist_dit_noff")
     bsi = make_bsi(make_model("dit_noff", False), k=int(g["k"]))
@@ -132,8 +132,8 @@ def test_sample_history_teacher_forced_and_free_running():
         mus, xhs, ys = bsi.sample_history(2)
     assert mus.shape == g["mus"].shape and xhs.shape == g["x_hats"].shape and ys.shape == g["ys"].shape
     for i in range(k + 1):
-        assert rel_linf(xhs[i], g["x_hats"][i]) < 3e-2, (i, rel_linf(xhs[i], g["x_hats"][i]))
-        assert rel_linf(mus[i], g["mus"][i]) < 3e-2
+        bound("test_sample_history_teacher_forced_and_free_running:135", rel_linf(xhs[i], g["x_hats"][i]), 1e-2)
+        bound("test_sample_history_teacher_forced_and_free_running:136", rel_linf(mus[i], g["mus"][i]), 1e-2)
     with torch.no_grad(), replay_noise(randn=draws):
         s = bsi.sample(2)
     assert torch.equal(s, xhs[-1])  # sample == last prediction of sample_history, bit for bit
@@ -161,7 +161,7 @@ def test_generic_model_path_tinyconv():
     assert max_rel(loss, g["loss"]) < 1e-4   # fp32 path (MIOpen conv + native wrapper)
     loss.mean().backward()
     for name, p in m.named_parameters():
-        assert rel_linf(p.grad, g["G." + name]) < 1e-3, name
+        bound("test_generic_model_path_tinyconv:164", rel_linf(p.grad, g["G." + name]), 1e-5)
     h = golden("g5_hist_tinyconv")
     m.load_state_dict({k[2:]: v for k, v in h.items() if k.startswith("W.")})
     with torch.no_grad(), replay_noise(randn=[h["eps0"]] + list(h["eps"])):
@@ -228,12 +228,12 @@ def test_elbo_vs_golden():
     x = g["x"].to(DEV)
     with torch.no_grad(), replay_noise(randn=[g["eps_r"], g["eps_m"]], rand=[g["offset"]], randperm=[g["perm"]]):
         elbo, bpd, extra = bsi.elbo(x, 3, 4, estimate_var=True)
-    assert max_rel(extra["l_recon"], g["l_recon"]) < 2e-4 and max_rel(extra["l_measure"], g["l_measure"]) < 1e-4
-    assert max_rel(elbo, g["elbo"]) < 2e-4 and max_rel(bpd, g["bpd"]) < 2e-4
-    assert max_rel(extra["bpd_var"], g["bpd_var"]) < 5e-3
+    bound("test_elbo_vs_golden:231", max_rel(extra["l_recon"], g["l_recon"]) < 2e-4 and max_rel(extra["l_measure"], g["l_measure"]), 1e-5)
+    bound("test_elbo_vs_golden:232", max_rel(elbo, g["elbo"]) < 2e-4 and max_rel(bpd, g["bpd"]), 1e-5)
+    bound("test_elbo_vs_golden:233", max_rel(extra["bpd_var"], g["bpd_var"]), 1e-4)
     with torch.no_grad(), replay_noise(randn=[g["feps_r"], g["feps_m"]], randint=[g["fidx"]]):
         felbo, fbpd, fextra = bsi.finite_elbo(x, 3, 4, t=torch.linspace(0, 1, 17, device=DEV), estimate_var=True)
-    assert max_rel(fextra["l_measure"], g["fl_measure"]) < 1e-4 and max_rel(felbo, g["felbo"]) < 2e-4
+    bound("test_elbo_vs_golden:236", max_rel(fextra["l_measure"], g["fl_measure"]) < 1e-4 and max_rel(felbo, g["felbo"]), 1e-5)
     with pytest.raises(AssertionError):
         with torch.no_grad():
             bsi.elbo(x, 1, 4, estimate_var=True)
@@ -259,7 +259,7 @@ def test_full_size_dit_l2_one_forward_vs_oracle():
     with torch.no_grad():
         got = bsi._predict_x(mu.to(DEV), t.to(DEV)).cpu()
         ref = bo.BSIOracle(f, data_shape=shape, k=128).predict_x(mu, t)
-    assert rel_linf(got, ref) < 2e-2, rel_linf(got, ref)
+    bound("test_full_size_dit_l2_one_forward_vs_oracle:262", rel_linf(got, ref), 2e-3)
     # size-independent properties at the benchmark batch: determinism and batch-invariance of the chain
     with torch.no_grad():
         a = bsi.sample(4, torch.Generator(DEV).manual_seed(5), t=torch.linspace(0, 1, 5, device=DEV))
@@ -286,12 +286,12 @@ def test_dit_patch4_decoder_larger_than_lds_vs_oracle():
     ref = do.dit_forward(Wr, mu, t, patch_size=ps, dim=dim, depth=depth, heads=heads, ff=(6, 8))
     (ref * r).sum().backward()
     got = m(mu.to(DEV), t.to(DEV))
-    assert rel_linf(got.detach().cpu(), ref.detach()) < 2e-2
+    bound("test_dit_patch4_decoder_larger_than_lds_vs_oracle:289", rel_linf(got.detach().cpu(), ref.detach()), 1e-2)
     (got * r.to(DEV)).sum().backward()
     for name, p in m.named_parameters():
         gref = Wr[name].grad
         err = float((p.grad.cpu().double() - gref.double()).norm() / gref.double().norm().clamp_min(1e-30))
-        assert err < 3e-2, (name, err)
+        bound("test_dit_patch4_decoder_larger_than_lds_vs_oracle:294", err, 1e-2)
 
 
 def test_train_loss_gradients_vs_golden():
@@ -302,7 +302,7 @@ def test_train_loss_gradients_vs_golden():
         bsi = make_bsi(model)
         with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
             loss = bsi.train_loss(g["x"].to(DEV))
-        assert max_rel(loss.detach(), g["loss"]) < 1e-2
+        bound("test_train_loss_gradients_vs_golden:305", max_rel(loss.detach(), g["loss"]), 1e-3)
         loss.mean().backward()
         sq, worst = 0.0, (0.0, None)
         for name, p in model.named_parameters():
@@ -312,7 +312,7 @@ def test_train_loss_gradients_vs_golden():
             err = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
             worst = max(worst, (err, name))
             # bf16 operands in every product of the backward chain: relative L2 error per tensor below 3e-2
-            assert err < 3e-2, (name, err)
+            bound("test_train_loss_gradients_vs_golden:315", err, 1e-2)
         assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)
 
 
@@ -335,7 +335,7 @@ def test_fused_clip_adamw_ema_vs_golden():
                                            1.0, 1.0, 5e-4, 0.9, 0.99, 1e-8, 1e-2, step, 1.0 if step < 3 else 0.25,
                                            N.stream()))
         ref = torch.cat([g[f"p{step}.{n}"].reshape(-1) for n in names])
-        assert rel_linf(flat_p, ref) < 1e-6, (step, rel_linf(flat_p, ref))
+        bound("test_fused_clip_adamw_ema_vs_golden:338", rel_linf(flat_p, ref), 1e-6)
         if step == 2:
             ema2 = ema.clone()
             assert torch.equal(ema, flat_p)                       # warm-up: copy
@@ -370,7 +370,7 @@ def test_dp_trainer_single_gpu_step():
         # not numerical noise (e.g. the key bias has an analytically zero gradient: softmax is shift invariant)
         mask = gref.abs() > 1e-2 * gref.abs().max()
         du, dr = (got - p0[n].cpu())[mask], (ref - p0[n].cpu())[mask]
-        assert float((du - dr).abs().mean() / dr.abs().mean()) < 5e-2, n
+        bound("test_dp_trainer_single_gpu_step:373", float((du - dr).abs().mean() / dr.abs().mean()), 1e-3)
     for (n, p), (_, e) in zip(model.named_parameters(), tr.ema_model.named_parameters()):
         assert torch.equal(p.detach(), e.detach()), n
     with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
@@ -379,22 +379,32 @@ def test_dp_trainer_single_gpu_step():
     assert tr.step_count == 2
 
 
-def test_training_dropout_matches_oracle_with_same_masks():
+@pytest.mark.parametrize("side", [16, 32])
+def test_training_dropout_matches_oracle_with_same_masks(side):
     """Dropout sites of the training engine (attention weights, MLP input): the counter-based masks are exported with
-    bsi_dropout_mask and applied in the CPU oracle; loss and gradients must agree as in the dropout-free case."""
+    bsi_dropout_mask and applied in the CPU oracle; loss and gradients must agree as in the dropout-free case.  side = 32 gives 256
+    tokens: the persistent attention kernels (forward with dropout + log-sum-exp, backward with dropout) of the DiT-L geometry."""
     from bsi_amd import _native as N
     from bsi_amd.models.dit import DenoisingDiT
     from bsi_amd.nn import FourierFeatures
-    p, B, T, d, heads, depth = 0.3, 4, 64, 128, 2, 2
+    p, B, d, heads, depth = 0.3, 4, 128, 2, 2
+    T = (side // 2) ** 2
+    shape = (3, side, side)
     g = golden("g4_train_dit")
     W = weights("dit_ff")
-    model = DenoisingDiT((3, 16, 16), 2, d, depth, heads, dropout=p, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    model = DenoisingDiT(shape, 2, d, depth, heads, dropout=p, fourier_features=FourierFeatures(n_min=6, n_max=8))
     model.load_state_dict(W)
     model = model.to(DEV).train()
-    bsi = make_bsi(model)
+    bsi = make_bsi(model, shape)
+    gen = torch.Generator().manual_seed(77)
+    if side == 16:
+        x, off, perm, eps = g["x"], g["offset"], g["perm"], g["eps"]
+    else:
+        x = (torch.round(255 * torch.rand((B, *shape), generator=gen)) / 255) * 2 - 1
+        off, perm, eps = torch.rand((), generator=gen), torch.randperm(B, generator=gen), torch.randn((B, *shape), generator=gen)
     torch.manual_seed(123)
-    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
-        loss = bsi.train_loss(g["x"].to(DEV))
+    with replay_noise(rand=[off], randperm=[perm], randn=[eps]):
+        loss = bsi.train_loss(x.to(DEV))
     loss.mean().backward()
     seed = (torch.initial_seed() * 0x9E3779B1 + model._drop_calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
     drop = {}
@@ -408,18 +418,23 @@ def test_training_dropout_matches_oracle_with_same_masks():
         assert abs(float(ma.float().mean()) - (1 - p)) < 0.01 and abs(float(mm.float().mean()) - (1 - p)) < 0.01
     Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     f = lambda a, b: do.dit_forward(Wr, a, b, patch_size=2, dim=d, depth=depth, heads=heads, ff=(6, 8), drop=drop)  # noqa: E731
-    o = bo.BSIOracle(f, data_shape=(3, 16, 16), k=16)
-    ref = o.train_loss(g["x"], g["offset"], g["perm"], g["eps"])
-    assert max_rel(loss.detach(), ref.detach()) < 2e-2, max_rel(loss.detach(), ref.detach())
+    o = bo.BSIOracle(f, data_shape=shape, k=16)
+    ref = o.train_loss(x, off, perm, eps)
+    lerr = max_rel(loss.detach(), ref.detach())
     ref.mean().backward()
+    worst = (0.0, None)
     for name, q in model.named_parameters():
         r = Wr[name].grad
-        err = float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
-        assert err < 4e-2, (name, err)
+        worst = max(worst, (float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30)), name))
+    report("dit_dropout_vs_oracle_same_masks", tokens=T, per_sample_max=lerr, worst_tensor_rel_l2=worst[0], worst_tensor=worst[1])
+    assert lerr < 1e-3, lerr          # the stated per-sample tolerance, with dropout p = 0.3 on
+    assert worst[0] < 1e-2, worst     # and the gradient-tensor bound
+    if side != 16:
+        return
     # eval() switches dropout off: same loss as the dropout-free golden
     model.eval()
     with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
-        assert max_rel(bsi.train_loss(g["x"].to(DEV)).cpu(), g["loss"]) < 1e-2
+        bound("test_training_dropout_matches_oracle_with_same_masks:437", max_rel(bsi.train_loss(g["x"].to(DEV)).cpu(), g["loss"]), 1e-3)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -443,8 +458,8 @@ def test_unet_forward_vs_golden():
         y = m(g["mu"].to(DEV), g["t"].to(DEV)).cpu()
         W = weights("unet_ff")
         yb = uo.unet_forward(W, g["mu"], g["t"], levels=1, ff=(6, 8), has_dropout_slot=True, md=torch.bfloat16)
-    assert rel_linf(y, g["out"]) < 1e-2, rel_linf(y, g["out"])
-    assert rel_linf(y, yb) < 1e-2, rel_linf(y, yb)
+    bound("test_unet_forward_vs_golden:461", rel_linf(y, g["out"]), 1e-2)
+    bound("test_unet_forward_vs_golden:462", rel_linf(y, yb), 1e-2)
 
 
 def test_unet_sampling_vs_golden():
@@ -458,15 +473,15 @@ def test_unet_sampling_vs_golden():
         for i in range(k + 1):
             mu_i = g["mus"][i].to(DEV)
             xh = bsi._predict_x(mu_i, t_eval[i].repeat(mu_i.shape[0]))
-            assert rel_linf(xh, g["x_hats"][i]) < 2e-2, (i, rel_linf(xh, g["x_hats"][i]))
+            bound("test_unet_sampling_vs_golden:476", rel_linf(xh, g["x_hats"][i]), 1e-2)
     # free-running without Fourier features through BSI.sample_history (fused native path)
     g = golden("g5_hist_unet_noff")
     bsi = make_bsi(make_unet("unet_noff", False), (3, 8, 8), k=k)
     with torch.no_grad(), replay_noise(randn=[g["eps0"]] + list(g["eps"])):
         mus, xhs, ys = bsi.sample_history(2)
     for i in range(k + 1):
-        assert rel_linf(xhs[i], g["x_hats"][i]) < 5e-2, (i, rel_linf(xhs[i], g["x_hats"][i]))
-        assert rel_linf(mus[i], g["mus"][i]) < 5e-2
+        bound("test_unet_sampling_vs_golden:483", rel_linf(xhs[i], g["x_hats"][i]), 1e-2)
+        bound("test_unet_sampling_vs_golden:484", rel_linf(mus[i], g["mus"][i]), 1e-2)
 
 
 def test_full_size_unet_one_forward_vs_oracle():
@@ -489,7 +504,7 @@ def test_full_size_unet_one_forward_vs_oracle():
     with torch.no_grad():
         got = bsi._predict_x(mu.to(DEV), t.to(DEV)).cpu()
         ref = bo.BSIOracle(f, data_shape=shape, k=128).predict_x(mu, t)
-    assert rel_linf(got, ref) < 3e-2, rel_linf(got, ref)
+    bound("test_full_size_unet_one_forward_vs_oracle:507", rel_linf(got, ref), 2e-3)
 
 
 def test_unet_train_loss_gradients_vs_golden():
@@ -499,7 +514,7 @@ def test_unet_train_loss_gradients_vs_golden():
     bsi = make_bsi(model, (3, 8, 8))
     with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
         loss = bsi.train_loss(g["x"].to(DEV))
-    assert max_rel(loss.detach(), g["loss"]) < 1e-2
+    bound("test_unet_train_loss_gradients_vs_golden:517", max_rel(loss.detach(), g["loss"]), 1e-3)
     loss.mean().backward()
     sq, worst = 0.0, (0.0, None)
     for name, p in model.named_parameters():
@@ -508,7 +523,7 @@ def test_unet_train_loss_gradients_vs_golden():
         sq += float((p.grad.double() ** 2).sum())
         err = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
         worst = max(worst, (err, name))
-        assert err < 3e-2, (name, err)
+        bound("test_unet_train_loss_gradients_vs_golden:526", err, 1e-2)
     assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)
 
 
@@ -548,12 +563,12 @@ def test_unet_training_dropout_and_two_levels_vs_oracle():
     Wr = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     f = lambda a, b: uo.unet_forward(Wr, a, b, levels=levels, ff=(6, 8), has_dropout_slot=True, drop=drop)  # noqa: E731
     ref = bo.BSIOracle(f, data_shape=shape, k=16).train_loss(x, off, perm, eps)
-    assert max_rel(loss.detach(), ref.detach()) < 2e-2, max_rel(loss.detach(), ref.detach())
+    bound("test_unet_training_dropout_and_two_levels_vs_oracle:566", max_rel(loss.detach(), ref.detach()), 1e-3)
     ref.mean().backward()
     for name, q in m.named_parameters():
         r = Wr[name].grad
         err = float((q.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
-        assert err < 4e-2, (name, err)
+        bound("test_unet_training_dropout_and_two_levels_vs_oracle:571", err, 1e-2)
 
 
 def test_dp_trainer_unet_single_gpu_step():
@@ -633,7 +648,7 @@ def test_dp_trainer_exchange_path_on_one_rank():
                 outs.append((float(loss), tr.fp.flat.clone(), tr.ema_fp.flat.clone()))
             assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]), (gname, outs[0][0], outs[1][0])
             # atomics in the backward make the low bits run-dependent; the two paths must agree to fp32 noise
-            assert rel_linf(outs[1][1], outs[0][1]) < 1e-5 and rel_linf(outs[1][2], outs[0][2]) < 1e-5, gname
+            bound("test_dp_trainer_exchange_path_on_one_rank:651", rel_linf(outs[1][1], outs[0][1]) < 1e-5 and rel_linf(outs[1][2], outs[0][2]), 1e-5)
     finally:
         dist.destroy_process_group()
         if os.path.exists(store.name):

@@ -522,7 +522,7 @@ def test_gemm_tn_and_colsum(N, M, Nn, K):
 # ----------------------------------------------------------------------------------------------
 # backward kernels (checked against torch autograd of the oracle expressions in fp64)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,tokens,heads,dh,long", [(2, 64, 2, 64, 0), (2, 256, 3, 64, 0), (1, 128, 1, 64, 0), (2, 1024, 1, 128, 1),
+@pytest.mark.parametrize("B,tokens,heads,dh,long", [(2, 64, 2, 64, 0), (2, 256, 3, 64, 0), (20, 256, 16, 64, 0), (1, 128, 1, 64, 0), (2, 1024, 1, 128, 1),
                                                     (2, 192, 2, 128, 1), (1, 320, 2, 64, 1), (3, 64, 1, 64, 1)])
 def test_attention_backward(N, B, tokens, heads, dh, long):
     d = heads * dh

@@ -114,3 +114,15 @@ def shard_draws(rank, step, nb, shape):
     stream per (rank, step), so that a single process can restate both ranks' work."""
     g = torch.Generator().manual_seed(1000 + 17 * rank + step)
     return torch.rand((), generator=g), torch.randperm(nb, generator=g), torch.randn((nb, *shape), generator=g)
+
+
+BOUNDS = {}  # tag -> (worst achieved value, limit) of this pytest process
+
+
+def bound(tag, value, limit):
+    """assert value < limit, and remember the worst achieved value per tag: the terminal summary lists achieved / limit for every
+    tag, so that an assertion bound far above what the kernels achieve is visible in the log."""
+    value = float(value)
+    w = BOUNDS.get(tag, (0.0, limit))[0]
+    BOUNDS[tag] = (max(w, value), limit)
+    assert value < limit, (tag, value, limit)

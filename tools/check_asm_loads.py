@@ -2,7 +2,8 @@
 """Lint for the hand-counted vector-memory waits of the HIP kernels.
 
 Several epilogues fetch rows with INLINE-ASM global loads and wait for them with an inline-asm `s_waitcnt vmcnt(N)` that carries the
-loaded registers as "+v" operands (gemm_bf16.hip wave_tile_epilogue_train, conv_igemm.hip store_f32_rows, attention_persist.hip):
+loaded registers as "+v" operands (gemm_bf16.hip wave_tile_epilogue_train, conv_igemm.hip store_f32_rows, attention_persist.hip,
+attention_bwd.hip attention_bwd_p_kernel, gemm_tn.hip gemm_tn2_kernel):
 hipcc's own waits would be vmcnt(0), it assumes loads and stores can complete out of order with each other.  The compiler does not
 know that the registers are not valid between the load and the wait.  The "+v" operands keep their USES behind the wait, but hipcc may
 still COPY such a register in front of the wait (it did, when two waits sat in the arms of an if / else).  This script compiles the

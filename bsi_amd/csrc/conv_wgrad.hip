@@ -23,15 +23,6 @@ int bsi_reduce_slabs2_launch(const float* slabsA, size_t strideA, size_t nA, flo
 
 namespace {
 
-__device__ __forceinline__ s16x4 wg_tr_read(const char* p) {
-    s16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p));
-    return r;
-}
-template <typename T>
-__device__ __forceinline__ void wg_pin(T& x) { asm volatile("" : "+v"(x)); }
-
-
 struct WgParams {
     const __bf16* dY;     // [M, ldy]
     const __bf16* X;      // [M, Cin]
@@ -182,10 +173,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
         __builtin_amdgcn_s_barrier();            \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
-// transposed reads as inline asm: in front of the ds_read_tr builtin hipcc puts `s_waitcnt vmcnt(0)` whenever LDS-DMA is in flight -- every
-// load phase drained the operand pipeline, the ring's look-ahead was one stage.  The reads' results are pinned behind the
-// `s_waitcnt lgkmcnt(0)` below by operand-carrying (empty) asm statements: volatile asm statements keep their order.
-#define TR(ptr) wg_tr_read(ptr)
+#define TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
 
     auto load_frags = [&](const char* b) {
         union U { bf16x8 v; s16x4 h[2]; };
@@ -229,10 +217,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) wg_pin(af[i]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wg_pin(bf[j]);
         WG_BARRIER();
         __builtin_amdgcn_s_setprio(1);
         if (!(p.abl & 4)) {
@@ -371,10 +355,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
         __builtin_amdgcn_s_barrier();            \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
-// transposed reads as inline asm: in front of the ds_read_tr builtin hipcc puts `s_waitcnt vmcnt(0)` whenever LDS-DMA is in flight -- every
-// load phase drained the operand pipeline, the ring's look-ahead was one stage.  The reads' results are pinned behind the
-// `s_waitcnt lgkmcnt(0)` below by operand-carrying (empty) asm statements: volatile asm statements keep their order.
-#define TR(ptr) wg_tr_read(ptr)
+#define TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
 
     auto load_frags = [&](const char* b) {
         union U { bf16x8 v; s16x4 h[2]; };
@@ -417,13 +398,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int i = 0; i < UNITS; ++i) wg_pin(af[h][i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wg_pin(bf[h][j]);
-        }
         WG_BARRIER();
         __builtin_amdgcn_s_setprio(1);
         if (!(p.abl & 4)) {

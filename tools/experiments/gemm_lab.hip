@@ -203,6 +203,7 @@ int main() {
                 rep("production", time_k64r<E, 0>(p, 20));
                 rep("barrier 8 MFMAs early", time_k64r<E, 524288>(p, 20));
                 rep("barrier 16 MFMAs early", time_k64r<E, 1048576>(p, 20));
+                rep("priority to the load phase", time_k64r<E, 2097152>(p, 20));
                 if (sh.N == 4096) {
                     rep("gelu production", time_k64r<G, 0>(p, 20));
                     rep("gelu barrier 8 MFMAs early", time_k64r<G, 524288>(p, 20));

@@ -347,7 +347,7 @@ def secondary_in_child(a):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def launch_ranks(a):
+def launch_ranks(a, command=None):
     """`python bench.py --gpus N` without torchrun: start the N rank processes (one per GPU) as children of this
     process, which itself makes NO GPU call (device_count() does not initialise the runtime on this image).  Rank 0's
     stdout (the JSON line) is relayed; the exit status is the worst child status."""
@@ -367,7 +367,7 @@ def launch_ranks(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # a user's setting wins
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen(command or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # rank 0's stdout is drained by a thread while all children are POLLED: when one exits non-zero (bad device, out of memory)
     # the others would sit in init_process_group / a collective until the RCCL timeout -- terminate them and return its status

@@ -412,8 +412,10 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i0 = 0; i0 < 4; ++i0) {  // boustrophedon, as in the slab kernel below
+                        const int i = (j & 1) ? 3 - i0 : i0;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_s_setprio(0);
             if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
@@ -721,8 +723,10 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i0 = 0; i0 < 4; ++i0) {  // boustrophedon: one operand changes per MFMA (power; gemm_bf16.hip)
+                            const int i = (j & 1) ? 3 - i0 : i0;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (t == 8 && c == nc - 1 && wm == 1) { epilogue(tile); after_e = full_tile(tile) ? 5 : 0; }  // group B: before its last barrier

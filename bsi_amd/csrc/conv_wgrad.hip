@@ -406,8 +406,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgParams p) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int i = 0; i < UNITS; ++i)
+                    for (int i0 = 0; i0 < UNITS; ++i0) {  // boustrophedon: one operand changes per MFMA (power; gemm_bf16.hip)
+                        const int i = (j & 1) ? UNITS - 1 - i0 : i0;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][i], bf[h][j], acc[i][j], 0, 0, 0);
+                    }
         }
         if (do_colsum) {
 #pragma unroll

@@ -725,8 +725,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i0 = 0; i0 < 4; ++i0) {  // boustrophedon, as in the k64r kernel below
+                    const int i = (j & 1) ? 3 - i0 : i0;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_s_setprio(0);
             if (v == nk - 1 && wm == 1) epilogue(tile);  // group B: before the barrier that ends its last C phase
             PHASE_BARRIER();
@@ -920,11 +922,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 PHASE_BARRIER();
                 // ---- C(v, ks)
                 __builtin_amdgcn_s_setprio(1);
+                // boustrophedon over the 4 x TM fragment grid: one operand changes per MFMA instead of two at every row end.  The
+                // chip is power limited under this stream and operand toggling is part of the bill: +2 % on a
+                // register-only MFMA stream (tools/experiments/mfma_power.hip), +0.5..2.5 % here (profiles/r3/mfma_power.txt)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i0 = 0; i0 < 4; ++i0) {
+                        const int i = (j & 1) ? 3 - i0 : i0;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    }
                 __builtin_amdgcn_s_setprio(0);
                 if (ks == 1 && v == nk - 1 && wm == 1) {  // group B: before the barrier that ends its last C phase
                     pre_status = issue_next();

@@ -451,8 +451,10 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i0 = 0; i0 < 4; ++i0) {  // boustrophedon: one operand changes per MFMA (power; gemm_bf16.hip k64r kernel)
+                    const int i = (j & 1) ? 3 - i0 : i0;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i].v, bf[j].v, acc[i][j], 0, 0, 0);
+                }
                 if (NL < 4 && split_issue) {  // the other 4 - NL instructions, inside the MFMA phase (placement: template parameter)
                     if (j == JA) {
                         __builtin_amdgcn_sched_barrier(0);

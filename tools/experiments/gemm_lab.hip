@@ -211,6 +211,19 @@ int main() {
             }
             continue;
         }
+        if (getenv("LAB_SNAKE")) {
+            // round 3: boustrophedon MFMA order (tools/experiments/mfma_power.hip: +2 % on a register-only stream)
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            for (int r = 0; r < 4; ++r) {
+                rep("production", time_k64r<E, 0>(p, 20));
+                rep("boustrophedon MFMA order", time_k64r<E, 4194304>(p, 20));
+                if (sh.N == 4096) {
+                    rep("gelu production", time_k64r<G, 0>(p, 20));
+                    rep("gelu boustrophedon MFMA order", time_k64r<G, 4194304>(p, 20));
+                }
+            }
+            continue;
+        }
         if (getenv("LAB_DMAONLY")) {
             // round 3: how long does the operand DMA stream take by itself (no MFMAs, fragments read once, no epilogue), on 256 and on 64 CUs?
             for (int ncu : {256, 64}) {

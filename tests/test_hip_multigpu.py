@@ -67,3 +67,20 @@ def test_bench_multi_rank_code_path_on_one_device():
     assert tr["per_gpu_batch"] == 8 and tr["comm"]["buckets"] == 24 + 2 and tr["comm"]["allreduce_bytes"] > 1.9e9
     assert tr["comm"]["ms_per_step_without_exchange"] > 0 and "exposed_comm_ms" in tr["comm"]
     assert "secondary" not in line and "cpu_baseline" not in line
+
+
+def test_bench_under_the_drivers_launcher_on_one_device():
+    """The driver's own N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with the one-device hook: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
+    from the launcher's environment, bench.py must not start ranks of its own, and rank 0 alone prints the JSON line."""
+    env = dict(os.environ, BSI_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--k", "2", "--train-steps", "0", "--no-secondary", "--no-cpu-baseline"],
+                       capture_output=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # one JSON line for the whole job
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 0 and line["scaling"] == "weak"
+    assert line["config"]["workload"] and line["value"] > 0

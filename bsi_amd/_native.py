@@ -167,6 +167,7 @@ _PROTOS = {
     "bsi_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "bsi_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bsi_resid_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "bsi_resid2_ln_modulate": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "bsi_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "bsi_attention_fwd_lse": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "bsi_attention_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -13,7 +13,8 @@ int bsi_dit_final_launch(const float* x, int Mtok, int d, int P, const float* ln
 int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
                                const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
                                const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream,
-                               float* x_out = nullptr, float* stats = nullptr);
+                               float* x_out = nullptr, float* stats = nullptr, const void* delta0 = nullptr,
+                               const float* gate0 = nullptr, int write_x = 1);
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
                          float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream, size_t part_stride = 0);

@@ -54,25 +54,37 @@ __global__ void nyquist_kernel(const float* __restrict__ t, int rows, const floa
 //     x[m,:] += gate[row] * delta[m,:]          (dit.py:93-97 / 98-102: torch.addcmul(x, gate, branch))
 // is applied and written back (fp32), then the norm runs on the updated row — one streaming pass instead of a
 // read-modify-write inside the GEMM epilogue.  `delta` may alias `out` (a wave reads its row before writing it).
+// Lazy form (inference engine): with write_x = 0 the updated row is normalised but NOT stored; the next pass names that update
+// as (delta0, gate0) in front of its own and stores the row once for both -- 302 MB less traffic per DiT block at 512 images.
 template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
 __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
                                    const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                    const __bf16* delta, const float* __restrict__ gate, __bf16* out, DropCfg dc,
-                                   float* x_out, float* __restrict__ stats) {
+                                   float* x_out, float* __restrict__ stats, const __bf16* delta0 = nullptr,
+                                   const float* __restrict__ gate0 = nullptr, int write_x = 1) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (size_t)row * d;
     float* xw = (x_out ? x_out : x) + (size_t)row * d;  // training tape: the updated row goes to its own slot
     const int d4 = d >> 2;
-    const int mrow = (shift || gate) ? (row / tokens) % mod_rows : 0;
+    const int mrow = (shift || gate || gate0) ? (row / tokens) % mod_rows : 0;
     f32x4 v[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
         v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (delta0 && c < d4) {  // an OLDER update that the previous pass applied in registers only (write_x = 0 there): the same
+                                 // fp32 fma on the same fp32 x as the pass that would have stored it, so the row is bit-identical
+            const u32x2 dw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta0 + (size_t)row * d) + c);
+            const f32x4 g = reinterpret_cast<const f32x4*>(gate0 + (size_t)mrow * mod_stride)[c];
+            v[i][0] = __fmaf_rn(g[0], __uint_as_float(dw[0] << 16), v[i][0]);
+            v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
+            v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
+            v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
+        }
         if (delta && c < d4) {
             const u32x2 dw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)row * d) + c);
             const f32x4 g = reinterpret_cast<const f32x4*>(gate + (size_t)mrow * mod_stride)[c];
@@ -80,7 +92,7 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
             v[i][1] = __fmaf_rn(g[1], __uint_as_float(dw[0] & 0xffff0000u), v[i][1]);
             v[i][2] = __fmaf_rn(g[2], __uint_as_float(dw[1] << 16), v[i][2]);
             v[i][3] = __fmaf_rn(g[3], __uint_as_float(dw[1] & 0xffff0000u), v[i][3]);
-            reinterpret_cast<f32x4*>(xw)[c] = v[i];
+            if (write_x) reinterpret_cast<f32x4*>(xw)[c] = v[i];
         }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
@@ -393,7 +405,7 @@ extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, c
 int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
                                const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
                                const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream,
-                               float* x_out, float* stats) {
+                               float* x_out, float* stats, const void* delta0, const float* gate0, int write_x) {
     BSI_CHECK_ARG(x && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_resid_ln_modulate: bad args M=%d d=%d", M, d);
     BSI_CHECK_ARG(out_bf16 || delta, "bsi_resid_ln_modulate: nothing to do");
     BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_resid_ln_modulate: shift and scale go together");
@@ -401,21 +413,31 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
     BSI_CHECK_ARG(!(shift || gate) || (mod_rows > 0 && tokens > 0 && mod_stride % 4 == 0),
                   "bsi_resid_ln_modulate: bad modulation table");
     BSI_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "bsi_resid_ln_modulate: ln weight and bias go together");
+    BSI_CHECK_ARG((delta0 == nullptr) == (gate0 == nullptr) && (!delta0 || delta), "bsi_resid_ln_modulate: an older update needs its gate and a newer update");
+    BSI_CHECK_ARG(write_x || (delta && out_bf16 && !x_out), "bsi_resid_ln_modulate: write_x = 0 needs an update and an output");
+    const __bf16* dl0 = reinterpret_cast<const __bf16*>(delta0);
     const int wpb = TPB / 64;
     dim3 grid((M + wpb - 1) / wpb);
     __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
     const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);
     else if (d <= 1024)
         hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);
     else
         hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
-                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats);
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);
     BSI_CHECK_LAUNCH("bsi_resid_ln_modulate");
     return BSI_OK;
+}
+
+extern "C" int bsi_resid2_ln_modulate(float* x, int M, int d, float eps, const void* delta0, const float* gate0, const void* delta,
+                                      const float* gate, int write_x, const float* shift, const float* scale, int mod_rows,
+                                      int mod_stride, int tokens, void* out_bf16, bsi_stream_t stream) {
+    return bsi_resid_ln_modulate_drop(x, M, d, eps, delta, gate, shift, scale, mod_rows, mod_stride, tokens, nullptr, nullptr,
+                                      out_bf16, DropCfg{}, stream, nullptr, nullptr, delta0, gate0, write_x);
 }
 
 extern "C" int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, const float* gate,

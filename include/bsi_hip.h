@@ -262,6 +262,15 @@ int bsi_resid_ln_modulate(float* x, int M, int d, float eps, const void* delta, 
                           const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
                           const float* ln_w, const float* ln_b, void* out_bf16, bsi_stream_t stream);
 
+/* Two consecutive updates of dit.py:93-102 with ONE store of the residual row between them.  A pass with write_x = 0 applies
+ * (delta, gate) in registers only: out_bf16 = LayerNorm(x + gate * delta) * (1 + scale) + shift, x untouched.  The next pass
+ * names that update as (delta0, gate0) -- the caller keeps delta0 alive until then -- in front of its own (delta, gate):
+ *   x[m,:] = fma(gate, delta, fma(gate0, delta0, x[m,:]))   (the same two fp32 fmas as two stored passes: bit-identical rows),
+ * stored when write_x != 0, then normalised as above.  delta0 == NULL: as bsi_resid_ln_modulate without affine weights. */
+int bsi_resid2_ln_modulate(float* x, int M, int d, float eps, const void* delta0, const float* gate0, const void* delta,
+                           const float* gate, int write_x, const float* shift, const float* scale, int mod_rows,
+                           int mod_stride, int tokens, void* out_bf16, bsi_stream_t stream);
+
 /* dit.py:39-46 / attention.py:34-40: softmax(q k^T / sqrt(dh)) v per (batch, head), non-causal.
  * qkv: bf16 [B, tokens, 3, heads, dh] (row stride ld_qkv elements); out: bf16 [B, tokens, heads*dh]
  * (row stride ld_out).  dh in {64, 128}; tokens % 64 == 0. */

@@ -490,6 +490,47 @@ def test_resid_ln_modulate(N, M, d, tokens, mod_rows):
     assert torch.equal(dx2.cpu(), x_ref)
 
 
+@pytest.mark.parametrize("M,d,tokens,mod_rows", [(128, 128, 64, 2), (512, 1024, 256, 2), (300, 2048, 100, 3)])
+def test_resid2_ln_modulate_lazy_store_is_bit_identical(N, M, d, tokens, mod_rows):
+    """The inference engine's lazy form of two consecutive updates (dit.py:93-102): the first pass applies the attention update in
+    registers only (write_x = 0), the second names it as (delta0, gate0) and stores the row once.  Rows and both normalised
+    outputs must equal the two stored passes of bsi_resid_ln_modulate bit for bit; the second delta aliases the output buffer as
+    in the engine."""
+    gen = torch.Generator().manual_seed(M * 5 + d)
+    x = torch.randn((M, d), generator=gen) * 2
+    da = bf16r(torch.randn((M, d), generator=gen)).to(torch.bfloat16)
+    dm = bf16r(torch.randn((M, d), generator=gen)).to(torch.bfloat16)
+    mod = torch.randn((mod_rows, 6 * d), generator=gen) * 0.3
+    dmod = dev(mod)
+    g = lambda j: dmod.data_ptr() + 4 * j * d  # noqa: E731  chunk j of the modulation table
+    L = N.lib()
+    # eager: two stored passes
+    xe, b1, b2 = dev(x.clone()), dev(da.clone()), dev(dm.clone())
+    o1 = empty(M, d, dtype=torch.bfloat16)
+    N.check(L.bsi_resid_ln_modulate(N.ptr(xe), M, d, 1e-5, N.ptr(b1), g(2), g(3), g(4), mod_rows, 6 * d, tokens, None, None,
+                                    N.ptr(o1), N.stream()))
+    N.check(L.bsi_resid_ln_modulate(N.ptr(xe), M, d, 1e-5, N.ptr(b2), g(5), g(0), g(1), mod_rows, 6 * d, tokens, None, None,
+                                    N.ptr(b2), N.stream()))
+    # lazy: the row is stored once
+    xl, c1, c2 = dev(x.clone()), dev(da.clone()), dev(dm.clone())
+    p1 = empty(M, d, dtype=torch.bfloat16)
+    N.check(L.bsi_resid2_ln_modulate(N.ptr(xl), M, d, 1e-5, None, None, N.ptr(c1), g(2), 0, g(3), g(4), mod_rows, 6 * d, tokens,
+                                     N.ptr(p1), N.stream()))
+    assert torch.equal(xl.cpu(), x)  # untouched by the register-only pass
+    assert torch.equal(p1.cpu(), o1.cpu())
+    N.check(L.bsi_resid2_ln_modulate(N.ptr(xl), M, d, 1e-5, N.ptr(c1), g(2), N.ptr(c2), g(5), 1, g(0), g(1), mod_rows, 6 * d, tokens,
+                                     N.ptr(c2), N.stream()))
+    assert torch.equal(xl.cpu(), xe.cpu()) and torch.equal(c2.cpu(), b2.cpu())
+    rows = (torch.arange(M) // tokens) % mod_rows
+    x_ref = torch.addcmul(torch.addcmul(x, mod[rows, 2 * d:3 * d], da.float()), mod[rows, 5 * d:6 * d], dm.float())
+    assert torch.equal(xl.cpu(), x_ref)  # two fp32 fmas, exact
+    # argument checks: an older update without a newer one, a register-only pass without output
+    assert L.bsi_resid2_ln_modulate(N.ptr(xl), M, d, 1e-5, N.ptr(c1), g(2), None, None, 1, g(0), g(1), mod_rows, 6 * d, tokens,
+                                    N.ptr(c2), N.stream()) != 0
+    assert L.bsi_resid2_ln_modulate(N.ptr(xl), M, d, 1e-5, None, None, N.ptr(c1), g(2), 0, g(0), g(1), mod_rows, 6 * d, tokens,
+                                    None, N.stream()) != 0
+
+
 @pytest.mark.parametrize("M,Nn,K", [(512, 256, 256), (4096, 1024, 1024), (16384, 3072, 1024), (8192, 1024, 4096),
                                      (1000 * 32, 128, 384), (544, 512, 128), (4, 768, 128), (300, 64, 64)])
 def test_gemm_tn_and_colsum(N, M, Nn, K):

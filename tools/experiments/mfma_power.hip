@@ -117,6 +117,56 @@ __global__ __launch_bounds__(512, 1) void mfma_lds_kernel(const bf16x8* __restri
     }
 }
 
+// One wave per SIMD (256-thread workgroup, up to 512 registers per wave): a 128 x 128 wave tile = 8 x 8 fragment grid, 64 accumulators
+// of 4 registers, 16 fragment reads and 2 * NDMA4 LDS-DMA instructions per wave per k32 step (64 MFMAs) -- the instruction mix of a
+// 256 x 256 tile on four waves (review item 1c), free running.
+template <int NREAD, int NDMA>
+__global__ __launch_bounds__(256, 1) void mfma_w4_kernel(const bf16x8* __restrict__ src, float* __restrict__ out, int iters,
+                                                         long long* __restrict__ clk, const char* __restrict__ stream, unsigned region) {
+    __shared__ bf16x8 lds[24 * 512 / 2];  // 96 KB
+    __shared__ char landing[NDMA ? 32768 : 16];
+    const int t = threadIdx.x;
+    for (int i = t; i < 24 * 512 / 2; i += 256) lds[i] = src[i];
+    __syncthreads();
+    const char* my = stream + (size_t)blockIdx.x * region + (t & 63) * 16 + (t >> 6) * 1024;
+    unsigned walk = 0;
+    bf16x8 a[8], b[8];
+    for (int i = 0; i < 8; ++i) a[i] = src[i * 512 + t];
+    for (int i = 0; i < 8; ++i) b[i] = src[(8 + i) * 512 + t];
+    f32x4 acc[8][8] = {};
+    const long long c0 = clock64();
+    const long long w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {  // 64 MFMAs per iteration, as one iteration of mfma_kernel<0>
+        const int base = ((it * 16) & 127) * 32 + (t & 63);
+        if (NDMA) {
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(my + walk + q * 4096),
+                                                 (__attribute__((address_space(3))) void*)(landing + (t >> 6) * 1024 + (q & 7) * 4096), 16, 0, 0);
+            walk += NDMA * 4096;
+            if (walk >= region) walk = 0;
+        }
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+            const int i = n >> 3, j = (i & 1) ? 7 - (n & 7) : (n & 7);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (NREAD && n >= 64 - NREAD) {
+                const int f = n - (64 - NREAD);
+                if (f < 8) a[f] = lds[(base + f * 64) % (24 * 512 / 2)];
+                else b[f - 8] = lds[(base + f * 64) % (24 * 512 / 2)];
+            }
+        }
+    }
+    float r = 0.f;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[blockIdx.x * 256 + t] = r;
+    if (t == 0) {
+        clk[2 * blockIdx.x] = clock64() - c0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     const int grid = argc > 2 ? atoi(argv[2]) : 256;
@@ -139,7 +189,8 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     const char* names[] = {"16x16x32", "32x32x16", "16x16x32 boustrophedon", "16x16x32 diagonal", "16x16x32 + 12 LDS reads / 32",
                            "16x16x32 + 8 LDS reads / 32", "16x16x32 + 4 LDS reads / 32", "+ 12 LDS reads + 4 DMA / 32 (L2)",
-                           "+ 12 LDS reads + 4 DMA / 32 (HBM)", "+ 8 LDS reads + 4 DMA / 32 (L2)", "+ 0 LDS reads + 4 DMA / 32 (L2)"};
+                           "+ 12 LDS reads + 4 DMA / 32 (HBM)", "+ 8 LDS reads + 4 DMA / 32 (L2)", "+ 0 LDS reads + 4 DMA / 32 (L2)",
+                           "1 wave/SIMD 128x128: MFMAs only", "1 wave/SIMD: + 16 reads / 64", "1 wave/SIMD: + 16 reads + 8 DMA / 64"};
     char* stream;
     hipMalloc(&stream, (size_t)grid * (4u << 20));
     hipMemset(stream, 0x3f, (size_t)grid * (4u << 20));
@@ -158,7 +209,10 @@ int main(int argc, char** argv) {
             else if (shape == 7) hipLaunchKernelGGL((mfma_lds_kernel<0, 12, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
             else if (shape == 8) hipLaunchKernelGGL((mfma_lds_kernel<0, 12, 4>), g, b, 0, 0, src, out, iters, clk, stream, 4u << 20);
             else if (shape == 9) hipLaunchKernelGGL((mfma_lds_kernel<0, 8, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
-            else hipLaunchKernelGGL((mfma_lds_kernel<0, 0, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 10) hipLaunchKernelGGL((mfma_lds_kernel<0, 0, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 11) hipLaunchKernelGGL((mfma_w4_kernel<0, 0>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 12) hipLaunchKernelGGL((mfma_w4_kernel<16, 0>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
+            else hipLaunchKernelGGL((mfma_w4_kernel<16, 8>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
@@ -167,7 +221,7 @@ int main(int argc, char** argv) {
             hipMemcpy(c.data(), clk, grid * 16, hipMemcpyDeviceToHost);
             double cyc = 0, wall = 0;
             for (int i = 0; i < grid; ++i) { cyc += c[2 * i]; wall += c[2 * i + 1]; }
-            const double flops = (double)grid * 8 * iters * 64.0 * 16384.0;  // 64 MFMA-equivalents of 16x16x32 per wave and iteration
+            const double flops = (double)grid * (shape >= 11 ? 4 : 8) * iters * 64.0 * 16384.0;  // 64 MFMA-equivalents of 16x16x32 per wave and iteration
             printf("%-32s grid %d data %s: %.2f ms  %.0f TFLOP/s  shader clock %.0f MHz  (%.3f TFLOP/s per MHz)\n",
                    names[shape], grid, zero ? "zeros" : "random", ms, flops / ms * 1e-9,
                    cyc / wall * 100.0, flops / ms * 1e-9 / (cyc / wall * 100.0));

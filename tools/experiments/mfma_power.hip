@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256, 1) void mfma_w4_kernel(const bf16x8* __restric
 #pragma unroll
         for (int n = 0; n < 64; ++n) {
             const int i = n >> 3, j = (i & 1) ? 7 - (n & 7) : (n & 7);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            // accumulators pinned to AGPRs: with the builtin hipcc moves them between the two halves of the register file inside the
+            // loop (6 v_accvgpr moves per MFMA at this size)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
             if (NREAD && n >= 64 - NREAD) {
                 const int f = n - (64 - NREAD);
                 if (f < 8) a[f] = lds[(base + f * 64) % (24 * 512 / 2)];

@@ -217,6 +217,7 @@ int main() {
             for (int r = 0; r < 4; ++r) {
                 rep("production", time_k64r<E, 0>(p, 20));
                 rep("boustrophedon MFMA order", time_k64r<E, 4194304>(p, 20));
+                rep("boustrophedon + reads before DMA issue", time_k64r<E, 4194304 | 8388608>(p, 20));
                 if (sh.N == 4096) {
                     rep("gelu production", time_k64r<G, 0>(p, 20));
                     rep("gelu boustrophedon MFMA order", time_k64r<G, 4194304>(p, 20));

@@ -214,20 +214,22 @@ int main() {
         if (getenv("LAB_SEG")) {
             // round 3: where a wave's time goes inside its phases (s_memtime stamps, one wave of each group per workgroup)
             constexpr int G = BSI_EPI_BIAS_GELU_BF16;
-            unsigned long long* dC; hipMalloc(&dC, 14 * 256 * 8);
+            unsigned long long* dC; hipMalloc(&dC, 18 * 256 * 8);
             LabParams q = p; q.out2 = dC;
             auto show = [&](const char* what, float ms_plain, float ms) {
-                unsigned long long hc[14 * 256];
+                unsigned long long hc[18 * 256];
                 hipMemcpy(hc, dC, sizeof hc, hipMemcpyDeviceToHost);
-                const char* names[7] = {"DMA issue + bookkeeping", "vmcnt wait", "lgkmcnt wait", "barrier before MFMAs", "32 MFMAs", "(epilogue,) barrier after", "fragment-read issue"};
-                const double phases = ((M + 255) / 256) * ((sh.N + 255) / 256) / 256.0 * (sh.K / 64) * 2;
+                const char* names[9] = {"DMA issue + bookkeeping", "vmcnt wait", "lgkmcnt wait", "barrier before MFMAs", "32 MFMAs", "(epilogue,) barrier after", "fragment-read issue",
+                                        "epilogue issue (per tile)", "epilogue end -> next tile's accumulators written (per tile)"};
+                const double tiles = ((M + 255) / 256) * ((sh.N + 255) / 256) / 256.0;
+                const double phases = tiles * (sh.K / 64) * 2;
                 for (int grp = 0; grp < 2; ++grp) {
-                    double sum[7] = {0};
-                    for (int b = 0; b < 256; ++b) for (int i = 0; i < 7; ++i) sum[i] += (double)hc[14 * b + 7 * grp + i];
+                    double sum[9] = {0};
+                    for (int b = 0; b < 256; ++b) for (int i = 0; i < 9; ++i) sum[i] += (double)hc[18 * b + 9 * grp + i];
                     printf("%s %s (%.3f ms stamped, %.3f plain) group %c, cycles per phase pair:", sh.name, what, ms, ms_plain, grp ? 'B' : 'A');
                     double tot = 0;
                     for (int i : {0, 6, 1, 2, 3, 4, 5}) { printf("  %s %.0f", names[i], sum[i] / 256.0 / phases); tot += sum[i] / 256.0 / phases; }
-                    printf("  | total %.0f\n", tot);
+                    printf("  | total %.0f | %s %.0f, %s %.0f\n", tot, names[7], sum[7] / 256.0 / tiles, names[8], sum[8] / 256.0 / (tiles - 1));
                 }
             };
             for (int r = 0; r < 2; ++r) {

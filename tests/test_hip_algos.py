@@ -59,12 +59,14 @@ def test_vdm_losses_vs_golden():
     bound("test_vdm_losses_vs_golden:59", max_rel(extra["l_prior"], g["l_prior"]), 1e-5)
     assert max_rel(extra["l_recon"], g["l_recon"]) < 1e-4   # no denoiser involved: fp32 wrapper arithmetic only
     bound("test_vdm_losses_vs_golden:61", max_rel(extra["l_diff"], g["l_diff"]), 1e-3)
-    bound("test_vdm_losses_vs_golden:62", max_rel(bpd, g["bpd"]) < 1e-3 and max_rel(elbo, g["elbo"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:62a", max_rel(bpd, g["bpd"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:62b", max_rel(elbo, g["elbo"]), 1e-3)
     bound("test_vdm_losses_vs_golden:63", rel_linf(extra["bpd_var"], g["bpd_var"]), 1e-2)
     g = golden("g9_vdm_finite_elbo")
     with torch.no_grad(), replay_noise(randint=[g["i"]], randn=[g["eps_recon"], g["eps_diff"]]):
         elbo, bpd, extra = v.finite_elbo(g["x"].to(DEV), 2, 2)
-    bound("test_vdm_losses_vs_golden:67", max_rel(extra["l_recon"], g["l_recon"]) < 1e-4 and max_rel(extra["l_diff"], g["l_diff"]), 1e-3)
+    bound("test_vdm_losses_vs_golden:67a", max_rel(extra["l_recon"], g["l_recon"]), 1e-4)
+    bound("test_vdm_losses_vs_golden:67b", max_rel(extra["l_diff"], g["l_diff"]), 1e-3)
     bound("test_vdm_losses_vs_golden:68", max_rel(bpd, g["bpd"]), 1e-3)
     with pytest.raises(AssertionError):
         v.elbo(g["x"].to(DEV), 1, 2, estimate_var=True)
@@ -105,12 +107,15 @@ def test_bfn_losses_vs_golden():
     b = make_bfn(make_model())
     with torch.no_grad(), replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps_recon"], g["eps_latent"]]):
         elbo, bpd, extra = b.elbo(g["x"].to(DEV), 2, 2, estimate_var=True)
-    bound("test_bfn_losses_vs_golden:108", max_rel(extra["l_recon"], g["l_recon"]) < 1e-2 and max_rel(extra["l_latent"], g["l_latent"]), 1e-3)
-    bound("test_bfn_losses_vs_golden:109", max_rel(bpd, g["bpd"]) < 1e-2 and rel_linf(extra["bpd_var"], g["bpd_var"]), 1e-2)
+    bound("test_bfn_losses_vs_golden:108a", max_rel(extra["l_recon"], g["l_recon"]), 1e-2)
+    bound("test_bfn_losses_vs_golden:108b", max_rel(extra["l_latent"], g["l_latent"]), 1e-3)
+    bound("test_bfn_losses_vs_golden:109a", max_rel(bpd, g["bpd"]), 1e-2)
+    bound("test_bfn_losses_vs_golden:109b", rel_linf(extra["bpd_var"], g["bpd_var"]), 1e-2)
     g = golden("g10_bfn_finite_elbo")
     with torch.no_grad(), replay_noise(randint=[g["i"]], randn=[g["eps_recon"], g["eps_latent"]]):
         elbo, bpd, extra = b.finite_elbo(g["x"].to(DEV), 2, 2, t=g["t"].to(DEV))
-    bound("test_bfn_losses_vs_golden:113", max_rel(extra["l_latent"], g["l_latent"]) < 1e-2 and max_rel(bpd, g["bpd"]), 1e-3)
+    bound("test_bfn_losses_vs_golden:113a", max_rel(extra["l_latent"], g["l_latent"]), 1e-2)
+    bound("test_bfn_losses_vs_golden:113b", max_rel(bpd, g["bpd"]), 1e-3)
     with pytest.raises(AttributeError):   # the reference's `self.linspace` quirk
         b.finite_elbo(g["x"].to(DEV), 2, 2)
 
@@ -122,7 +127,8 @@ def test_bfn_predict_and_sampler():
         xh = b._predict_x(g["mu"].to(DEV), g["t"].to(DEV))
     assert float(xh[:2].abs().max()) == 0.0 and float(xh.abs().max()) <= 1.0   # t < t_min -> 0; clipped to [x_min, x_max]
     # row 2 (t = 1e-3): gamma = 0.0137, the bf16 denoiser's error enters multiplied by sqrt((1 - gamma) / gamma) = 8.5
-    bound("test_bfn_predict_and_sampler:125", rel_linf(xh[3], g["x_hat"][3]) < 2e-2 and rel_linf(xh, g["x_hat"]), 5e-2)
+    bound("test_bfn_predict_and_sampler:125a", rel_linf(xh[3], g["x_hat"][3]), 2e-2)
+    bound("test_bfn_predict_and_sampler:125b", rel_linf(xh, g["x_hat"]), 5e-2)
     g = golden("g10_bfn_hist")
     k = int(g["k"])
     b = make_bfn(make_model(), k=k)
@@ -141,5 +147,6 @@ def test_bfn_predict_and_sampler():
     assert torch.equal(smp, x_hats[-1]) and torch.isfinite(mus).all()
     # rho_{i+1} = rho_i + alpha_i, rho_0 = 1: posterior precision of the refine update
     assert abs(float(rho[0]) - 1) < 1e-7 and rel_linf(rho[1:] - rho[:-1], alpha) < 1e-5
-    bound("test_bfn_predict_and_sampler:144", rel_linf(x_hats[:2], g["x_hats"][:2]) < 2e-2 and rel_linf(mus[:2], g["mus"][:2]), 1e-5)
+    bound("test_bfn_predict_and_sampler:144a", rel_linf(x_hats[:2], g["x_hats"][:2]), 2e-2)
+    bound("test_bfn_predict_and_sampler:144b", rel_linf(mus[:2], g["mus"][:2]), 1e-5)
     bound("test_bfn_predict_and_sampler:145", rel_linf(x_hats, g["x_hats"]), 0.3)

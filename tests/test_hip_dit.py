@@ -228,12 +228,15 @@ def test_elbo_vs_golden():
     x = g["x"].to(DEV)
     with torch.no_grad(), replay_noise(randn=[g["eps_r"], g["eps_m"]], rand=[g["offset"]], randperm=[g["perm"]]):
         elbo, bpd, extra = bsi.elbo(x, 3, 4, estimate_var=True)
-    bound("test_elbo_vs_golden:231", max_rel(extra["l_recon"], g["l_recon"]) < 2e-4 and max_rel(extra["l_measure"], g["l_measure"]), 1e-5)
-    bound("test_elbo_vs_golden:232", max_rel(elbo, g["elbo"]) < 2e-4 and max_rel(bpd, g["bpd"]), 1e-5)
+    bound("test_elbo_vs_golden:231a", max_rel(extra["l_recon"], g["l_recon"]), 2e-4)
+    bound("test_elbo_vs_golden:231b", max_rel(extra["l_measure"], g["l_measure"]), 1e-5)
+    bound("test_elbo_vs_golden:232a", max_rel(elbo, g["elbo"]), 2e-4)
+    bound("test_elbo_vs_golden:232b", max_rel(bpd, g["bpd"]), 1e-5)
     bound("test_elbo_vs_golden:233", max_rel(extra["bpd_var"], g["bpd_var"]), 1e-4)
     with torch.no_grad(), replay_noise(randn=[g["feps_r"], g["feps_m"]], randint=[g["fidx"]]):
         felbo, fbpd, fextra = bsi.finite_elbo(x, 3, 4, t=torch.linspace(0, 1, 17, device=DEV), estimate_var=True)
-    bound("test_elbo_vs_golden:236", max_rel(fextra["l_measure"], g["fl_measure"]) < 1e-4 and max_rel(felbo, g["felbo"]), 1e-5)
+    bound("test_elbo_vs_golden:236a", max_rel(fextra["l_measure"], g["fl_measure"]), 1e-4)
+    bound("test_elbo_vs_golden:236b", max_rel(felbo, g["felbo"]), 1e-5)
     with pytest.raises(AssertionError):
         with torch.no_grad():
             bsi.elbo(x, 1, 4, estimate_var=True)
@@ -648,7 +651,8 @@ def test_dp_trainer_exchange_path_on_one_rank():
                 outs.append((float(loss), tr.fp.flat.clone(), tr.ema_fp.flat.clone()))
             assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]), (gname, outs[0][0], outs[1][0])
             # atomics in the backward make the low bits run-dependent; the two paths must agree to fp32 noise
-            bound("test_dp_trainer_exchange_path_on_one_rank:651", rel_linf(outs[1][1], outs[0][1]) < 1e-5 and rel_linf(outs[1][2], outs[0][2]), 1e-5)
+            bound("test_dp_trainer_exchange_path_on_one_rank:651a", rel_linf(outs[1][1], outs[0][1]), 1e-5)
+            bound("test_dp_trainer_exchange_path_on_one_rank:651b", rel_linf(outs[1][2], outs[0][2]), 1e-5)
     finally:
         dist.destroy_process_group()
         if os.path.exists(store.name):

@@ -122,6 +122,7 @@ BOUNDS = {}  # tag -> (worst achieved value, limit) of this pytest process
 def bound(tag, value, limit):
     """assert value < limit, and remember the worst achieved value per tag: the terminal summary lists achieved / limit for every
     tag, so that an assertion bound far above what the kernels achieve is visible in the log."""
+    assert not isinstance(value, (bool, np.bool_)), (tag, "bound() takes the achieved error, not a comparison result")
     value = float(value)
     w = BOUNDS.get(tag, (0.0, limit))[0]
     BOUNDS[tag] = (max(w, value), limit)

@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the train benchmark (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=512, help="GLOBAL batch of the train benchmark (split over ranks)")
     ap.add_argument("--train-timeout", type=int, default=300, help="seconds before the train benchmark is abandoned")
+    ap.add_argument("--cu-reserve", type=int, default=16,
+                    help="compute units the persistent kernels leave to the RCCL kernels during a data-parallel train step "
+                         "(DPTrainer cu_reserve; N > 1 only, and the per-rank rehearsal at N = 1); the rank processes get "
+                         "NCCL_MAX_NCHANNELS = this unless the environment already sets it")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (UNet, DiT-L/4, ELBO)")
     ap.add_argument("--secondary-budget", type=float, default=150.0,
                     help="seconds the secondary block may use; entries that would not fit are reported as skipped")
@@ -165,17 +169,24 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
     nb = split_batch(a.train_batch, world, rank)
     model.train()
     sched = lambda s: warmup_cosine_lr(s, base_lr=5e-4, warmup_steps=1000, max_steps=1000000, start_lr=1e-8, end_lr=5e-5)  # noqa: E731
-    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, lr_schedule=sched)
+    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, lr_schedule=sched,
+                   cu_reserve=a.cu_reserve if world > 1 else 0)
     g = torch.Generator(dev).manual_seed(99 + rank)
-    u = torch.rand((nb, 3, 32, 32), device=dev, generator=g)
-    x = (torch.round(255 * u) / 255) * 2 - 1           # synthetic 8-bit images in [-1, 1]
+
+    def images(n):
+        u = torch.rand((n, 3, 32, 32), device=dev, generator=g)
+        return (torch.round(255 * u) / 255) * 2 - 1    # synthetic 8-bit images in [-1, 1]
+
+    x = images(nb)
     loss = tr.train_step(x, g)                          # warm-up (also builds the transposed weight shadows)
+    tr.time_stages = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.train_steps):
         loss = tr.train_step(x, g)
     barrier()
     dt = time.perf_counter() - t0
+    stages = tr.stage_ms()
     if world > 1:
         tm = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
@@ -184,8 +195,11 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
     comm = None
     if world > 1:
         # communication breakdown (so that a multi-GPU number comes with a diagnosis): the same steps WITHOUT the gradient
-        # exchange (ranks then train on their shards alone -- measured last, the losses above are from the exchanged steps)
+        # exchange.  Those steps would apply each rank's own gradient / world and let the replicas drift apart, so the
+        # trainer's state (parameters, moments, EMA, step count) is snapshotted before and restored after them.
         n2 = max(1, min(3, a.train_steps))
+        snap = [t.clone() for t in (tr.fp.flat, tr.m, tr.v)] + ([tr.ema_fp.flat.clone()] if tr.ema_fp else [])
+        step0 = tr.step_count
         tr.exchange = False
         tr.train_step(x, g)
         barrier()
@@ -195,19 +209,57 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
         barrier()
         d2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(d2, op=torch.distributed.ReduceOp.MAX)
+        tr.exchange = True
+        for dst, src in zip([tr.fp.flat, tr.m, tr.v] + ([tr.ema_fp.flat] if tr.ema_fp else []), snap):
+            dst.copy_(src)
+        tr.step_count = step0
+        tr.stage_ms()
+        del snap
         ms_no = 1e3 * float(d2.item()) / n2
         nbytes = 4 * tr.fp.flat.numel()
-        comm = {"allreduce_bytes": nbytes, "buckets": len(tr.xchg.plan), "ms_per_step_without_exchange": ms_no,
-                "exposed_comm_ms": 1e3 * dt / a.train_steps - ms_no,
-                "ring_busbw_GBps_if_fully_exposed": (2 * (world - 1) / world * nbytes / 1e9) /
-                                                    max(1e-9, (1e3 * dt / a.train_steps - ms_no) * 1e-3)}
+        exposed = 1e3 * dt / a.train_steps - ms_no
+        comm = {"allreduce_bytes": nbytes, "buckets": len(tr.xchg.plan), "cu_reserve": tr.cu_reserve,
+                "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "ms_per_step_without_exchange": ms_no, "exposed_comm_ms": exposed,
+                # a lower bound of the ring bus bandwidth, meaningful only when a measurable part of the exchange is exposed
+                "ring_busbw_GBps_if_fully_exposed": ((2 * (world - 1) / world * nbytes / 1e9) / (exposed * 1e-3)) if exposed > 0.5 else None}
+    per_rank = None
+    if world == 1 and a.train_batch >= 8:
+        # The per-rank workloads of the multi-GPU configurations (BASELINE configs[3]: the global batch split over 2 / 4 / 8
+        # ranks, bsi/data/h5image.py:309-312), measured on this one GPU: the compute half of the 2- / 4- / 8-GPU step, with and
+        # without the CU reserve the data-parallel step runs under, optimizer time split out (it does not shrink with the shard).
+        per_rank = []
+        for w_ in (2, 4, 8):
+            b_ = a.train_batch // w_
+            xs = images(b_)
+            rec = {"world": w_, "per_gpu_batch": b_}
+            for key, r_ in (("", 0), ("_cu_reserve", a.cu_reserve)):
+                tr.cu_reserve = r_
+                tr.train_step(xs, g)
+                tr.stage_ms()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_ = max(3, min(a.train_steps, 5))
+                for _ in range(n_):
+                    tr.train_step(xs, g)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t1) / n_
+                fb, opt = tr.stage_ms()
+                rec["ms_per_step" + key] = ms
+                rec["fwd_bwd_ms" + key] = fb
+                rec["optimizer_ms" + key] = opt
+            rec["cu_reserve"] = a.cu_reserve
+            rec["model_tflops"] = b_ * 3 * FWD_GFLOP_PER_IMG / rec["ms_per_step"]
+            per_rank.append(rec)
+        tr.cu_reserve = 0
     model.eval()
     steps_per_s = a.train_steps / dt
     return {"comm": comm, "metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+all-reduce+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
             "value": steps_per_s, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.train_steps, "global_batch": a.train_batch,
             "per_gpu_batch": nb, "images_per_s": steps_per_s * a.train_batch, "scaling": "strong",
             "model_tflops_per_gpu": steps_per_s * a.train_batch * 3 * FWD_GFLOP_PER_IMG / 1e3 / world,
-            "loss": float(loss)}
+            "fwd_bwd_exchange_ms": stages[0] if stages else None, "optimizer_ms": stages[1] if stages else None,
+            "per_rank_workloads_on_one_gpu": per_rank, "loss": float(loss)}
 
 
 def secondary_bench(a, bsi, dev, budget_s):
@@ -367,6 +419,8 @@ def launch_ranks(a, command=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # a user's setting wins
+        if getattr(a, "cu_reserve", 0) > 0:
+            env.setdefault("NCCL_MAX_NCHANNELS", str(a.cu_reserve))  # RCCL: at most as many workgroups as CUs are reserved for it
         procs.append(subprocess.Popen(command or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # rank 0's stdout is drained by a thread while all children are POLLED: when one exits non-zero (bad device, out of memory)
@@ -426,6 +480,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if a.cu_reserve > 0:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.cu_reserve))  # before init_process_group (torchrun launches land here)
         if ONE_DEVICE:
             local = 0
             dist.init_process_group("gloo")

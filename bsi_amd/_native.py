@@ -226,6 +226,8 @@ _PROTOS = {
     "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                              _vp, _vp, _vp, _vp]),
     "bsi_clock_probe": (_i, [_vp, _i, _vp]),
+    "bsi_set_cu_reserve": (_i, [_i]),
+    "bsi_compute_cus": (_i, []),
     "bsi_prof_enable": (_i, [C.c_uint]),
     "bsi_prof_read": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

@@ -641,7 +641,7 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
     BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 4 == 0, "bsi_attention_bwd: bad leading dimensions");
     static const bool resident_only = getenv("BSI_ATTN_BWD_RESIDENT") != nullptr;  // A/B partner of the persistent kernel
     if (tokens == PT && !resident_only) {
-        const int pairs = B * heads, ncu = device_cus();
+        const int pairs = B * heads, ncu = compute_cus();
         const int grid = pairs < ncu ? pairs : ncu;
         constexpr int plds = STATS + 3 * PT * 4;
         const float sc = 1.0f / sqrtf((float)dh);

@@ -251,7 +251,7 @@ int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int l
     auto kern = attention_fwd_p_kernel<DROP, LSE>;
     constexpr int lds = P_SCR + 16 * 2048;  // 160 KB
     set_max_lds(reinterpret_cast<const void*>(kern), lds);
-    const int pairs = B * heads, ncu = device_cus();
+    const int pairs = B * heads, ncu = compute_cus();
     const int grid = pairs < ncu ? pairs : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, qkv, ld_qkv, pairs, heads, out, ld_out,
                        1.4426950408889634f / sqrtf((float)PDH), lse, dc);

@@ -68,6 +68,17 @@ inline int device_cus() {
     return cus[dev];
 }
 
+// Compute units the persistent kernels may fill: device_cus() minus the CUs reserved for kernels of another stream that must
+// be able to run BESIDE them -- the RCCL all-reduce of the data-parallel step (bsi_set_cu_reserve, bsi_amd/dp.py).  Every
+// kernel of this library that launches "one workgroup per CU" with a static partition of its tiles sizes its grid (and the
+// split counts derived from it) with this: a 160-KB-LDS workgroup that cannot be placed because a communication kernel holds
+// its CU would otherwise start a whole kernel late and double the launch's duration.
+extern int g_bsi_cu_reserve;  // prof.hip
+inline int compute_cus() {
+    const int c = device_cus() - g_bsi_cu_reserve;
+    return c < 8 ? 8 : c;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }

@@ -754,19 +754,13 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 #undef PHASE_BARRIER
 }
 
-int g_conv_cus = 0;
 int g_conv_abl = 0;
 int g_conv_grid_limit = 0;  // > 0: at most this many workgroups (tests: several tiles per workgroup on small inputs)
 
 int conv_cus() {
-    if (g_conv_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_conv_cus = prop.multiProcessorCount;
-        if (g_conv_cus <= 0) g_conv_cus = 256;
-    }
-    if (g_conv_grid_limit > 0 && g_conv_grid_limit < g_conv_cus) return g_conv_grid_limit;
-    return g_conv_cus;
+    const int cus = compute_cus();
+    if (g_conv_grid_limit > 0 && g_conv_grid_limit < cus) return g_conv_grid_limit;
+    return cus;
 }
 
 template <int EPI>

@@ -510,15 +510,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_conv2d_kernel(const float* _
     }
 }
 
-int g_wg_cus = 0;
-
-void plan(WgParams& p) {
-    if (g_wg_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_wg_cus = prop.multiProcessorCount;
-        if (g_wg_cus <= 0) g_wg_cus = 256;
-    }
+void plan(WgParams& p, int cus = 0) {
+    const int g_wg_cus = cus > 0 ? cus : compute_cus();  // one workgroup per CU per round (minus the CUs reserved for communication)
     {   // 3 or 4 units of 128 im2col columns per tile: whichever pads the K range less (4 on a tie)
         const int nu = (p.Ktot + 127) / 128;
         const int pad4 = (nu + 3) / 4 * 4 - nu, pad3 = (nu + 2) / 3 * 3 - nu;
@@ -563,8 +556,15 @@ extern "C" size_t bsi_conv_wgrad_workspace_bytes(int M, int Cin, int Cin2, int C
     if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
     WgParams p{};
     p.M = M; p.Cin = Cin; p.Cin2 = Cin2; p.Cout = Cout; p.taps = taps; p.Ktot = taps * Cin + Cin2;
-    plan(p);
-    return (size_t)p.splits * p.slab_stride * sizeof(float) + (size_t)p.splits * (size_t)Cout * sizeof(float);  // + bias-gradient slabs
+    // the split count depends on the CUs the launch may fill: size for every reserve bsi_set_cu_reserve accepts, so that a
+    // workspace allocated before the reserve changed still fits
+    size_t worst = 0;
+    for (int cus = device_cus(); cus >= 8 && cus >= device_cus() - BSI_MAX_CU_RESERVE; cus -= 8) {
+        plan(p, cus);
+        const size_t b = (size_t)p.splits * p.slab_stride * sizeof(float) + (size_t)p.splits * (size_t)Cout * sizeof(float);  // + bias-gradient slabs
+        worst = b > worst ? b : worst;
+    }
+    return worst;
 }
 
 struct Conv2dOut {  // optional: write the torch Conv2d layout instead of the packed one (engine-internal entry below)

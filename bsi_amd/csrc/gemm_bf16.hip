@@ -749,7 +749,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
 }
 
 extern int g_gm;
-int num_cus();
 
 // ---------------------------------------------------------------------------------------------------------
 // Variant 12: 128-B tile rows (whole cache lines per DMA row, see variant 10) on a RING OF FIVE HALF-STAGES.
@@ -976,18 +975,7 @@ int launch_cfg(const GemmParams& p0, hipStream_t s) {
 
 int g_variant = 12;  // 12: production (K = 64 half-stage ring + K = 32 ring), 6: K = 32 ring only
 int g_gm = 4;  // band height: 4 m-tiles x 8 n-tiles per XCD round minimises L2 misses (PMC: fc1 605 -> 403 MB per launch)
-int g_num_cus[64] = {};
-
-int num_cus() {  // of the CURRENT device (a process may drive several)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (g_num_cus[dev] == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus[dev] = prop.multiProcessorCount;
-        if (g_num_cus[dev] <= 0) g_num_cus[dev] = 256;
-    }
-    return g_num_cus[dev];
-}
+// grids: compute_cus() (common.h) = the CUs of the current device minus those reserved for a concurrent communication kernel
 
 template <int EPI>
 int launch_k64r(const GemmParams& p0, hipStream_t s) {
@@ -997,7 +985,7 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const int grid = nwg < compute_cus() ? nwg : compute_cus();
     const size_t lds = 5 * (size_t)256 * 128;
     auto kern = gemm_bf16_k64r_kernel<EPI>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -1014,7 +1002,7 @@ int launch_pring(const GemmParams& p0, hipStream_t s) {
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const int grid = nwg < compute_cus() ? nwg : compute_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
     auto kern = gemm_bf16_pring_kernel<EPI>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -1069,14 +1057,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 }
 
 // number of K slices for this problem (1 = do not split): only for few tiles, K long enough, slices of whole 128-column blocks
-int splitk_plan(int M, int N, int K) {
+int splitk_plan(int M, int N, int K, int cus) {
     // K >= 2048 only: measured (tools/experiments/splitk_time.py) fc2 (K = 4096) 72 -> 28..40 us, but the K = 1024 GEMMs get slower
     // (22 -> 26..37 us): their K loop is already short and the fp32 slab round trip + finishing launch cost more than they save
     if (M <= 128 || M > 2048 || K < 2048 || K % 128 != 0 || N % 4 != 0) return 1;
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
     int best = 1;
     for (int sp = 2; sp <= 8; sp *= 2)
-        if (K % (sp * 128) == 0 && K / sp >= 256 && tiles * sp <= num_cus()) best = sp;
+        if (K % (sp * 128) == 0 && K / sp >= 256 && tiles * sp <= cus) best = sp;
     return best;
 }
 
@@ -1094,7 +1082,7 @@ int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
     const int nwg = p.tiles_m * p.tiles_n * splits;
-    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const int grid = nwg < compute_cus() ? nwg : compute_cus();
     const size_t lds = 4 * (size_t)512 * 64 + 32768;
     auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32>;
     set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -1166,7 +1154,7 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
 }
 
 extern "C" size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K) {
-    const int sp = splitk_plan(M, N, K);
+    const int sp = splitk_plan(M, N, K, device_cus());  // the most splits any CU reserve can ask for
     return sp > 1 ? (size_t)sp * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -1177,7 +1165,7 @@ extern "C" int bsi_gemm_bf16_ws(const bsi_gemm_args* a, void* workspace, size_t 
     if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0 && a->N % 16 == 0 &&
         a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && a->ldo >= a->N &&
         (a->epilogue == BSI_EPI_BIAS_BF16 || a->epilogue == BSI_EPI_BIAS_GELU_BF16 || a->epilogue == BSI_EPI_BIAS_SILU_BF16)) {
-        const int sp = splitk_plan(a->M, a->N, a->K);
+        const int sp = splitk_plan(a->M, a->N, a->K, compute_cus());
         if (sp > 1 && workspace_bytes >= (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float)) {
             GemmParams p{};
             p.A = reinterpret_cast<const __bf16*>(a->A);

@@ -727,10 +727,7 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
     BSI_CHECK_ARG(ldc == K, "bsi_gemm_tn_bf16: output must be dense (ldc == K)");
     BSI_CHECK_ARG(K % 4 == 0, "bsi_gemm_tn_bf16: K %% 4");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    const int cus = compute_cus();  // one workgroup per CU per round; CUs reserved for a communication kernel are left out
     TnParams p{};
     p.P = reinterpret_cast<const __bf16*>(P);
     p.Q = reinterpret_cast<const __bf16*>(Q);

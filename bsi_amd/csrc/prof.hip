@@ -28,6 +28,18 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+int g_bsi_cu_reserve = 0;  // see compute_cus(), common.h
+
+extern "C" int bsi_set_cu_reserve(int cus) {
+    BSI_CHECK_ARG(cus >= 0 && cus % 8 == 0 && cus <= BSI_MAX_CU_RESERVE,
+                  "bsi_set_cu_reserve: %d is not 0 or a multiple of 8 up to %d (workgroups are dealt to the 8 XCDs round robin)", cus,
+                  BSI_MAX_CU_RESERVE);
+    g_bsi_cu_reserve = cus;
+    return BSI_OK;
+}
+
+extern "C" int bsi_compute_cus(void) { return compute_cus(); }
+
 void bsi_prof_begin(int cls, hipStream_t s) {
     if (!(g_mask & (1u << cls))) return;
     std::lock_guard<std::mutex> lk(g_mu);

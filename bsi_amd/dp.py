@@ -11,6 +11,7 @@ after every batch (bsi/tasks/bsi.py:196-198, bsi/tasks/ema_pytorch.py:308-340).
 import copy
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -137,7 +138,8 @@ class DPTrainer:
 
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
-                 ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False):
+                 ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False,
+                 cu_reserve: int | None = None):
         self.bsi = bsi
         self.model = bsi.model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -148,6 +150,19 @@ class DPTrainer:
         # force_exchange runs the gradient exchange (events, side stream, RCCL calls) even in a group of one rank, so that
         # the multi-GPU code path can be exercised on a single device
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        # Compute units left to the RCCL kernels for the length of a step.  The GEMM / weight-gradient / attention / convolution
+        # kernels of the backward are persistent: one 160-KB-LDS workgroup per CU with a STATIC share of the tiles.  An all-reduce
+        # kernel of `_exchange` that holds c CUs while a bucket is in flight would leave c of those workgroups unplaced until the
+        # others finish -- the launch takes up to twice as long.  With the reserve the grids are `CUs - reserve` wide and the
+        # communication kernels find their CUs free (DDP's reducer in the reference simply shares the GPU, bsi/tasks/bsi.py:163-166).
+        # Default: BSI_DP_CU_RESERVE or 16 when the exchange is on (bench.py caps RCCL's channels to the same number), else 0.
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get("BSI_DP_CU_RESERVE", "16")) if self.exchange else 0
+        self.cu_reserve = int(cu_reserve)
+        # measurement hook (bench.py): with time_stages on, every step appends three HIP events (start, after backward + exchange,
+        # after the optimizer) to stage_events; `stage_ms()` turns them into (forward + backward + exchange, optimizer) milliseconds
+        self.time_stages = False
+        self.stage_events = []
         self.step_count = 0
         self.ema_beta, self.ema_after = ema_beta, ema_update_after_step
         self._invalidate(self.model)
@@ -236,6 +251,16 @@ class DPTrainer:
                                        self.betas[1], self.eps, self.weight_decay, self.step_count, ema_w, N.stream()))
         self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
 
+    def stage_ms(self):
+        """Mean (forward + backward + exchange, optimizer) milliseconds of the steps recorded since the last call."""
+        evs, self.stage_events = self.stage_events, []
+        if not evs:
+            return None
+        evs[-1][2].synchronize()
+        a = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
+        b = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)
+        return a, b
+
     # ------------------------------------------------------------------------------------------------
     def _invalidate(self, model):
         model._pack = None
@@ -243,13 +268,28 @@ class DPTrainer:
 
     def train_step(self, x: torch.Tensor, generator=None) -> torch.Tensor:
         """One optimizer step on this rank's shard `x`; returns the (local) mean loss (detached)."""
-        loss, flat_g = self._backward(x, generator)
-        if self.exchange:
-            self._exchange(flat_g)
+        reserve = self.cu_reserve if x.is_cuda else 0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (self.time_stages and x.is_cuda) else None
+        if ev:
+            ev[0].record()
+        if reserve:
+            N.check(N.lib().bsi_set_cu_reserve(reserve))  # grids are sized at launch: in effect for the kernels enqueued below
+        try:
+            loss, flat_g = self._backward(x, generator)
+            if self.exchange:
+                self._exchange(flat_g)
+        finally:
+            if reserve:
+                N.check(N.lib().bsi_set_cu_reserve(0))    # sampling / evaluation between steps use every CU
         lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
         w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
         self.step_count += 1
+        if ev:
+            ev[1].record()
         self._update(flat_g, lr, w)
+        if ev:
+            ev[2].record()
+            self.stage_events.append(ev)
         self._invalidate(self.model)
         if self.ema_model is not None:
             self._invalidate(self.ema_model)

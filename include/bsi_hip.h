@@ -614,6 +614,14 @@ enum {
     BSI_PROF_ATTN = 4, BSI_PROF_LN = 5, BSI_PROF_PROLOGUE = 6, BSI_PROF_FINAL = 7, BSI_PROF_GEMM_ENC = 8,
     BSI_PROF_ADALN = 9, BSI_PROF_NCLASS = 16
 };
+/* Data-parallel step (replaces what DDP's reducer gets from running on its own stream, /root/reference bsi/tasks/bsi.py:163-166):
+ * leave `cus` compute units (0 or a multiple of 8, at most BSI_MAX_CU_RESERVE) out of every persistent kernel's grid -- the
+ * GEMMs, weight-gradient GEMMs, convolutions and attention kernels launch one 160-KB-LDS workgroup per CU with a static share
+ * of the tiles, so a workgroup whose CU is held by an RCCL kernel would start a whole kernel late.  Process-wide, takes effect
+ * at the next launch; 0 (the default) = all CUs.  bsi_compute_cus: the CU count those kernels size their grids with. */
+#define BSI_MAX_CU_RESERVE 64
+int bsi_set_cu_reserve(int cus);
+int bsi_compute_cus(void);
 /* bit i of mask enables class i; 0 disables.  Events are recorded around every launch of an enabled class
  * made through bsi_dit_forward / bsi_dit_adaln. */
 int bsi_prof_enable(unsigned mask);

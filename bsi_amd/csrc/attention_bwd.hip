@@ -294,11 +294,19 @@ __device__ __forceinline__ float group_sum(float v) {  // sum over the four 16-l
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
-template <bool DROP>
+// DROP: 0 = no dropout; 1 = the mask is evaluated here from the counter hash (drop_keep_rc); 2 = the mask arrives as the 64-bit
+// words the persistent forward kernel wrote (attention_persist.hip: word (16-query block qb, 16-key block kt, r), bit 16 g + c =
+// keep(query 16 qb + c, key 16 kt + 4 g + r); 8 KB per pair, fetched by LDS-DMA beside the K / V tiles, double buffered).  Pass 1
+// has exactly the forward's lane <-> (query, key) map, so a word is the select mask of v_cndmask as it stands (scalar register
+// pair); pass 2 (a lane = one key, four queries) reads the 16-bit group of its key and tests four bits.  The survivors' scale
+// multiplies dP inside the fused multiply-add of dS and the dV tile once at the end.
+constexpr int MASKW = STATS + 3 * PT * 4, MASKW_BYTES = 8192;
+
+template <int DROP>
 __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __restrict__ qkv, int ld_qkv, const __bf16* __restrict__ o,
                                                               const __bf16* __restrict__ dout, int ld_o, const float* __restrict__ lse,
                                                               int pairs, int heads, __bf16* __restrict__ dqkv, int ld_dqkv, float scale,
-                                                              DropCfg dc) {
+                                                              DropCfg dc, const char* __restrict__ maskw) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lse_s = reinterpret_cast<float*>(lds + STATS);
     float* dlt_s = lse_s + PT;
@@ -334,6 +342,11 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + off2 + t * str2), LDS_PTR(dst2 + t * 1024), 16, 0, 0);
+    };
+    auto issue_mask = [&](int pr, int mbuf) {  // DROP == 2: the pair's 8 KB of mask words, 1 KB per wave (always in front of group A: no count changes)
+        if constexpr (DROP == 2)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(maskw + (size_t)pr * MASKW_BYTES + wave * 1024 + lane * 16),
+                                             LDS_PTR(lds + MASKW + mbuf * MASKW_BYTES + wave * 1024), 16, 0, 0);
     };
     // ---- this wave's own rows of the NEXT pair, as MFMA fragments straight from memory (inline asm: the compiler must not wait for them)
     u32x4 qn[2][2], dn[2][2], on[2][2];
@@ -377,7 +390,9 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 
     int pr = blockIdx.x;
     if (pr >= pairs) return;
+    int mbuf = 0;
     issue_kv(pr);
+    issue_mask(pr, 0);
     issue_group_a(pr);
     issue_group_b(pr);
     WAIT_A(0);
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
             dq_delta[jq] = group_sum(a);
             lq[jq] = lsn[jq] * L2E;
             const int q = r0 + 16 * jq + c16;
-            if constexpr (DROP) rh[jq] = drop_row(dc, (unsigned)pr * PT + q);
+            if constexpr (DROP == 1) rh[jq] = drop_row(dc, (unsigned)pr * PT + q);
             if (g == 0) {
                 dlt_s[q] = dq_delta[jq];
                 lse_s[q] = lq[jq];
@@ -458,14 +473,33 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int jq = 0; jq < 2; ++jq)
+                for (int jq = 0; jq < 2; ++jq) {
+                    u32x4 mwa = u32x4{0u, 0u, 0u, 0u}, mwb = mwa;
+                    if constexpr (DROP == 2) {  // the four words (r = 0..3) of (query block 2 wave + jq, key block kc / 16 + kt): wave-uniform address
+                        const char* mp = lds + MASKW + mbuf * MASKW_BYTES + (((2 * wave + jq) * 16 + (kc >> 4) + kt) << 5);
+                        mwa = *reinterpret_cast<const u32x4*>(mp);
+                        mwb = *reinterpret_cast<const u32x4*>(mp + 16);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][jq][r], sl2, -lq[jq]));
                         float dpv = dp[kt][jq][r];
-                        if constexpr (DROP) dpv = drop_keep_rc(dc, rh[jq], kc + 16 * kt + 4 * g + r) ? dpv * dc.scale : 0.0f;
-                        s[kt][jq][r] = scale * pv * (dpv - dq_delta[jq]);
+                        if constexpr (DROP == 1) dpv = drop_keep_rc(dc, rh[jq], kc + 16 * kt + 4 * g + r) ? dpv * dc.scale : 0.0f;
+                        if constexpr (DROP == 2) {
+                            const unsigned lo = r < 2 ? mwa[2 * r] : mwb[2 * r - 4], hi = r < 2 ? mwa[2 * r + 1] : mwb[2 * r - 3];
+                            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hi) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readfirstlane(lo);
+                            dpv = __builtin_amdgcn_inverse_ballot_w64(w) ? dpv : 0.0f;
+                            s[kt][jq][r] = scale * pv * __fmaf_rn(dpv, dc.scale, -dq_delta[jq]);
+                        } else {
+                            s[kt][jq][r] = scale * pv * (dpv - dq_delta[jq]);
+                        }
                     }
+                    if constexpr (DROP == 2) {  // one (key block, query block) at a time: otherwise every block's words (64 scalar registers) are live at once
+                        asm volatile("" : "+v"(s[kt][jq][0]), "+v"(s[kt][jq][1]), "+v"(s[kt][jq][2]), "+v"(s[kt][jq][3]));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]: the eight transposed reads of a 32-key block as inline asm (behind the
             // builtin hipcc drains vmcnt -- the Q / dO tiles in flight), then one wait that names them
             const unsigned kco = (unsigned)kc * RB;
@@ -524,6 +558,7 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 
         // =========================== pass 2: dK, dV for keys r0 .. r0+31 ===========================
         issue_kv(nxt);
+        issue_mask(nxt, mbuf ^ 1);
         issue_group_a(nxt);
         f32x4 dk[4][2], dv[4][2];
 #pragma unroll
@@ -554,21 +589,36 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
                 const f32x4 lr = *reinterpret_cast<const f32x4*>(lse_s + qc + 16 * qt + 4 * g);
                 const f32x4 dr = *reinterpret_cast<const f32x4*>(dlt_s + qc + 16 * qt + 4 * g);
                 u32x4 rhq = u32x4{0u, 0u, 0u, 0u};
-                if constexpr (DROP) rhq = *reinterpret_cast<const u32x4*>(rowh_s + qc + 16 * qt + 4 * g);
+                if constexpr (DROP == 1) rhq = *reinterpret_cast<const u32x4*>(rowh_s + qc + 16 * qt + 4 * g);
 #pragma unroll
-                for (int jk = 0; jk < 2; ++jk)
+                for (int jk = 0; jk < 2; ++jk) {
+                    unsigned mbits = 0u;  // bit r: keep(query qc + 16 qt + 4 g + r, this lane's key r0 + 16 jk + c16)
+                    if constexpr (DROP == 2) {
+                        // word (query block qc / 16 + qt, key block 2 wave + jk, r = key & 3), its 16-bit group (key >> 2) & 3, bits 4 g ..
+                        const char* mp = lds + MASKW + mbuf * MASKW_BYTES + ((((qc >> 4) + qt) * 16 + 2 * wave + jk) << 5) + (c16 & 3) * 8 + (c16 >> 2) * 2;
+                        mbits = (unsigned)*reinterpret_cast<const unsigned short*>(mp) >> (4 * g);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[qt][jk][r], sl2, -lr[r]));
                         float dpv = dp[qt][jk][r], pd = pv;
-                        if constexpr (DROP) {
+                        if constexpr (DROP == 1) {
                             const bool keep = drop_keep_rc(dc, rhq[r], r0 + 16 * jk + c16);
                             dpv = keep ? dpv * dc.scale : 0.0f;
                             pd = keep ? pv * dc.scale : 0.0f;
                         }
-                        s[qt][jk][r] = pd;                          // dropped P (for dV)
-                        dp[qt][jk][r] = scale * pv * (dpv - dr[r]);  // dS
+                        if constexpr (DROP == 2) {
+                            const bool keep = (mbits >> r) & 1u;
+                            dpv = keep ? dpv : 0.0f;
+                            pd = keep ? pv : 0.0f;       // 1 / (1 - p) multiplies the dV tile at the end
+                            s[qt][jk][r] = pd;
+                            dp[qt][jk][r] = scale * pv * __fmaf_rn(dpv, dc.scale, -dr[r]);
+                        } else {
+                            s[qt][jk][r] = pd;                          // dropped P (for dV)
+                            dp[qt][jk][r] = scale * pv * (dpv - dr[r]);  // dS
+                        }
                     }
+                }
             }
             bf16x8 pf[2], dsf[2];
 #pragma unroll
@@ -614,12 +664,14 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
                 u32x2 wk_, wv_;
                 wk_[0] = pack_bf16x2(dk[dt][jk][0], dk[dt][jk][1]);
                 wk_[1] = pack_bf16x2(dk[dt][jk][2], dk[dt][jk][3]);
-                wv_[0] = pack_bf16x2(dv[dt][jk][0], dv[dt][jk][1]);
-                wv_[1] = pack_bf16x2(dv[dt][jk][2], dv[dt][jk][3]);
+                const float vs = DROP == 2 ? dc.scale : 1.0f;
+                wv_[0] = pack_bf16x2(dv[dt][jk][0] * vs, dv[dt][jk][1] * vs);
+                wv_[1] = pack_bf16x2(dv[dt][jk][2] * vs, dv[dt][jk][3] * vs);
                 *reinterpret_cast<u32x2*>(drow_ + heads * DH + 16 * dt + 4 * g) = wk_;
                 *reinterpret_cast<u32x2*>(drow_ + 2 * heads * DH + 16 * dt + 4 * g) = wv_;
             }
         }
+        mbuf ^= 1;
         WAIT_A(20);  // the next K / V tiles (8) and fragment group A (10) have landed; O fragments (4) and the 16 stores may fly
         PBARRIER();
         if (pr + (int)gridDim.x >= pairs) break;
@@ -634,7 +686,8 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 }  // namespace
 
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
-                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream) {
+                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
+                           const void* maskw) {
     BSI_CHECK_ARG(qkv && out && dout && lse && dqkv && B > 0 && heads > 0, "bsi_attention_bwd: bad args");
     BSI_CHECK_ARG(dh == 64, "bsi_attention_bwd: head dim %d unsupported (64)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
@@ -645,17 +698,17 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
         const int grid = pairs < ncu ? pairs : ncu;
         constexpr int plds = STATS + 3 * PT * 4;
         const float sc = 1.0f / sqrtf((float)dh);
-        if (dc.thr) {
-            set_max_lds(reinterpret_cast<const void*>(attention_bwd_p_kernel<true>), plds);
-            hipLaunchKernelGGL(attention_bwd_p_kernel<true>, dim3(grid), dim3(512), plds, reinterpret_cast<hipStream_t>(stream),
+        const bool words = dc.thr && maskw && bsi_attention_uses_mask_words(tokens, dh);
+        auto go = [&](auto kern, int lds_bytes) {
+            set_max_lds(reinterpret_cast<const void*>(kern), lds_bytes);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream),
                                reinterpret_cast<const __bf16*>(qkv), ld_qkv, reinterpret_cast<const __bf16*>(out),
-                               reinterpret_cast<const __bf16*>(dout), ld_o, lse, pairs, heads, reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc);
-        } else {
-            set_max_lds(reinterpret_cast<const void*>(attention_bwd_p_kernel<false>), plds);
-            hipLaunchKernelGGL(attention_bwd_p_kernel<false>, dim3(grid), dim3(512), plds, reinterpret_cast<hipStream_t>(stream),
-                               reinterpret_cast<const __bf16*>(qkv), ld_qkv, reinterpret_cast<const __bf16*>(out),
-                               reinterpret_cast<const __bf16*>(dout), ld_o, lse, pairs, heads, reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc);
-        }
+                               reinterpret_cast<const __bf16*>(dout), ld_o, lse, pairs, heads, reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc,
+                               reinterpret_cast<const char*>(maskw));
+        };
+        if (words) go(attention_bwd_p_kernel<2>, plds + 2 * MASKW_BYTES);
+        else if (dc.thr) go(attention_bwd_p_kernel<1>, plds);
+        else go(attention_bwd_p_kernel<0>, plds);
         BSI_CHECK_LAUNCH("bsi_attention_bwd(persistent)");
         return BSI_OK;
     }

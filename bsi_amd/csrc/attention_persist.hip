@@ -12,7 +12,13 @@
 //     address of each lane;
 //   * scores transposed (S^T = K.Q^T), softmax over two 128-key chunks (one online rescale per pair), P^T packed to bf16 = B
 //     operand of O^T = V^T.P^T; every LDS address = a per-lane register + an immediate (no vector-ALU address arithmetic);
-//   * the 16 x 64 output tile of a wave leaves through 2 KB of LDS as whole 128-B lines (2 store instructions per wave).
+//   * the 16 x 64 output tile of a wave leaves through 2 KB of LDS as whole 128-B lines (2 store instructions per wave);
+//   * training dropout (dit.py:43-44, `dropout_p` of SDPA) arrives as MASK WORDS made by attn_dropmask_kernel below: per
+//     (pair, 16-query block qb, 16-key block kt, r) one 64-bit word whose bit 16 g + c is keep(query 16 qb + c, key 16 kt + 4 g + r)
+//     -- exactly this kernel's (and the backward's first pass's) lane <-> (query, key) map, so a word IS the select mask of
+//     v_cndmask (a scalar register pair): one vector instruction per probability instead of the ~10 the counter hash took inside
+//     the softmax (round 3: 240 -> 373 us with dropout).  A wave's 512 B of words for the NEXT pair are fetched by LDS-DMA into
+//     its output scratch once the epilogue has read it back.  The survivors' scale 1 / (1 - p) multiplies the output row once.
 #include <type_traits>
 
 #include "common.h"
@@ -50,7 +56,7 @@ __device__ __forceinline__ s16x4 tr_read(unsigned addr) {
 template <bool DROP, bool LSE>
 __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __restrict__ qkv, int ld_qkv, int pairs, int heads,
                                                                __bf16* __restrict__ out, int ld_out, float scale_log2e,
-                                                               float* __restrict__ lse, DropCfg dc) {
+                                                               float* __restrict__ lse, DropCfg dc, const char* __restrict__ maskw) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,19 +65,22 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
 
     // ---- LDS-DMA plan: 64 instructions of 1 KB per pair (K rows 0..255, then V rows 0..255), 4 per wave
     const int tile = wave >> 3;                      // waves 0-7 fetch K, waves 8-15 fetch V
-    unsigned soff[4];                                 // per-lane source byte offset from the pair's Q base
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = 8 * ((4 * wave + t) & 31) + (lane >> 3), p = lane & 7;
-        const int c = tile == 0 ? (p ^ ((row >> 1) & 7)) : ((((p >> 1) ^ ((row >> 1) & 3)) << 1) | (p & 1));
-        soff[t] = (unsigned)row * (unsigned)(ld_qkv * 2) + (unsigned)c * 16u + (unsigned)((tile + 1) * heads * PDH * 2);
-    }
     const int dma_dst = tile * (PT * PRB) + ((4 * wave) & 31) * 1024;   // + t * 1024 + buf * P_BUF
     auto pair_base = [&](int pr) { return reinterpret_cast<const char*>(qkv) + ((size_t)(pr / heads) * PT * ld_qkv + (size_t)(pr % heads) * PDH) * 2; };
+    // The per-lane source offsets are RECOMPUTED at every issue (a dozen vector instructions per pair) from a lane id the compiler
+    // cannot see through: as loop invariants they were four 64-bit address pairs live through the whole pair, and the kernel sits at
+    // its 128-register cap -- the training instances spilled exactly those, and every reload (scratch load + s_waitcnt vmcnt(0) right
+    // behind an LDS-DMA issue) waited for that DMA to land.
     auto issue_kv = [&](const char* base, int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(base + soff[t]), LDS_PTR(lds + buf * P_BUF + dma_dst + t * 1024), 16, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            const int row = 8 * ((4 * wave + t) & 31) + (ln >> 3), p = ln & 7;
+            const int c = tile == 0 ? (p ^ ((row >> 1) & 7)) : ((((p >> 1) ^ ((row >> 1) & 3)) << 1) | (p & 1));
+            const unsigned so = (unsigned)row * (unsigned)(ld_qkv * 2) + (unsigned)c * 16u + (unsigned)((tile + 1) * heads * PDH * 2);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(base + so), LDS_PTR(lds + buf * P_BUF + dma_dst + t * 1024), 16, 0, 0);
+        }
     };
     // Q fragments of the NEXT pair: plain loads the compiler must not wait for (its own waits would drain the output stores too)
     const unsigned qoff = (unsigned)(q0 + c16) * (unsigned)(ld_qkv * 2) + (unsigned)g * 16u;
@@ -81,16 +90,25 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(qn1) : "v"(base + qoff) : "memory");
     };
 
+    char* scr = lds + P_SCR + wave * 2048;
+    auto issue_mask = [&](int p_) {  // this wave's 64 mask words (512 B: lanes 0..31) of pair p_ into the head of its scratch
+        if constexpr (DROP) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));  // recomputed per pair, like the K / V offsets (as a loop invariant this address was spilled)
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((p_ * 16 + wave) * 512);  // scalar: pairs * 8 KB < 4 GB (launcher)
+            if (ln < 32) __builtin_amdgcn_global_load_lds(GLB_PTR(maskw + so + ln * 16), LDS_PTR(scr), 16, 0, 0);
+        }
+    };
     int pr = blockIdx.x;
     if (pr >= pairs) return;
     {
         const char* base = pair_base(pr);
+        issue_mask(pr);
         issue_kv(base, 0);
         issue_q(base);
     }
     asm volatile("s_waitcnt vmcnt(0) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
     int buf = 0;
-    char* scr = lds + P_SCR + wave * 2048;
     while (true) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // every wave's share of this pair's K/V has landed; the previous pair is finished
@@ -122,8 +140,8 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
                        va3 = vbase + ((3 ^ vkey) << 5);                               // + 4096 kb + 2048 (second 16 keys) + 16384 chunk
         f32x4 o[4];
         float m_run = 0.f, l_run = 0.f;
-        unsigned rowh = 0u;
-        if constexpr (DROP) rowh = drop_row(dc, (unsigned)pr * PT + q0 + c16);
+        // (DROP: the mask words of this pair were issued at the end of the previous pair, in front of the 6 loads above)
+        if constexpr (DROP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         auto chunk = [&](auto CH) {
             constexpr int ch = decltype(CH)::value;
             // ---- S^T = K . Q^T : rows = keys, cols = queries
@@ -160,15 +178,35 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
             const float mb = m_new * scale_log2e;
             float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt)
+            for (int kt = 0; kt < 8; ++kt) {
+                u32x4 mwa = u32x4{0u, 0u, 0u, 0u}, mwb = mwa;
+                if constexpr (DROP) {  // the four words (r = 0..3) of key block (ch, kt): a wave-uniform address, broadcast
+                    mwa = *reinterpret_cast<const u32x4*>(scr + (ch * 32 + kt * 4) * 8);
+                    mwb = *reinterpret_cast<const u32x4*>(scr + (ch * 32 + kt * 4) * 8 + 16);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float pv = __builtin_amdgcn_exp2f(__fmaf_rn(s[kt][r], scale_log2e, -mb));
                     if (r & 1) ps1 += pv; else ps0 += pv;  // the normaliser uses the undropped probabilities
-                    if constexpr (DROP) pv = drop_keep_rc(dc, rowh, ch * 128 + 16 * kt + 4 * g + r) ? pv * dc.scale : 0.0f;
+                    if constexpr (DROP) {
+                        const unsigned lo = r < 2 ? mwa[2 * r] : mwb[2 * r - 4], hi = r < 2 ? mwa[2 * r + 1] : mwb[2 * r - 3];
+                        const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hi) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readfirstlane(lo);
+                        pv = __builtin_amdgcn_inverse_ballot_w64(w) ? pv : 0.0f;  // 1 / (1 - p) multiplies the output row (epilogue)
+                    }
                     s[kt][r] = pv;
                 }
+                // one key block at a time: left alone, the probabilities sink towards their use in the PV section and every block's
+                // words (64 scalar registers) stay live until then.  The empty statement consumes the four results here.
+                if constexpr (DROP) {
+                    asm volatile("" : "+v"(s[kt][0]), "+v"(s[kt][1]), "+v"(s[kt][2]), "+v"(s[kt][3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             l_run += ps0 + ps1;
+            // the mask words are ordinary LDS loads; the transposed reads below are inline asm behind hand-counted lgkmcnt waits: keep
+            // the compiler from moving a load of the next chunk's words in between them
+            if constexpr (DROP) __builtin_amdgcn_sched_barrier(0);
             // ---- O^T += V^T . P^T over 32-key blocks.  The transposed reads go out as inline asm: behind the builtin hipcc waits
             //      vmcnt(0) -- for the NEXT pair's LDS-DMA, which it cannot tell apart from this buffer -- and the pipeline is gone.
             s16x4 va[2][4], vb[2][4];
@@ -206,6 +244,7 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
             reads(std::integral_constant<int, 3>{}, 1);
             pv_block(2, 0, true);
             pv_block(3, 1, false);
+            if constexpr (DROP) __builtin_amdgcn_sched_barrier(0);
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
             l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
             t = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
             l = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-            const float inv = 1.0f / l;
+            const float inv = DROP ? dc.scale / l : 1.0f / l;
             if constexpr (LSE) {  // log-sum-exp of the scaled scores (natural log), saved for the backward pass
                 if (g == 0) lse[(size_t)pr * PT + q0 + c16] = (m_run * scale_log2e + __log2f(l)) * 0.6931471805599453f;
             }
@@ -240,21 +279,45 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         if (!has_next) break;
         pr = next;
         buf ^= 1;
-        // the next pair's K/V (4 LDS-DMA) and Q fragments (2 loads) are older than this pair's output stores: leave the stores in flight
-        if constexpr (LSE) asm volatile("s_waitcnt vmcnt(3) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
-        else asm volatile("s_waitcnt vmcnt(2) ; data of %0 %1" : "+v"(qn0), "+v"(qn1)::"memory");
+        issue_mask(pr);  // the scratch has been read back (the stores above hold its data): the next pair's mask words may land in it
+        // the next pair's K/V (4 LDS-DMA) and Q fragments (2 loads) are older than this pair's output stores: leave the stores (and
+        // the mask-word DMA just issued) in flight
+        constexpr int INFLIGHT = 2 + (LSE ? 1 : 0) + (DROP ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(%2) ; data of %0 %1" : "+v"(qn0), "+v"(qn1) : "n"(INFLIGHT) : "memory");
     }
 }
 
+// Dropout-mask words of one attention call (layout: header): one wave per (pair, 16-query block) = 64 words.  A lane's four
+// keys of a key block are an aligned quad of mask columns = one hash (drop_quad); the four comparisons' lane masks are the words.
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(DropCfg dc, int blocks16, unsigned long long* __restrict__ maskw) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // = pair * 16 + qb
+    if (wid >= blocks16) return;
+    const int g = lane >> 4, c16 = lane & 15;
+    const unsigned rowh = drop_row(dc, (unsigned)wid * 16u + (unsigned)c16);  // row = pair * 256 + 16 qb + c
+    const unsigned thr16 = dc.thr >> 16;
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+        const DropQuad dq = drop_quad(rowh, (unsigned)(4 * kt + g));  // columns 16 kt + 4 g + (0..3)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long w = __builtin_amdgcn_ballot_w64(drop_field(dq, (unsigned)r) >= thr16);
+            if (lane == 4 * kt + r) mine = w;
+        }
+    }
+    maskw[(size_t)wid * 64 + lane] = mine;
+}
+
 template <bool DROP, bool LSE>
-int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int ld_out, float* lse, DropCfg dc, hipStream_t s) {
+int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int ld_out, float* lse, DropCfg dc, const void* maskw, hipStream_t s) {
     auto kern = attention_fwd_p_kernel<DROP, LSE>;
     constexpr int lds = P_SCR + 16 * 2048;  // 160 KB
     set_max_lds(reinterpret_cast<const void*>(kern), lds);
     const int pairs = B * heads, ncu = compute_cus();
     const int grid = pairs < ncu ? pairs : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, qkv, ld_qkv, pairs, heads, out, ld_out,
-                       1.4426950408889634f / sqrtf((float)PDH), lse, dc);
+                       1.4426950408889634f / sqrtf((float)PDH), lse, dc, reinterpret_cast<const char*>(maskw));
     BSI_CHECK_LAUNCH("bsi_attention_fwd(persistent)");
     return BSI_OK;
 }
@@ -262,10 +325,21 @@ int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int l
 }  // namespace
 
 // tokens == 256, dh == 64 (checked by the caller in attention.hip)
+// maskw (dropout only): [B * heads][16][64] 64-bit words, FILLED HERE (attn_dropmask_kernel) and consumed by this launch and by
+// bsi_attention_bwd_drop.  Dropout without a word buffer is not this kernel's business (the caller takes the chunked kernel).
 int bsi_attention_fwd_persistent(const void* qkv, int ld_qkv, int B, int heads, void* out, int ld_out, float* lse, DropCfg dc,
-                                 hipStream_t s) {
+                                 void* maskw, hipStream_t s) {
     const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
     __bf16* o = reinterpret_cast<__bf16*>(out);
-    if (dc.thr) return lse ? launch_p<true, true>(q, ld_qkv, B, heads, o, ld_out, lse, dc, s) : launch_p<true, false>(q, ld_qkv, B, heads, o, ld_out, lse, dc, s);
-    return lse ? launch_p<false, true>(q, ld_qkv, B, heads, o, ld_out, lse, dc, s) : launch_p<false, false>(q, ld_qkv, B, heads, o, ld_out, lse, dc, s);
+    if (dc.thr) {
+        BSI_CHECK_ARG(maskw != nullptr, "bsi_attention_fwd(persistent): dropout needs the mask-word buffer");
+        BSI_CHECK_ARG((size_t)B * heads * 8192 < (1ull << 31), "bsi_attention_fwd(persistent): %d pairs exceed the 32-bit mask-word offsets", B * heads);
+        const int blocks16 = B * heads * 16;
+        hipLaunchKernelGGL(attn_dropmask_kernel, dim3((blocks16 + 3) / 4), dim3(256), 0, s, dc, blocks16, reinterpret_cast<unsigned long long*>(maskw));
+        BSI_CHECK_LAUNCH("bsi_attention_fwd(dropout mask words)");
+        return lse ? launch_p<true, true>(q, ld_qkv, B, heads, o, ld_out, lse, dc, maskw, s)
+                   : launch_p<true, false>(q, ld_qkv, B, heads, o, ld_out, lse, dc, maskw, s);
+    }
+    return lse ? launch_p<false, true>(q, ld_qkv, B, heads, o, ld_out, lse, dc, nullptr, s)
+               : launch_p<false, false>(q, ld_qkv, B, heads, o, ld_out, lse, dc, nullptr, s);
 }

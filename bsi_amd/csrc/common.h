@@ -217,14 +217,36 @@ __host__ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned lo
     return drop_keep_rc(c, bsi_mix32((unsigned)(idx >> 32) + c.s0) ^ c.s1, (unsigned)idx);
 }
 // Elements are addressed as (row, column) = the (high, low) words of the index: the inner hash depends on the row only, so
-// kernels hoist it per row (drop_row) and pay one 32-bit mix per element (drop_keep_rc) with no 64-bit arithmetic.
+// kernels hoist it per row (drop_row) and pay one cheap mix per aligned quad of columns (drop_keep_rc) with no 64-bit arithmetic.
 __host__ __device__ __forceinline__ unsigned drop_row(const DropCfg& c, unsigned row) { return bsi_mix32(row + c.s0) ^ c.s1; }
-// One 32-bit mix serves TWO neighbouring columns (its low / high 16 bits against the 16-bit threshold): the kernels visit columns
-// in aligned pairs, so the compiler shares the hash -- the two 32-bit multiplies of the mix (quarter rate on the vector ALU) were
-// most of what dropout cost the attention kernels (backward 949 -> 1330 us with dropout).  p is resolved to 2^-16.
+// One hash serves FOUR neighbouring columns (an aligned quad): 64 bits = four 16-bit fields, each compared with the 16-bit
+// threshold; the kernels visit columns in aligned quads (a lane's MFMA registers, a float4 of an elementwise pass), so the
+// compiler shares the hash.  The mixer uses 24-bit multiplies only (v_mad_u32_u24: full rate; the two 32-bit multiplies of
+// bsi_mix32 are quarter rate on the vector ALU and were most of what dropout cost the attention kernels, round 3: forward 240 ->
+// 373 us, backward 873 -> 1062 us): 16 full-rate instructions per quad.  Avalanche (tools/experiments/drop_hash_stats.py): every
+// input bit flips 15.9-16.2 of the 32 output bits of either word; fields uniform (chi-square within 222-252 for 255 dof),
+// neighbouring columns / rows uncorrelated (|r| < 1e-3).  p is resolved to 2^-16.
+struct DropQuad { unsigned h1, h2; };
+__host__ __device__ __forceinline__ unsigned bsi_mad24(unsigned a, unsigned b24, unsigned c) { return (a & 0xffffffu) * b24 + c; }
+__host__ __device__ __forceinline__ DropQuad drop_quad(unsigned rowh, unsigned quad) {
+    unsigned t = quad ^ rowh;
+    t ^= t >> 16;
+    t = bsi_mad24(t, 0x9E3779u, t >> 11);
+    t ^= t >> 13;
+    t = bsi_mad24(t, 0x85EBCBu, t >> 9);
+    DropQuad q;
+    q.h1 = t ^ (t >> 16);
+    unsigned u = q.h1 ^ (q.h1 >> 7);
+    u = bsi_mad24(u, 0xC2B2AFu, q.h1 >> 5);
+    q.h2 = u ^ (u >> 15);
+    return q;
+}
+__host__ __device__ __forceinline__ unsigned drop_field(const DropQuad& q, unsigned col) {  // the 16-bit field of column col (its low 2 bits)
+    const unsigned h = (col & 2u) ? q.h2 : q.h1;
+    return (col & 1u) ? (h >> 16) : (h & 0xffffu);
+}
 __host__ __device__ __forceinline__ bool drop_keep_rc(const DropCfg& c, unsigned rowh, unsigned col) {
-    const unsigned h = bsi_mix32((col >> 1) ^ rowh);
-    return ((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= (c.thr >> 16);
+    return drop_field(drop_quad(rowh, col >> 2), col) >= (c.thr >> 16);
 }
 inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
     DropCfg c{};

@@ -24,7 +24,11 @@ int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, i
 int bsi_ln_mod_bwd_drop(const void* dxn, const float* x, const float* scale, int mod_stride, float* dshift,
                         float* dscale, int dmod_stride, float* dX, int M, int d, int tokens, float eps, DropCfg dc,
                         bsi_stream_t stream);
+// maskw: optional [B * heads][8 KB] dropout-mask words (256 tokens, head dim 64, dropout on: bsi_attention_uses_mask_words) that
+// the forward writes and the backward reads instead of evaluating the hash again; NULL: both sides hash.
+bool bsi_attention_uses_mask_words(int tokens, int dh);
 int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
-                            float* lse, DropCfg dc, bsi_stream_t stream);
+                            float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr);
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
-                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream);
+                           int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
+                           const void* maskw = nullptr);

@@ -44,6 +44,7 @@ struct BlockTape {
     float* lse;
     float *xa, *xb;    // fp32 [M, dim]: inputs of LayerNorm 1 / 2 (xa of block 0 is written by the patch encoder)
     float *sa, *sb;    // fp32 [M, 2]: (mean, rstd) of those rows
+    char* maskw;       // [B * heads][8 KB]: dropout-mask words of the attention weights (persistent kernels, 256 tokens x head dim 64)
 };
 
 struct Tape {
@@ -70,7 +71,7 @@ inline Tape carve_tape(const Dims& d, int B, void* base) {
     t.ada_s = p + off; off += au((size_t)d.depth * B * dim * 2);
     t.blocks = p + off;
     t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4) +
-                    au(M * dim * 4) * 2 + au(M * 2 * 4) * 2;
+                    au(M * dim * 4) * 2 + au(M * 2 * 4) * 2 + au((size_t)B * d.heads * 8192);
     off += t.block_bytes * d.depth;
     t.total = off;
     return t;
@@ -93,7 +94,8 @@ inline BlockTape block_tape(const Tape& t, const Dims& d, int B, int l) {
     b.xa = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
     b.xb = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
     b.sa = reinterpret_cast<float*>(p + off); off += au(M * 2 * 4);
-    b.sb = reinterpret_cast<float*>(p + off);
+    b.sb = reinterpret_cast<float*>(p + off); off += au(M * 2 * 4);
+    b.maskw = p + off;
     return b;
 }
 
@@ -213,7 +215,7 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
                                        d.tokens, nullptr, nullptr, bt.xn1, DropCfg{}, stream, bt.xa, bt.sa));
         TRY(gemm(bt.xn1, dim, bw.qkv_w, dim, bw.qkv_b, bt.qkv, 3 * dim, M, 3 * dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_attention_fwd_train(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse,
-                                    make_drop(dropout_p, seed, 2 * l), stream));
+                                    make_drop(dropout_p, seed, 2 * l), stream, bt.maskw));
         TRY(gemm(bt.ao, dim, bw.out_w, dim, bw.out_b, bt.d1, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_resid_ln_modulate_drop(bt.xa, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride,
                                        d.tokens, nullptr, nullptr, bt.xn2, make_drop(dropout_p, seed, 2 * l + 1), stream, bt.xb,
@@ -295,7 +297,7 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
         TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
-                                   make_drop(dropout_p, seed, 2 * l), stream));
+                                   make_drop(dropout_p, seed, 2 * l), stream, bt.maskw));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
         TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
         // LayerNorm 1 backward (dX becomes dL/dxa) + the MLP branch of the block below: xa = xb' + g_m' * d2'

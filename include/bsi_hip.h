@@ -580,8 +580,10 @@ int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*
                      const bsi_dit_grads* g /*host*/, int B, const float* g_out, const float* c_out, void* tape,
                      void* workspace, float dropout_p, unsigned long long seed, bsi_stream_t stream);
 /* Dropout of the DiT blocks in training (dit.py:43-44 attention-weight dropout, dit.py:70,101 nn.Dropout before the
- * MLP) is a counter-based mask: element (row, col) of site s is kept iff hash(seed, s, row, col) >= p*2^32, re-evaluated
- * in the backward kernels (nothing stored).  Sites: 2*block (attention weights: row = (b*heads+h)*T + query, col = key) and
+ * MLP) is a counter-based mask: element (row, col) of site s is kept iff a 16-bit field of hash(seed, s, row, col / 4) is
+ * >= p*2^16 (one hash per aligned quad of columns), re-evaluated in the backward kernels; only the attention weights of the
+ * DiT geometry proper (256 tokens, head dim 64) keep their mask on the tape, as 64-bit lane-mask words (8 KB per (image, head)
+ * and block) that the forward and backward attention kernels use as select masks.  Sites: 2*block (attention weights: row = (b*heads+h)*T + query, col = key) and
  * 2*block+1 (MLP input: row = token, col = feature); UNet: site = residual block, row = pixel, col = channel.
  * bsi_dropout_mask exposes the mask of a [rows, cols] site (uint8 keep flags) for tests. */
 int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned rows, unsigned cols, uint8_t* out /*[rows*cols]*/,

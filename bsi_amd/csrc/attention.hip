@@ -301,7 +301,7 @@ int launch_attn(const __bf16* qkv, int ld_qkv, int B, int tokens, int heads, __b
 }  // namespace
 
 int bsi_attention_fwd_persistent(const void* qkv, int ld_qkv, int B, int heads, void* out, int ld_out, float* lse, DropCfg dc,
-                                 void* maskw, hipStream_t s);
+                                 void* maskw, bool mask_ready, hipStream_t s);
 
 // 256 tokens x head dim 64 with dropout on: the persistent kernels exchange the dropout mask as 64-bit words (8 KB per
 // (batch, head) pair, attention_persist.hip) -- the forward writes them when `maskw` is given, the backward reads them
@@ -312,7 +312,7 @@ bool bsi_attention_uses_mask_words(int tokens, int dh) {
 }
 
 static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
-                              float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr) {
+                              float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr, bool mask_ready = false) {
     BSI_CHECK_ARG(qkv && out && B > 0 && heads > 0, "bsi_attention_fwd: bad args");
     BSI_CHECK_ARG(dh == 64 || dh == 128, "bsi_attention_fwd: head dim %d unsupported (64 or 128)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0, "bsi_attention_fwd: tokens=%d must be a multiple of 64", tokens);
@@ -329,7 +329,7 @@ static int attention_fwd_impl(const void* qkv, int ld_qkv, int B, int tokens, in
         // the DiT geometry proper (256 tokens): persistent kernel, next pair's traffic under this pair's arithmetic
         // (with dropout it needs the mask-word buffer of the training engine; without one the chunked kernel evaluates the hash itself)
         if (tokens == 256 && !no_persist && !chunked && (size_t)tokens * ld_qkv * 2 < (1ull << 32) && (!dc.thr || maskw))
-            return bsi_attention_fwd_persistent(qkv, ld_qkv, B, heads, out, ld_out, lse, dc, maskw, s);
+            return bsi_attention_fwd_persistent(qkv, ld_qkv, B, heads, out, ld_out, lse, dc, maskw, mask_ready, s);
         if (tokens <= 256 && !chunked) return launch_attn<64, 64, true>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
         return launch_attn<64, 64>(q, ld_qkv, B, tokens, heads, o, ld_out, lse, dc, s);
     }
@@ -349,7 +349,7 @@ extern "C" int bsi_attention_fwd_lse(const void* qkv, int ld_qkv, int B, int tok
 }
 
 int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
-                            float* lse, DropCfg dc, bsi_stream_t stream, void* maskw) {
+                            float* lse, DropCfg dc, bsi_stream_t stream, void* maskw, bool mask_ready) {
     return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, dc, stream,
-                              bsi_attention_uses_mask_words(tokens, dh) ? maskw : nullptr);
+                              bsi_attention_uses_mask_words(tokens, dh) ? maskw : nullptr, mask_ready);
 }

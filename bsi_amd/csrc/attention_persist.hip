@@ -141,7 +141,10 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
         f32x4 o[4];
         float m_run = 0.f, l_run = 0.f;
         // (DROP: the mask words of this pair were issued at the end of the previous pair, in front of the 6 loads above)
-        if constexpr (DROP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (DROP) {
+            if (has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // last pair: nothing younger was issued behind the words
+        }
         auto chunk = [&](auto CH) {
             constexpr int ch = decltype(CH)::value;
             // ---- S^T = K . Q^T : rows = keys, cols = queries
@@ -154,7 +157,14 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s[kt], 0, 0, 0);
             }
             // ---- softmax of the query column this lane holds (32 of the chunk's 128 keys per lane)
-            // v_max3_f32 by hand: fmaxf() on MFMA outputs makes hipcc canonicalise every operand first (one extra v_max per value)
+            // v_max3_f32 by hand: fmaxf() on MFMA outputs makes hipcc canonicalise every operand first (one extra v_max per value).
+            // hipcc pads nothing for an asm statement: the wait states between an MFMA and a vector instruction that reads its result
+            // (8-pass MFMA: 11) are ours to insert.  Left to the scheduler the (non-volatile) v_max3 statements sat 3-5 instructions
+            // behind the MFMAs that feed them in the training instance -- a stale maximum, exp2 overflow, NaN on real activations
+            // while random inputs passed.  All MFMAs of the chunk first, 16 wait states, then the chain.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             float mx = max3(s[0][0], s[0][1], s[0][2]);
             mx = max3(mx, s[0][3], s[1][0]);
 #pragma unroll
@@ -287,26 +297,12 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
     }
 }
 
-// Dropout-mask words of one attention call (layout: header): one wave per (pair, 16-query block) = 64 words.  A lane's four
-// keys of a key block are an aligned quad of mask columns = one hash (drop_quad); the four comparisons' lane masks are the words.
+// Dropout-mask words of one attention call (layout: header; generator: drop_mask_block, common.h): one wave per block of 64 words.
 __global__ __launch_bounds__(256) void attn_dropmask_kernel(DropCfg dc, int blocks16, unsigned long long* __restrict__ maskw) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // = pair * 16 + qb
     if (wid >= blocks16) return;
-    const int g = lane >> 4, c16 = lane & 15;
-    const unsigned rowh = drop_row(dc, (unsigned)wid * 16u + (unsigned)c16);  // row = pair * 256 + 16 qb + c
-    const unsigned thr16 = dc.thr >> 16;
-    unsigned long long mine = 0ull;
-#pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
-        const DropQuad dq = drop_quad(rowh, (unsigned)(4 * kt + g));  // columns 16 kt + 4 g + (0..3)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long w = __builtin_amdgcn_ballot_w64(drop_field(dq, (unsigned)r) >= thr16);
-            if (lane == 4 * kt + r) mine = w;
-        }
-    }
-    maskw[(size_t)wid * 64 + lane] = mine;
+    maskw[(size_t)wid * 64 + lane] = drop_mask_block(dc, (unsigned)wid, lane);
 }
 
 template <bool DROP, bool LSE>
@@ -325,18 +321,20 @@ int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int l
 }  // namespace
 
 // tokens == 256, dh == 64 (checked by the caller in attention.hip)
-// maskw (dropout only): [B * heads][16][64] 64-bit words, FILLED HERE (attn_dropmask_kernel) and consumed by this launch and by
+// maskw (dropout only): [B * heads][16][64] 64-bit words, FILLED HERE (attn_dropmask_kernel) unless mask_ready, consumed by this launch and by
 // bsi_attention_bwd_drop.  Dropout without a word buffer is not this kernel's business (the caller takes the chunked kernel).
 int bsi_attention_fwd_persistent(const void* qkv, int ld_qkv, int B, int heads, void* out, int ld_out, float* lse, DropCfg dc,
-                                 void* maskw, hipStream_t s) {
+                                 void* maskw, bool mask_ready, hipStream_t s) {
     const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
     __bf16* o = reinterpret_cast<__bf16*>(out);
     if (dc.thr) {
         BSI_CHECK_ARG(maskw != nullptr, "bsi_attention_fwd(persistent): dropout needs the mask-word buffer");
         BSI_CHECK_ARG((size_t)B * heads * 8192 < (1ull << 31), "bsi_attention_fwd(persistent): %d pairs exceed the 32-bit mask-word offsets", B * heads);
-        const int blocks16 = B * heads * 16;
-        hipLaunchKernelGGL(attn_dropmask_kernel, dim3((blocks16 + 3) / 4), dim3(256), 0, s, dc, blocks16, reinterpret_cast<unsigned long long*>(maskw));
-        BSI_CHECK_LAUNCH("bsi_attention_fwd(dropout mask words)");
+        if (!mask_ready) {
+            const int blocks16 = B * heads * 16;
+            hipLaunchKernelGGL(attn_dropmask_kernel, dim3((blocks16 + 3) / 4), dim3(256), 0, s, dc, blocks16, reinterpret_cast<unsigned long long*>(maskw));
+            BSI_CHECK_LAUNCH("bsi_attention_fwd(dropout mask words)");
+        }
         return lse ? launch_p<true, true>(q, ld_qkv, B, heads, o, ld_out, lse, dc, maskw, s)
                    : launch_p<true, false>(q, ld_qkv, B, heads, o, ld_out, lse, dc, maskw, s);
     }

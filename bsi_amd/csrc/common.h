@@ -223,22 +223,20 @@ __host__ __device__ __forceinline__ unsigned drop_row(const DropCfg& c, unsigned
 // threshold; the kernels visit columns in aligned quads (a lane's MFMA registers, a float4 of an elementwise pass), so the
 // compiler shares the hash.  The mixer uses 24-bit multiplies only (v_mad_u32_u24: full rate; the two 32-bit multiplies of
 // bsi_mix32 are quarter rate on the vector ALU and were most of what dropout cost the attention kernels, round 3: forward 240 ->
-// 373 us, backward 873 -> 1062 us): 16 full-rate instructions per quad.  Avalanche (tools/experiments/drop_hash_stats.py): every
-// input bit flips 15.9-16.2 of the 32 output bits of either word; fields uniform (chi-square within 222-252 for 255 dof),
-// neighbouring columns / rows uncorrelated (|r| < 1e-3).  p is resolved to 2^-16.
+// 373 us, backward 873 -> 1062 us): 13 full-rate instructions per quad.  Statistics (tools/experiments/drop_hash_stats.py):
+// every input bit flips 16.0-17.3 of the 32 output bits of either word; fields uniform (chi-square 242-298 for 255 dof);
+// neighbouring columns / rows uncorrelated (|r| < 1e-3); row and column drop counts dispersed as the binomial.  p is resolved to 2^-16.
 struct DropQuad { unsigned h1, h2; };
 __host__ __device__ __forceinline__ unsigned bsi_mad24(unsigned a, unsigned b24, unsigned c) { return (a & 0xffffffu) * b24 + c; }
 __host__ __device__ __forceinline__ DropQuad drop_quad(unsigned rowh, unsigned quad) {
-    unsigned t = quad ^ rowh;
-    t ^= t >> 16;
-    t = bsi_mad24(t, 0x9E3779u, t >> 11);
-    t ^= t >> 13;
-    t = bsi_mad24(t, 0x85EBCBu, t >> 9);
+    const unsigned x = quad ^ rowh;
+    unsigned t = bsi_mad24(x, 0x9E3779u, x >> 12);
+    t ^= t >> 15;
+    t = bsi_mad24(t, 0x85EBCBu, t >> 10);
     DropQuad q;
-    q.h1 = t ^ (t >> 16);
-    unsigned u = q.h1 ^ (q.h1 >> 7);
-    u = bsi_mad24(u, 0xC2B2AFu, q.h1 >> 5);
-    q.h2 = u ^ (u >> 15);
+    q.h1 = t ^ (t >> 14);
+    const unsigned u = bsi_mad24(q.h1, 0xC2B2AFu, q.h1 >> 6);
+    q.h2 = u ^ (u >> 13);
     return q;
 }
 __host__ __device__ __forceinline__ unsigned drop_field(const DropQuad& q, unsigned col) {  // the 16-bit field of column col (its low 2 bits)
@@ -248,6 +246,40 @@ __host__ __device__ __forceinline__ unsigned drop_field(const DropQuad& q, unsig
 __host__ __device__ __forceinline__ bool drop_keep_rc(const DropCfg& c, unsigned rowh, unsigned col) {
     return drop_field(drop_quad(rowh, col >> 2), col) >= (c.thr >> 16);
 }
+#ifdef __HIPCC__
+// Dropout-mask WORDS of the attention weights (256 tokens, head dim 64; consumers: attention_persist.hip, attention_bwd.hip).
+// Block `wid` = pair * 16 + qb covers queries 16 qb .. 16 qb + 15 of (batch, head) pair `pair` against all 256 keys = 64 words:
+// word 4 kt + r, bit 16 g + c = keep(row = pair * 256 + 16 qb + c, column = 16 kt + 4 g + r) -- the lane <-> (query, key) map of
+// the S^T = K.Q^T accumulators.  One wave computes a block: a lane's four keys of a key block are an aligned quad of mask columns
+// = one hash, the four comparisons' lane masks are the words; lane 4 kt + r returns word (kt, r).
+__device__ __forceinline__ unsigned long long drop_mask_block(const DropCfg& dc, unsigned wid, int lane) {
+    const int g = lane >> 4, c16 = lane & 15;
+    const unsigned rowh = drop_row(dc, wid * 16u + (unsigned)c16);
+    const unsigned thr16 = dc.thr >> 16;
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+        const DropQuad dq = drop_quad(rowh, (unsigned)(4 * kt + g));
+        unsigned long long w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = __builtin_amdgcn_ballot_w64(drop_field(dq, (unsigned)r) >= thr16);
+        // v_writelane: the four scalar words into lanes 4 kt .. 4 kt + 3 (2 instructions per word; a compare + two selects otherwise).
+        // ONE statement per key block, opened by wait states: a v_writelane that reads a scalar register right behind the v_cmp
+        // that wrote it got the OLD value (5 % of the mask bits wrong with one statement per word) -- hipcc pads nothing inside asm.
+        asm("s_nop 4\n\t"
+            "v_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\t"
+            "v_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+            "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\t"
+            "v_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+            : "+v"(lo), "+v"(hi)
+            : "s"((unsigned)w[0]), "s"((unsigned)(w[0] >> 32)), "s"((unsigned)w[1]), "s"((unsigned)(w[1] >> 32)), "s"((unsigned)w[2]),
+              "s"((unsigned)(w[2] >> 32)), "s"((unsigned)w[3]), "s"((unsigned)(w[3] >> 32)), "n"(4 * kt), "n"(4 * kt + 1), "n"(4 * kt + 2),
+              "n"(4 * kt + 3));
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+
 inline DropCfg make_drop(float p, unsigned long long seed, unsigned site) {
     DropCfg c{};
     if (p <= 0.f) return c;

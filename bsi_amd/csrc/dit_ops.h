@@ -14,7 +14,7 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
                                const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
                                const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream,
                                float* x_out = nullptr, float* stats = nullptr, const void* delta0 = nullptr,
-                               const float* gate0 = nullptr, int write_x = 1);
+                               const float* gate0 = nullptr, int write_x = 1, DropCfg mask_dc = DropCfg{}, void* maskw = nullptr);
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
                          float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream, size_t part_stride = 0);
@@ -27,8 +27,9 @@ int bsi_ln_mod_bwd_drop(const void* dxn, const float* x, const float* scale, int
 // maskw: optional [B * heads][8 KB] dropout-mask words (256 tokens, head dim 64, dropout on: bsi_attention_uses_mask_words) that
 // the forward writes and the backward reads instead of evaluating the hash again; NULL: both sides hash.
 bool bsi_attention_uses_mask_words(int tokens, int dh);
+// mask_ready: the words were already written (by the LayerNorm pass in front of the qkv projection, bsi_resid_ln_modulate_drop)
 int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out,
-                            float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr);
+                            float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr, bool mask_ready = false);
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
                            int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
                            const void* maskw = nullptr);

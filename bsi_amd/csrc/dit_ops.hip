@@ -56,16 +56,23 @@ __global__ void nyquist_kernel(const float* __restrict__ t, int rows, const floa
 // read-modify-write inside the GEMM epilogue.  `delta` may alias `out` (a wave reads its row before writing it).
 // Lazy form (inference engine): with write_x = 0 the updated row is normalised but NOT stored; the next pass names that update
 // as (delta0, gate0) in front of its own and stores the row once for both -- 302 MB less traffic per DiT block at 512 images.
-template <int VPL>  // float4 vectors per lane: covers d <= VPL*256
+// MASKGEN (training, the pass in front of the qkv projection): the wave of row m also computes block m of the attention layer's
+// dropout-mask words (drop_mask_block: 64 words = a 16-query block of one (image, head) pair against its 256 keys; with 256
+// tokens and 16 heads... in general M = B * tokens blocks of 16 queries x heads / 16: the launcher checks M == B * heads * 16).
+// The pass is HBM bound with the vector ALU mostly idle, so the ~470 instructions per row ride along: the separate
+// attn_dropmask_kernel took 115 us per layer at 512 images.
+template <int VPL, bool MASKGEN = false>  // float4 vectors per lane: covers d <= VPL*256
 __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
                                    const float* __restrict__ scale, int mod_rows, int mod_stride, int tokens,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                    const __bf16* delta, const float* __restrict__ gate, __bf16* out, DropCfg dc,
                                    float* x_out, float* __restrict__ stats, const __bf16* delta0 = nullptr,
-                                   const float* __restrict__ gate0 = nullptr, int write_x = 1) {
+                                   const float* __restrict__ gate0 = nullptr, int write_x = 1, DropCfg mdc = DropCfg{},
+                                   unsigned long long* __restrict__ maskw = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
+    if constexpr (MASKGEN) maskw[(size_t)row * 64 + lane] = drop_mask_block(mdc, (unsigned)row, lane);
     const float* xr = x + (size_t)row * d;
     float* xw = (x_out ? x_out : x) + (size_t)row * d;  // training tape: the updated row goes to its own slot
     const int d4 = d >> 2;
@@ -405,7 +412,8 @@ extern "C" int bsi_nyquist_embed(const float* t, int rows, const float* scale, c
 int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* delta, const float* gate,
                                const float* shift, const float* scale, int mod_rows, int mod_stride, int tokens,
                                const float* ln_w, const float* ln_b, void* out_bf16, DropCfg dc, bsi_stream_t stream,
-                               float* x_out, float* stats, const void* delta0, const float* gate0, int write_x) {
+                               float* x_out, float* stats, const void* delta0, const float* gate0, int write_x, DropCfg mdc,
+                               void* maskw) {
     BSI_CHECK_ARG(x && M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bsi_resid_ln_modulate: bad args M=%d d=%d", M, d);
     BSI_CHECK_ARG(out_bf16 || delta, "bsi_resid_ln_modulate: nothing to do");
     BSI_CHECK_ARG((shift == nullptr) == (scale == nullptr), "bsi_resid_ln_modulate: shift and scale go together");
@@ -415,6 +423,7 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
     BSI_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "bsi_resid_ln_modulate: ln weight and bias go together");
     BSI_CHECK_ARG((delta0 == nullptr) == (gate0 == nullptr) && (!delta0 || delta), "bsi_resid_ln_modulate: an older update needs its gate and a newer update");
     BSI_CHECK_ARG(write_x || (delta && out_bf16 && !x_out), "bsi_resid_ln_modulate: write_x = 0 needs an update and an output");
+    BSI_CHECK_ARG(!(maskw && mdc.thr) || (d > 256 && d <= 1024 && out_bf16), "bsi_resid_ln_modulate: mask words ride on the d <= 1024 instance");
     const __bf16* dl0 = reinterpret_cast<const __bf16*>(delta0);
     const int wpb = TPB / 64;
     dim3 grid((M + wpb - 1) / wpb);
@@ -423,6 +432,10 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
                            mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);
+    else if (d <= 1024 && maskw && mdc.thr)  // row m -> mask block m (the caller guarantees M blocks: M = B * heads * 16)
+        hipLaunchKernelGGL((ln_modulate_kernel<4, true>), grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
+                           mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x, mdc,
+                           reinterpret_cast<unsigned long long*>(maskw));
     else if (d <= 1024)
         hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
                            mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);

@@ -211,11 +211,16 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         BlockTape bt = block_tape(tp, d, B, l);
         const float* ml = tp.mod + (size_t)l * 6 * dim;
         // xa = x_prev + gate * d2 of the block below (block 0: the encoder wrote xa), xn1 = LN(xa) * (1 + scale) + shift
+        // (with dropout on the DiT geometry, this HBM-bound pass also computes the attention layer's dropout-mask words: row m ->
+        //  block m, M = B * tokens = B * heads * 16 blocks when tokens == 16 * heads)
+        const DropCfg adc = make_drop(dropout_p, seed, 2 * l);
+        const bool ride = adc.thr != 0 && bsi_attention_uses_mask_words(d.tokens, 64) && d.tokens == 16 * d.heads && dim > 256 && dim <= 1024;
         TRY(bsi_resid_ln_modulate_drop(l == 0 ? bt.xa : x_prev, M, dim, 1e-5f, pend_delta, pend_gate, ml, ml + dim, B, mod_stride,
-                                       d.tokens, nullptr, nullptr, bt.xn1, DropCfg{}, stream, bt.xa, bt.sa));
+                                       d.tokens, nullptr, nullptr, bt.xn1, DropCfg{}, stream, bt.xa, bt.sa, nullptr, nullptr, 1,
+                                       ride ? adc : DropCfg{}, ride ? bt.maskw : nullptr));
         TRY(gemm(bt.xn1, dim, bw.qkv_w, dim, bw.qkv_b, bt.qkv, 3 * dim, M, 3 * dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_attention_fwd_train(bt.qkv, 3 * dim, B, d.tokens, d.heads, 64, bt.ao, dim, bt.lse,
-                                    make_drop(dropout_p, seed, 2 * l), stream, bt.maskw));
+                                    adc, stream, bt.maskw, ride));
         TRY(gemm(bt.ao, dim, bw.out_w, dim, bw.out_b, bt.d1, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
         TRY(bsi_resid_ln_modulate_drop(bt.xa, M, dim, 1e-5f, bt.d1, ml + 2 * dim, ml + 3 * dim, ml + 4 * dim, B, mod_stride,
                                        d.tokens, nullptr, nullptr, bt.xn2, make_drop(dropout_p, seed, 2 * l + 1), stream, bt.xb,

@@ -382,21 +382,34 @@ def test_dp_trainer_single_gpu_step():
     assert tr.step_count == 2
 
 
-@pytest.mark.parametrize("side", [16, 32])
+@pytest.mark.parametrize("side", [16, 32, 1032])
 def test_training_dropout_matches_oracle_with_same_masks(side):
     """Dropout sites of the training engine (attention weights, MLP input): the counter-based masks are exported with
     bsi_dropout_mask and applied in the CPU oracle; loss and gradients must agree as in the dropout-free case.  side = 32 gives 256
-    tokens: the persistent attention kernels (forward with dropout + log-sum-exp, backward with dropout) of the DiT-L geometry."""
+    tokens: the persistent attention kernels of the DiT-L geometry, whose dropout mask travels as 64-bit lane-mask words
+    (attn_dropmask_kernel).  Case 1032 = side 32 at DiT-L's width (dim 1024, 16 heads, one block, seeded weights): there the
+    words are computed by the LayerNorm pass in front of the qkv projection (tokens == 16 heads: row m -> mask block m)."""
     from bsi_amd import _native as N
     from bsi_amd.models.dit import DenoisingDiT
     from bsi_amd.nn import FourierFeatures
     p, B, d, heads, depth = 0.3, 4, 128, 2, 2
+    wide = side == 1032
+    if wide:
+        side, B, d, heads, depth = 32, 2, 1024, 16, 1
     T = (side // 2) ** 2
     shape = (3, side, side)
     g = golden("g4_train_dit")
-    W = weights("dit_ff")
     model = DenoisingDiT(shape, 2, d, depth, heads, dropout=p, fourier_features=FourierFeatures(n_min=6, n_max=8))
-    model.load_state_dict(W)
+    if wide:
+        torch.manual_seed(5)
+        with torch.no_grad():
+            for q_ in model.parameters():
+                q_.copy_(torch.randn(q_.shape) * (0.02 if q_.ndim > 1 else 0.01))
+            model.dit.patch_decoder[0].weight.fill_(1.0)
+        W = {k: v.clone() for k, v in model.state_dict().items()}
+    else:
+        W = weights("dit_ff")
+        model.load_state_dict(W)
     model = model.to(DEV).train()
     bsi = make_bsi(model, shape)
     gen = torch.Generator().manual_seed(77)

@@ -8,16 +8,14 @@ def mix_old(x):
     x = x.astype(np.uint64)
     x ^= x>>np.uint64(16); x = (x*np.uint64(0x7feb352d))&np.uint64(M32); x ^= x>>np.uint64(15); x=(x*np.uint64(0x846ca68b))&np.uint64(M32); x^= x>>np.uint64(16)
     return x
-def quad(x):
+def quad(x):  # drop_quad of bsi_amd/csrc/common.h
     x = x.astype(np.uint64)
-    t = x ^ (x>>np.uint64(16))
-    t = mad24(t, 0x9E3779, t>>np.uint64(11))
-    t = t ^ (t>>np.uint64(13))
-    t = mad24(t, 0x85EBCB, t>>np.uint64(9))
-    h1 = t ^ (t>>np.uint64(16))
-    u = h1 ^ (h1>>np.uint64(7))
-    u = mad24(u, 0xC2B2AF, h1>>np.uint64(5))
-    h2 = u ^ (u>>np.uint64(15))
+    t = mad24(x, 0x9E3779, x>>np.uint64(12))
+    t = t ^ (t>>np.uint64(15))
+    t = mad24(t, 0x85EBCB, t>>np.uint64(10))
+    h1 = t ^ (t>>np.uint64(14))
+    u = mad24(h1, 0xC2B2AF, h1>>np.uint64(6))
+    h2 = u ^ (u>>np.uint64(13))
     return h1&np.uint64(M32), h2&np.uint64(M32)
 rng=np.random.default_rng(0)
 # rows: rowh = mix_old(row + s0) ^ s1 ; cols 0..255 ; 4096 rows

@@ -38,6 +38,15 @@ void bsi_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// Laboratory ablations (kernel parts switched off: results are WRONG) exist only in a laboratory build of the library
+// (make -C bsi_amd/csrc LAB=1 OUTDIR=...): in the product build BSI_ABL() is the constant 0, the branches vanish from the hot loops
+// and the setters refuse those bits.  Kernel-CHOICE bits (which of two correct kernels runs) are ordinary run-time flags.
+#ifdef BSI_LAB
+#define BSI_ABL(flags, bits) ((flags) & (bits))
+#else
+#define BSI_ABL(flags, bits) 0
+#endif
+
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, device): remember the pairs already set (round 1 kept one
 // flag per process, which left the kernels of a second device without the attribute).  A lost race only repeats the call.
 inline void set_max_lds(const void* kern, int bytes) {

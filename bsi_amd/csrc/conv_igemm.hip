@@ -273,17 +273,17 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     int itile = tile, ik = 0, itap = 0, icb = 0, islot = 0;  // next stage: K step, its tap / channel byte offset, ring slot
     auto issue_next = [&]() -> bool {
         if (itile >= hi) return false;
-        if (p.abl & 1) { if (++ik == nk) { ik = 0; itile += wpx; } return true; }
+        if (BSI_ABL(p.abl, 1)) { if (++ik == nk) { ik = 0; itile += wpx; } return true; }
         char* base = lds + islot * C_SLOT;
         const bool src2 = itap >= p.taps;
         int dy = 0, dx = 0;
         if (!src2 && p.taps == 9) { dy = itap / 3 - 1; dx = itap - (itap / 3) * 3 - 1; }
         const int rowb = src2 ? p.Cin2 * 2 : p.Cin * 2;
         const long delta = (long)(dy * p.Wd + dx) * rowb + icb;
-        const unsigned tmask = ((p.abl & 8) ? 15u : (unsigned)tap_mask(dy, dx)) | 16u;
+        const unsigned tmask = ((BSI_ABL(p.abl, 8)) ? 15u : (unsigned)tap_mask(dy, dx)) | 16u;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((src2 ? A2b : Ab) + delta), 0, BUF_RECORDS, 0x00020000);
-        if (!(p.abl & 64)) {
+        if (!(BSI_ABL(p.abl, 64))) {
             const unsigned vo0 = (unsigned)mrow * (unsigned)rowb + achunk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + (q * NW + wave) * 1024), 16, vo, q * NW * 16 * rowb, 0, 0);
             }
         }
-        if (!(p.abl & 32))
+        if (!(BSI_ABL(p.abl, 32)))
             __builtin_amdgcn_global_load_lds(GLB_PTR(Wb + (size_t)ik * 64 + woffs), LDS_PTR(base + (32 + wave) * 1024), 16, 0, 0);
         icb += 64;
         if (!src2 && icb == p.Cin * 2) { icb = 0; ++itap; }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     auto epilogue = [&](int t) {
         asm volatile("" : "+s"(t));  // keeps the tile-dependent row addresses out of the K loop (see the slab kernel)
         const int mw0 = (t / p.tiles_n) * C_BM + (wm * 2 + wmm) * 128, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
-        if (nb0 >= p.N || (p.abl & 4)) return;  // wave-uniform: the lane-group exchanges below need every lane
+        if (nb0 >= p.N || (BSI_ABL(p.abl, 4))) return;  // wave-uniform: the lane-group exchanges below need every lane
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
             if constexpr (EPI == CEPI_FILM_SILU_BF16) film_silu_inplace(p, acc, mw0, nb, HW);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         const bool has_next = next < hi;
         init_acc(tile);
         for (int v = 0; v < nk; ++v) {
-            if (!(p.abl & 16)) {
+            if (!(BSI_ABL(p.abl, 16))) {
                 const char* b = lds + slot * C_SLOT;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(b + woff + i * 4 * C_RB);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PHASE_BARRIER();
             __builtin_amdgcn_s_setprio(1);
-            if (!(p.abl & 2)) {
+            if (!(BSI_ABL(p.abl, 2))) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         }
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
         // the store allowance is valid only if every store instruction of the epilogue was issued (no row / column tail)
-        after_e = ((tile / p.tiles_n) * C_BM + C_BM <= p.M && (tile % p.tiles_n) * C_BN + C_BN <= p.N && !(p.abl & 4)) ? C_D - 1 : 0;
+        after_e = ((tile / p.tiles_n) * C_BM + C_BM <= p.M && (tile % p.tiles_n) * C_BN + C_BN <= p.N && !(BSI_ABL(p.abl, 4))) ? C_D - 1 : 0;
         if (!has_next) break;
         tile = next;
     }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
         // without the fence they are computed in front of it and live -- spilled -- through it
         asm volatile("" : "+s"(t));
         const int mw0 = (t / p.tiles_n) * C_BM + wrow0, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
-        if (nb0 >= p.N || (p.abl & 4)) return;
+        if (nb0 >= p.N || (BSI_ABL(p.abl, 4))) return;
         if constexpr (BF16_OUT) {
             if (nb >= p.N) return;
             // FiLM + SiLU per (image, channel); the wave's 128 rows lie in ONE image (launcher: H*W % 128 == 0)
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 
     // the vmcnt allowance may count an epilogue's stores only when every one of them is issued (no row / column tail)
     auto full_tile = [&](int t) {
-        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N && !(p.abl & 4);
+        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N && !(BSI_ABL(p.abl, 4));
     };
     // prologue: slab 0 and weight stages 0 .. S_WD-1; slab 0 and stage 0 must have landed before the first load phase
 #pragma unroll
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                 constexpr int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
                 constexpr unsigned ZL = dx < 0 ? XL : dx > 0 ? XR : 0u;  // fragments whose lane 0 (dx < 0) / lane 15 (dx > 0) falls outside
                 // ---- L phase: fragments of (chunk c, tap t)
-                if (!(p.abl & 16) || (c == 0 && t == 0)) {
+                if (!(BSI_ABL(p.abl, 16)) || (c == 0 && t == 0)) {
                     const char* wb = lds + (P & (S_WSLOTS - 1)) * S_WSTAGE;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + woff + i * 4 * C_RB);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                     }
                 }
                 // ---- issue: next slab piece (taps 0..4), weight stage P + S_WD
-                if (!(p.abl & 1)) {
+                if (!(BSI_ABL(p.abl, 1))) {
                     if constexpr (t < 5) {
                         issue_slab_piece(t);
                         if constexpr (t == 4) advance_slab();
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
                 PHASE_BARRIER();
                 // ---- C phase
                 __builtin_amdgcn_s_setprio(1);
-                if (!(p.abl & 2)) {  // (bsi_conv_set_ablation: kernel experiments)
+                if (!(BSI_ABL(p.abl, 2))) {  // (bsi_conv_set_ablation: kernel experiments)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -819,7 +819,11 @@ int launch_conv(ConvParams p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int bsi_conv_set_ablation(int flags) {  // kernel experiments only (tools/conv_bench.py); results are wrong with flags != 0
+extern "C" int bsi_conv_set_ablation(int flags) {  // bits 256 / 512 / 2048 / 4096: kernel choice; bits 1..64: laboratory build only
+#ifndef BSI_LAB
+    BSI_CHECK_ARG(!(flags & 127), "bsi_conv_set_ablation: bits 1..64 switch kernel parts off (wrong results) and exist only in a laboratory "
+                                  "build (make -C bsi_amd/csrc LAB=1 OUTDIR=<dir>, BSI_HIP_LIB=<dir>/libbsi_hip.so); got %d", flags);
+#endif
     g_conv_abl = flags;
     return BSI_OK;
 }

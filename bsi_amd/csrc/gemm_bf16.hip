@@ -45,32 +45,22 @@ struct GemmParams {
     void* out2;       // BIAS_GELU_DUAL: pre-activation output (bf16, layout of out)
     int tiles_m, tiles_n;
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
-    int ng;       // n-tiles per group of the tile order (0: all), see tile_coords
     // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
     // split s multiplies the K range [s*kslice, (s+1)*kslice) and writes its partial sums to out + s*slab_stride floats
     int splits, kslice;
     size_t slab_stride;
 };
 
-// tile index -> (tm, tn).  The n-tiles are cut into groups of p.ng (0 = one group of all tiles_n); inside a group the tiles are
-// walked in bands of gm m-tiles, m fastest inside a band.  An XCD runs 32 consecutive tiles together: with one group (ng = 0)
-// they form a gm x (32/gm) block that moves along n and then down the bands; with ng = 32/gm they form one band, the XCD keeps
-// its ng weight panels from round to round (n-stationary) and only the activation panels stream.
+// tile index -> (tm, tn): the tiles are walked in bands of gm m-tiles, m fastest inside a band.  An XCD runs 32 consecutive tiles
+// together: a gm x (32/gm) block that moves along n and then down the bands.  (An n-stationary order that keeps an XCD's weight
+// panels from round to round was measured in round 3: +-1 %, tools/experiments/gemm_variants.inc keeps it.)
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm, int& tn) {
-    int ncols = p.tiles_n, n_first = 0;
-    if (p.ng > 0 && p.ng < p.tiles_n) {
-        const int group_tiles = p.tiles_m * p.ng;
-        const int gidx = t / group_tiles;  // the last group may be narrower
-        n_first = gidx * p.ng;
-        t -= gidx * group_tiles;
-        ncols = min(p.ng, p.tiles_n - n_first);
-    }
-    const int band_tiles = p.gm * ncols;
+    const int band_tiles = p.gm * p.tiles_n;
     const int band = t / band_tiles;
     const int r = t - band * band_tiles;
     const int rows = min(p.gm, p.tiles_m - band * p.gm);  // last band may be short
     tm = band * p.gm + r % rows;
-    tn = n_first + r / rows;
+    tn = r / rows;
 }
 
 template <int EPI>

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
 
     int slot = 0, pslot = T_D;
     for (int v = 0; v < nk; ++v) {
-        if (!(p.abl & 4) || v == 0) load_frags(lds + slot * T_SLOT);
-        if (v + T_D < nk && !(p.abl & 2)) {
+        if (!(BSI_ABL(p.abl, 4)) || v == 0) load_frags(lds + slot * T_SLOT);
+        if (v + T_D < nk && !(BSI_ABL(p.abl, 2))) {
             stage(v + T_D, pslot);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T_D - 1)) : "memory");
         } else {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnParams p) {
         }
         TN_BARRIER();
         __builtin_amdgcn_s_setprio(1);
-        if (!(p.abl & 8)) {
+        if (!(BSI_ABL(p.abl, 8))) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
 
     int slot = 0, pslot = T2_D;
     for (int v = 0; v < nk; ++v) {
-        if (!(p.abl & 4) || v == 0) {  // (BSI_TN_ABL: laboratory flags, as in gemm_tn_kernel)
+        if (!(BSI_ABL(p.abl, 4)) || v == 0) {  // (BSI_TN_ABL: laboratory flags, as in gemm_tn_kernel)
             const unsigned so = (unsigned)slot * T2_SLOT;
             const unsigned aq = aq0 + so, ap = ap0 + so;
             constexpr int HB = 8 * T2_PITCH;  // rows + 4 = 8 positions further
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
 #pragma unroll
             for (int qq = 0; qq < NL; ++qq) stage_one(v + T2_D, pslot, qq);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + (NL < 4 ? NL : 0)) : "memory");
-        } else if (v + T2_D < nk && !(p.abl & 2)) {
+        } else if (v + T2_D < nk && !(BSI_ABL(p.abl, 2))) {
             stage(v + T2_D, pslot);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (T2_D - 1)) : "memory");
         } else {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
         // the MFMA phase as in the forward GEMM: +1.5-2.5 % (tools/tn_bench.py, profiles/r3/tn_ab.txt)
         __builtin_amdgcn_s_setprio(0);
         TN_BARRIER();
-        if (!(p.abl & 8)) {
+        if (!(BSI_ABL(p.abl, 8))) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
 #pragma unroll

@@ -1,5 +1,6 @@
 """Implicit-GEMM convolution throughput at the VDM-UNet shapes (32x32 images, 128 output channels).
-usage: [B=128] [ABL=0,1,2,...] python tools/conv_bench.py   (ABL: ablation flags of bsi_conv_set_ablation, one column each)"""
+usage: [B=128] [ABL=0,1,2,...] python tools/conv_bench.py   (ABL: flags of bsi_conv_set_ablation, one column each; bits 1..64 switch kernel
+parts off and need a laboratory build: make -C bsi_amd/csrc LAB=1 OUTDIR=/tmp/lab && BSI_HIP_LIB=/tmp/lab/libbsi_hip.so ...)"""
 import ctypes as C
 import os
 import sys

@@ -10,6 +10,7 @@
 #include "../../bsi_amd/csrc/gemm_bf16.hip"
 #include "gemm_variants.inc"
 #include "../../bsi_amd/csrc/bsi_ops.hip"  // bsi_set_error
+int g_bsi_cu_reserve = 0;  // compute_cus() of common.h (defined in prof.hip in the library)
 
 template <int EPI, int ABL>
 float time_pp(LabParams p, int iters) {
@@ -268,6 +269,22 @@ int main() {
                     const double bytes = (double)((q.M + 255) / 256) * ((sh.N + 255) / 256) * (512.0 * sh.K * 2.0);
                     printf("%s %3d CUs: full %.1f us | DMA stream alone %.1f us = %.1f GB/s per CU | barriers alone %.1f us | MFMA + reads, no DMA, no epilogue %.1f us\n", sh.name, ncu,
                            1e3 * full, 1e3 * dma, bytes / (dma * 1e-3) / 1e9 / ncu, 1e3 * none, 1e3 * mf);
+                }
+            }
+            continue;
+        }
+        if (getenv("LAB_WDUP")) {
+            // round 4: what NOT sharing the W half-stage between the two wave groups costs the steady state (ABL 33554432: every W
+            // instruction issued twice, bit-identical results) -- the price of offsetting the groups by an epilogue
+            constexpr int G = BSI_EPI_BIAS_GELU_BF16;
+            for (int r = 0; r < 3; ++r) {
+                rep("production issue", time_k64r<E, 0>(p, 20));
+                rep("W half-stages issued twice", time_k64r<E, 33554432>(p, 20));
+                rep("no epilogue (upper bound of hiding it)", time_k64r<E, 4>(p, 20));
+                if (sh.N == 4096) {
+                    rep("gelu production issue", time_k64r<G, 0>(p, 20));
+                    rep("gelu W half-stages issued twice", time_k64r<G, 33554432>(p, 20));
+                    rep("gelu no epilogue", time_k64r<G, 4>(p, 20));
                 }
             }
             continue;

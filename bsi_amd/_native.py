@@ -156,6 +156,7 @@ _PROTOS = {
     "bsi_nyquist_embed": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
     "bsi_gemm_splitk_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "bsi_gemm_splitk_f32_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "bsi_gemm_bf16_ws": (_i, [C.POINTER(GemmArgs), _vp, C.c_size_t, _vp]),
     "bsi_gemm_set_variant": (_i, [_i]),
     "bsi_conv_set_grid_limit": (_i, [_i]),

@@ -54,6 +54,8 @@ struct Tape {
     char* emb;      // bf16 [B, dim]
     float* ada_pre; // fp32 [depth, B, dim]
     char* ada_s;    // bf16 [depth, B, dim]
+    char* skws;     // split-K slabs of the per-sample adaLN GEMMs (bsi_gemm_splitk_f32_workspace_bytes)
+    size_t skws_bytes;
     char* blocks;   // per block region
     size_t block_bytes, total;
 };
@@ -69,6 +71,11 @@ inline Tape carve_tape(const Dims& d, int B, void* base) {
     t.emb = p + off; off += au((size_t)B * dim * 2);
     t.ada_pre = reinterpret_cast<float*>(p + off); off += au((size_t)d.depth * B * dim * 4);
     t.ada_s = p + off; off += au((size_t)d.depth * B * dim * 2);
+    {
+        const size_t a0 = bsi_gemm_splitk_f32_workspace_bytes(B, (int)dim, (int)dim), a2 = bsi_gemm_splitk_f32_workspace_bytes(B, 6 * (int)dim, (int)dim);
+        t.skws_bytes = a0 > a2 ? a0 : a2;
+        t.skws = p + off; off += au(t.skws_bytes);
+    }
     t.blocks = p + off;
     t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4) +
                     au(M * dim * 4) * 2 + au(M * 2 * 4) * 2 + au((size_t)B * d.heads * 8192);
@@ -144,6 +151,15 @@ int gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void
     return bsi_gemm_bf16(&g, stream);
 }
 
+// per-sample GEMM (M = images) with an fp32 result: split over K through `ws` when the shape qualifies (gemm_bf16.hip, splitk_plan_f32)
+int gemm_rows(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo, int M, int N, int K, void* ws,
+              size_t ws_bytes, bsi_stream_t stream) {
+    bsi_gemm_args g{};
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+    g.epilogue = BSI_EPI_BIAS_F32;
+    return bsi_gemm_bf16_ws(&g, ws, ws_bytes, stream);
+}
+
 void* const* g_block_events = nullptr;
 int g_block_events_n = 0;
 
@@ -195,10 +211,9 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         const bsi_dit_block_weights& bw = w->blocks[l];
         float* pre = tp.ada_pre + (size_t)l * B * dim;
         char* sl = tp.ada_s + (size_t)l * B * dim * 2;
-        TRY(gemm(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
+        TRY(gemm_rows(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, tp.skws, tp.skws_bytes, stream));
         TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
-        TRY(gemm(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, BSI_EPI_BIAS_F32,
-                 nullptr, nullptr, nullptr, 0, stream));
+        TRY(gemm_rows(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, tp.skws, tp.skws_bytes, stream));
     }
     TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin, d.nfreq, d.kpad, tp.a0, s));
     TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, block_tape(tp, d, B, 0).xa, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32,
@@ -322,7 +337,8 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
             // bf16 dmod[:, l, :] = the slab planes of this block summed in fixed order
             TRY(bsi_sum_cast_rows_bf16(dml, nplanes, plane, dstride, B, 6 * dim, ws.dmod_bf, 6 * dim, stream));
             TRY(bsi_gemm_tn_bias_bf16(ws.dmod_bf, 6 * dim, sl, dim, B, 6 * dim, dim, bg.ada2_w, dim, bg.ada2_b, 0, ws.tn, stream));
-            TRY(gemm(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, BSI_EPI_BIAS_F32, nullptr, nullptr, nullptr, 0, stream));
+            TRY(gemm_rows(ws.dmod_bf, 6 * dim, bT.ada2_wT, 6 * dim, nullptr, ws.ds, dim, B, dim, 6 * dim, ws.tn,
+                          bsi_gemm_tn_workspace_bytes((int)M, 4 * dim, dim), stream));  // the weight-gradient slabs are free between its launches
             TRY(bsi_silu_bwd_bf16(ws.ds, pre, (size_t)B * dim, ws.dpre_bf, stream));
             TRY(bsi_gemm_tn_bias_bf16(ws.dpre_bf, dim, tp.emb, dim, B, dim, dim, bg.ada0_w, dim, bg.ada0_b, 0, ws.tn, stream));
         }

@@ -1046,6 +1046,35 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// fp32 counterpart (BSI_EPI_BIAS_F32): out[m][n] = bias[n] + sum over slabs, in slab order
+__global__ __launch_bounds__(256) void splitk_finish_f32_kernel(const float* __restrict__ slabs, size_t slab_stride, int splits,
+                                                                const float* __restrict__ bias, int M, int N, int ldo,
+                                                                float* __restrict__ out) {
+    const int n4 = N >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), c = (int)(i % n4) * 4;
+        f32x4 a = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < splits; ++sp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)sp * slab_stride + (size_t)m * N + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + c) = a;
+    }
+}
+
+// Per-sample GEMMs with an fp32 result (the adaLN MLP of a training step: M = images, N = 1024 or 6144, K = 1024 or 6144): 8-48
+// tiles, each walking its whole K loop alone -- 52-71 us of pure latency per launch, 72 launches per step (3.7 ms of a 50 ms step at
+// 64 images per GPU).  The slice count depends on K ONLY, so an output element is the same sum whatever M is (a batch and its shards
+// stay bit-identical).
+int splitk_plan_f32(int M, int N, int K) {
+    if (M > 2048 || K < 1024 || N % 4 != 0) return 1;
+    const int sp = K >= 4096 ? 8 : 4;
+    if (K % (sp * 128) != 0) return 1;
+    return sp;
+}
+
 // number of K slices for this problem (1 = do not split): only for few tiles, K long enough, slices of whole 128-column blocks
 int splitk_plan(int M, int N, int K, int cus) {
     // K >= 2048 only: measured (tools/experiments/splitk_time.py) fc2 (K = 4096) 72 -> 28..40 us, but the K = 1024 GEMMs get slower
@@ -1081,8 +1110,12 @@ int launch_splitk(const GemmParams& p0, int splits, void* workspace, hipStream_t
     const size_t total = (size_t)p.M * (p.N / 4);
     size_t g = (total + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel<EPI>, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), p.slab_stride,
-                       splits, p0.bias, p.M, p.N, p0.ldo, reinterpret_cast<__bf16*>(p0.out));
+    if constexpr (EPI == BSI_EPI_BIAS_F32)
+        hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), p.slab_stride,
+                           splits, p0.bias, p.M, p.N, p0.ldo, reinterpret_cast<float*>(p0.out));
+    else
+        hipLaunchKernelGGL(splitk_finish_kernel<EPI>, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), p.slab_stride,
+                           splits, p0.bias, p.M, p.N, p0.ldo, reinterpret_cast<__bf16*>(p0.out));
     BSI_CHECK_LAUNCH("bsi_gemm_bf16_ws(finish)");
     return BSI_OK;
 }
@@ -1148,10 +1181,31 @@ extern "C" size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K) {
     return sp > 1 ? (size_t)sp * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+extern "C" size_t bsi_gemm_splitk_f32_workspace_bytes(int M, int N, int K) {
+    const int sp = splitk_plan_f32(M, N, K);
+    return sp > 1 ? (size_t)sp * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 extern "C" int bsi_gemm_bf16_ws(const bsi_gemm_args* a, void* workspace, size_t workspace_bytes, bsi_stream_t stream) {
     // small-M latency path: split-K through the caller's workspace when the shape qualifies, the epilogue is a plain bf16 one
     // and the workspace is large enough; otherwise exactly bsi_gemm_bf16
     // the SAME argument contract as bsi_gemm_bf16 on both paths (round 1 skipped the N % 16 and K % 64 checks here)
+    if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0 && a->N % 16 == 0 &&
+        a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldo % 4 == 0 && a->ldo >= a->N &&
+        a->epilogue == BSI_EPI_BIAS_F32) {  // per-sample fp32 GEMMs (splitk_plan_f32)
+        const int sp = splitk_plan_f32(a->M, a->N, a->K);
+        if (sp > 1 && workspace_bytes >= (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float)) {
+            GemmParams p{};
+            p.A = reinterpret_cast<const __bf16*>(a->A);
+            p.W = reinterpret_cast<const __bf16*>(a->W);
+            p.bias = a->bias;
+            p.out = a->out;
+            p.M = a->M; p.N = a->N; p.K = a->K;
+            p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
+            p.tokens = 1;
+            return launch_splitk<BSI_EPI_BIAS_F32>(p, sp, workspace, reinterpret_cast<hipStream_t>(stream));
+        }
+    }
     if (a && workspace && a->A && a->W && a->out && a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0 && a->N % 16 == 0 &&
         a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && a->ldo >= a->N &&
         (a->epilogue == BSI_EPI_BIAS_BF16 || a->epilogue == BSI_EPI_BIAS_GELU_BF16 || a->epilogue == BSI_EPI_BIAS_SILU_BF16)) {

@@ -225,6 +225,9 @@ int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
  * tiles does not walk its whole K loop on a handful of CUs; otherwise (or with too small a workspace) it is bsi_gemm_bf16.
  * bsi_gemm_splitk_workspace_bytes returns the bytes that make the split possible for a shape (0 = never split). */
 size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K);
+/* The same for BSI_EPI_BIAS_F32 on per-sample GEMMs (M <= 2048 rows, K >= 1024: the adaLN MLP of a train step, dit.py:77-81): the
+ * slice count depends on K only, so a result does not depend on how many rows were computed with it. */
+size_t bsi_gemm_splitk_f32_workspace_bytes(int M, int N, int K);
 int bsi_gemm_bf16_ws(const bsi_gemm_args* a /*host*/, void* workspace, size_t workspace_bytes, bsi_stream_t stream);
 /* Weight-gradient GEMM (backward of nn.Linear w.r.t. its weight, autograd `grad_output.T @ input`):
  *   out[N,K] (+)= P[M,N]^T . Q[M,K],  P = dY and Q = X are bf16 row-major (token index m slow), fp32 result.

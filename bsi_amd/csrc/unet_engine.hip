@@ -39,8 +39,30 @@ struct UWs {
     float* h[3];  // fp32 [M, dim] rotating feature maps, each followed by its GroupNorm partials (map_bytes: conv epilogue -> bsi_groupnorm_apply_nhwc)
     float* skips; // fp32 [levels][M, dim], same
     size_t map_bytes, fmap_bytes;  // one feature map without / with its partials
+    // split GroupNorm of the up blocks (gn_split): per level the normalised and the raw bf16 cat(x, skip), [M, 2 dim] each -- the skip
+    // half (columns dim ..) is written on the way DOWN by the pass that reads the skip tensor anyway, the x half on the way up
+    char* upa;
+    char* upraw;
+    size_t up_bytes;
     size_t total;
 };
+
+// GroupNorm statistics from the producing convolution's epilogue (one streaming normalisation pass instead of the register-resident
+// reduce-then-normalise kernel); BSI_UNET_NO_GN_FUSE=1 keeps the separate kernel for comparison
+inline bool gn_fuse_on(const bsi_unet_config* c) {
+    static const bool no_gn_fuse = getenv("BSI_UNET_NO_GN_FUSE") != nullptr;
+    return !no_gn_fuse && c->dim == 128 && (c->H * c->W) % 128 == 0;
+}
+// The 256-channel GroupNorm of an up block as two 128-channel halves (unet_ops.h, bsi_groupnorm_apply_split; round-3 review item 4):
+// built, bit-identical results, and NOT the default -- BSI_UNET_GN_SPLIT=1 switches it on.  Measured (profiles/r4/unet_gn_split_ab.txt,
+// 256 images): the up block's pass 86.4 -> 55.4 us, the pass in front of a down block 39.6 -> 69.4 us, UNet sampling +0.6-1.0 %:
+// 18 % fewer bytes, but the halves are 256-B pieces at a 512-B pitch of the [M, 2 dim] operand of conv1 and stream at 4.8 TB/s where
+// whole rows run at 6.2.  Contiguous halves need a two-source operand in the slab convolution; and the level buffers cost 17 GB of
+// workspace at 512 images.
+inline bool gn_split_on(const bsi_unet_config* c) {
+    static const bool on = getenv("BSI_UNET_GN_SPLIT") != nullptr;
+    return on && gn_fuse_on(c) && c->levels > 0;
+}
 
 inline UWs carve(const bsi_unet_config* c, int B, void* base) {
     const UDims d = udims(c, B);
@@ -59,6 +81,9 @@ inline UWs carve(const bsi_unet_config* c, int B, void* base) {
     w.fmap_bytes = w.map_bytes + au((M + 127) / 128 * (dim / 4) * 2 * 4);  // + (mean, M2) per 128 pixels x 4 channels
     for (int i = 0; i < 3; ++i) { w.h[i] = reinterpret_cast<float*>(p + off); off += w.fmap_bytes; }
     w.skips = reinterpret_cast<float*>(p + off); off += w.fmap_bytes * c->levels;
+    w.up_bytes = gn_split_on(c) ? au(M * 2 * dim * 2) : 0;
+    w.upa = p + off; off += w.up_bytes * c->levels;
+    w.upraw = p + off; off += w.up_bytes * c->levels;
     w.total = off;
     return w;
 }
@@ -147,10 +172,7 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
     float* h = ws.h[0];
     int cur = 0;
     auto skip_buf = [&](int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws.skips) + (size_t)i * ws.fmap_bytes); };
-    // GroupNorm statistics from the producing convolution's epilogue (one streaming normalisation pass instead of the
-    // register-resident reduce-then-normalise kernel); BSI_UNET_NO_GN_FUSE=1 keeps the separate kernel for comparison
-    static const bool no_gn_fuse = getenv("BSI_UNET_NO_GN_FUSE") != nullptr;
-    const bool gn_fuse = !no_gn_fuse && dim == 128 && d.HW % 128 == 0;
+    const bool gn_fuse = gn_fuse_on(cfg), gn_split = gn_split_on(cfg);
     auto part_of = [&](const float* map) -> float* {
         return gn_fuse ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(map)) + ws.map_bytes) : nullptr;
     };
@@ -161,34 +183,56 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
         return bsi_groupnorm_nhwc(x1, dim, x2, cin2, B, d.HW, gw, gb, 1e-5f, silu, ws.a, raw, stream);
     };
     // residual block (residual_block.py:61-64): out = skip(x) + conv2(silu(film(conv1(silu(gn(x))))))
-    auto resblock = [&](int blk, const float* x1, const float* x2, float* dst) -> int {
+    // skip_level >= 0 (gn_split): x1 IS skip tensor `skip_level`; its pass also writes the skip half of that level's up block.
+    // up_level >= 0: an up block, x2 = skip tensor `up_level`.
+    auto resblock = [&](int blk, const float* x1, const float* x2, float* dst, int skip_level, int up_level) -> int {
         const bsi_unet_resblock_weights& rb = w->blocks[blk];
         const int cin2 = x2 ? dim : 0;
-        TRY(groupnorm(x1, x2, cin2, rb.gn_w, rb.gn_b, 1, x2 ? ws.raw : nullptr));
+        const void* a_in = ws.a;      // conv1 operand
+        const void* raw_in = ws.raw;  // folded 1x1 skip operand of conv2
+        if (gn_split) {
+            if (up_level >= 0) {  // the x half of cat(x, skip): groups of 8 channels, columns 0 .. dim of the level's buffers
+                char* ua = ws.upa + (size_t)up_level * ws.up_bytes;
+                char* ur = ws.upraw + (size_t)up_level * ws.up_bytes;
+                TRY(bsi_groupnorm_apply_split(x1, part_of(x1), B, d.HW, 1e-5f, GnTarget{ua, ur, rb.gn_w, rb.gn_b, 2 * dim, 0, 8, 1}, GnTarget{}, stream));
+                a_in = ua;
+                raw_in = ur;
+            } else {
+                GnTarget second{};
+                if (skip_level >= 0) {  // skip tensor j is popped by up iteration L - 1 - j = block L + 2 + (L - 1 - j)
+                    const bsi_unet_resblock_weights& ub = w->blocks[L + 2 + (L - 1 - skip_level)];
+                    second = GnTarget{ws.upa + (size_t)skip_level * ws.up_bytes, ws.upraw + (size_t)skip_level * ws.up_bytes, ub.gn_w + dim, ub.gn_b + dim,
+                                      2 * dim, dim, 8, 1};
+                }
+                TRY(bsi_groupnorm_apply_split(x1, part_of(x1), B, d.HW, 1e-5f, GnTarget{ws.a, nullptr, rb.gn_w, rb.gn_b, dim, 0, 4, 1}, second, stream));
+            }
+        } else {
+            TRY(groupnorm(x1, x2, cin2, rb.gn_w, rb.gn_b, 1, x2 ? ws.raw : nullptr));
+        }
         // conv1 with the FiLM + SiLU epilogue of the slab kernel (one image per wave: the (scale, shift) coefficients are loaded once
         // per tile); BSI_UNET_SPLIT_FILM=1 keeps conv1 -> bf16 + a separate FiLM/SiLU pass for comparison
         static const bool split_film = getenv("BSI_UNET_SPLIT_FILM") != nullptr;
         if (split_film || d.HW % 128 != 0) {
-            TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.h1, nullptr, 0, 0, nullptr, B, H, W, dim + cin2, 0, dim, 9,
+            TRY(conv(a_in, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.h1, nullptr, 0, 0, nullptr, B, H, W, dim + cin2, 0, dim, 9,
                      BSI_CONV_BIAS_BF16, stream));
             TRY(bsi_film_silu_drop(ws.h1, (int)d.M, dim, d.HW, film + (size_t)blk * 2 * dim, film_rows, fstride, DropCfg{}, ws.y, stream));
         } else {
-            TRY(conv(ws.a, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.y, film + (size_t)blk * 2 * dim, film_rows, fstride, nullptr, B, H, W,
+            TRY(conv(a_in, nullptr, rb.conv1_w, rb.conv1_b, ws.zeros, ws.y, film + (size_t)blk * 2 * dim, film_rows, fstride, nullptr, B, H, W,
                      dim + cin2, 0, dim, 9, BSI_CONV_FILM_SILU_BF16, stream));
         }
         // conv2 (+ the 1x1 skip conv of cat(x, x_skip) folded in as extra K steps; its bias is folded into conv2_b)
-        return conv(ws.y, x2 ? ws.raw : nullptr, rb.conv2_w, rb.conv2_b, ws.zeros, dst, nullptr, 0, 0, x2 ? nullptr : x1, B, H, W, dim,
+        return conv(ws.y, x2 ? raw_in : nullptr, rb.conv2_w, rb.conv2_b, ws.zeros, dst, nullptr, 0, 0, x2 ? nullptr : x1, B, H, W, dim,
                     x2 ? 2 * dim : 0, dim, 9, BSI_CONV_BIAS_RESID_F32, stream, part_of(dst));
     };
     TRY(conv(ws.xin, nullptr, w->enc_w, w->enc_b, ws.zeros, h, nullptr, 0, 0, nullptr, B, H, W, d.cin_pad, 0, dim, 9,
              BSI_CONV_BIAS_RESID_F32, stream, part_of(h)));
     for (int i = 0; i < L; ++i) {  // down path: every block's output is also a skip tensor (simplified_unet.py:36-39)
         float* dst = skip_buf(i);
-        TRY(resblock(i, h, nullptr, dst));
+        TRY(resblock(i, h, nullptr, dst, i - 1, -1));  // block i > 0 reads skip tensor i - 1
         h = dst;
     }
     // centre: ResBlock, Residual(GroupNorm -> Attention2D), ResBlock (vdm_unet.py:80-89)
-    TRY(resblock(L, h, nullptr, ws.h[cur]));
+    TRY(resblock(L, h, nullptr, ws.h[cur], L - 1, -1));  // reads the last skip tensor
     h = ws.h[cur];
     TRY(groupnorm(h, nullptr, 0, w->agn_w, w->agn_b, 0, nullptr));
     TRY(conv(ws.a, nullptr, w->aqkv_w, w->aqkv_b, ws.zeros, ws.qkv, nullptr, 0, 0, nullptr, B, H, W, dim, 0, 3 * dim, 9,
@@ -203,14 +247,14 @@ extern "C" int bsi_unet_forward(const bsi_unet_config* cfg, const bsi_unet_weigh
     }
     {
         float* dst = ws.h[2];
-        TRY(resblock(L + 1, h, nullptr, dst));
+        TRY(resblock(L + 1, h, nullptr, dst, -1, -1));
         h = dst;
     }
     // up path: block(cat(x, skips.pop()))  (simplified_unet.py:43-46)
     int pp = 0;
     for (int i = 0; i < L; ++i) {
         float* dst = ws.h[pp];
-        TRY(resblock(L + 2 + i, h, skip_buf(L - 1 - i), dst));
+        TRY(resblock(L + 2 + i, h, skip_buf(L - 1 - i), dst, -1, L - 1 - i));
         h = dst;
         pp ^= 1;
     }

@@ -19,3 +19,19 @@ int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, i
 int bsi_conv_wgrad_conv2d_nhwc_bf16(const void* dy, int ldy, const void* x, const void* x2, const void* zeros, int B, int H, int W,
                                     int Cin, int cin_logical, int Cin2, int Cout, int taps, float* w, float* w2, float* dbias,
                                     void* workspace, bsi_stream_t stream);
+
+// GroupNorm of ONE 128-channel fp32 map into up to two bf16 targets (inference engine, round 4).  GroupNorm(32) over the 256
+// channels of cat(x, skip) (residual_block.py:39-64 on simplified_unet.py:43-46) is two independent halves of 16 groups of 8
+// channels: the skip half is normalised (with the UP block's affine, channels 128..255) by the pass that reads the skip tensor
+// anyway -- the GroupNorm in front of the next DOWN block -- so the up block's pass reads only its own input.  A target is the
+// column range [col0, col0 + 128) of a bf16 [M, ld] matrix; cpg = channels per group (4: GroupNorm(32) of 128 channels, 8: a half
+// of the 256-channel one); raw (optional) receives the un-normalised bf16 copy (operand of the folded 1x1 skip convolution).
+struct GnTarget {
+    void* out;
+    void* raw;
+    const float* gamma;  // [128], already offset to this half's channels
+    const float* beta;
+    int ld, col0, cpg, silu;
+};
+int bsi_groupnorm_apply_split(const float* x, const float* part, int B, int HW, float eps, GnTarget first, GnTarget second /* out == NULL: none */,
+                              bsi_stream_t stream);

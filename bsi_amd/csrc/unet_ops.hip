@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "unet_ops.h"
 #include "dit_ops.h"
 
 namespace {
@@ -419,6 +420,98 @@ extern "C" int bsi_groupnorm_apply_nhwc(const float* x1, int C1, const float* pa
     else
         hipLaunchKernelGGL(groupnorm_apply_kernel<256>, grid, dim3(GA_TPB), 0, S(stream), x1, C1, part1, x2, part2, HW, gamma, beta, eps, silu, o, r, stats);
     BSI_CHECK_LAUNCH("bsi_groupnorm_apply_nhwc");
+    return BSI_OK;
+}
+
+// See unet_ops.h (bsi_groupnorm_apply_split).  Same streaming structure as groupnorm_apply_kernel<128>: workgroup = 128 pixels of one
+// image, a thread owns one 4-channel quad; the statistics of BOTH groupings (4- and 8-channel groups) come from the same partials.
+struct GnTargetDev { __bf16* out; __bf16* raw; const float* gamma; const float* beta; int ld, col0, silu; };
+template <int CPG1, int CPG2>  // channels per group of the two targets (CPG2 = 0: one target)
+__global__ __launch_bounds__(GA_TPB) void groupnorm_apply_split_kernel(const float* __restrict__ x, const float* __restrict__ part, int HW, float eps,
+                                                                       GnTargetDev t1, GnTargetDev t2) {
+    constexpr int C = 128, Q = C / 4, PPI = GA_TPB / Q;  // 32 quads per pixel, 8 pixels per trip
+    __shared__ float mean1[32], rstd1[32], mean2[32], rstd2[32];
+    const int b = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
+    const int nblk = HW / 128;
+    auto merge = [&](int g, int cpg, float* mean_s, float* rstd_s) {  // group g = channels [g cpg, (g + 1) cpg): cpg / 4 units, fixed order
+        const float* pp = part + ((size_t)b * nblk * (C / 4) + (size_t)g * (cpg / 4)) * 2;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int k = 0; k < nblk; ++k)
+            for (int u = 0; u < cpg / 4; ++u) {
+                const f32x2 pm = *reinterpret_cast<const f32x2*>(pp + ((size_t)k * (C / 4) + u) * 2);
+                const float nb = 512.f, nn = n + nb, delta = pm[0] - mean;
+                mean += delta * (nb / nn);
+                m2 += pm[1] + delta * delta * (n * nb / nn);
+                n = nn;
+            }
+        mean_s[g] = mean;
+        rstd_s[g] = 1.0f / sqrtf(m2 / n + eps);
+    };
+    if (t < C / CPG1) merge(t, CPG1, mean1, rstd1);
+    if constexpr (CPG2 > 0) {
+        if (t >= 64 && t < 64 + C / CPG2) merge(t - 64, CPG2, mean2, rstd2);
+    }
+    __syncthreads();
+    const int q = t % Q, prow = t / Q, c0 = q * 4;
+    const size_t pix0 = (size_t)b * HW + (size_t)chunk * GA_PIX;
+    const float* src = x + pix0 * C + c0;
+    const float m1 = mean1[c0 / CPG1], r1 = rstd1[c0 / CPG1];
+    const f32x4 ga1 = *reinterpret_cast<const f32x4*>(t1.gamma + c0), be1 = *reinterpret_cast<const f32x4*>(t1.beta + c0);
+    float m2v = 0.f, r2 = 0.f;
+    f32x4 ga2 = f32x4{0.f, 0.f, 0.f, 0.f}, be2 = ga2;
+    if constexpr (CPG2 > 0) {
+        m2v = mean2[c0 / CPG2]; r2 = rstd2[c0 / CPG2];
+        ga2 = *reinterpret_cast<const f32x4*>(t2.gamma + c0); be2 = *reinterpret_cast<const f32x4*>(t2.beta + c0);
+    }
+    auto emit = [&](const GnTargetDev& tg, const f32x4& v, float mean, float rstd, const f32x4& ga, const f32x4& be, size_t pix) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = __fmaf_rn((v[e] - mean) * rstd, ga[e], be[e]);
+            if (tg.silu) y[e] = y[e] / (1.0f + __expf(-y[e]));
+        }
+        const size_t o = pix * tg.ld + tg.col0 + c0;
+        u32x2 w;
+        w[0] = pack_bf16x2(y[0], y[1]);
+        w[1] = pack_bf16x2(y[2], y[3]);
+        *reinterpret_cast<u32x2*>(tg.out + o) = w;
+        if (tg.raw) {
+            u32x2 r;
+            r[0] = pack_bf16x2(v[0], v[1]);
+            r[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(tg.raw + o) = r;
+        }
+    };
+    constexpr int TRIPS = GA_PIX / PPI, U = 8;
+#pragma unroll 1
+    for (int k0 = 0; k0 < TRIPS; k0 += U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(prow + (k0 + u) * PPI) * C));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t pix = pix0 + prow + (k0 + u) * PPI;
+            emit(t1, v[u], m1, r1, ga1, be1, pix);
+            if constexpr (CPG2 > 0) emit(t2, v[u], m2v, r2, ga2, be2, pix);
+        }
+    }
+}
+
+int bsi_groupnorm_apply_split(const float* x, const float* part, int B, int HW, float eps, GnTarget first, GnTarget second, bsi_stream_t stream) {
+    BSI_CHECK_ARG(x && part && first.out && first.gamma && first.beta && B > 0 && HW > 0 && HW % 128 == 0, "bsi_groupnorm_apply_split: bad args");
+    BSI_CHECK_ARG((first.cpg == 4 || first.cpg == 8) && (!second.out || second.cpg == 8) && first.ld % 4 == 0 && first.col0 % 4 == 0 &&
+                      (!second.out || (second.gamma && second.beta && second.ld % 4 == 0 && second.col0 % 4 == 0)),
+                  "bsi_groupnorm_apply_split: unsupported grouping / layout");
+    auto dev = [](const GnTarget& g) {
+        return GnTargetDev{reinterpret_cast<__bf16*>(g.out), reinterpret_cast<__bf16*>(g.raw), g.gamma, g.beta, g.ld, g.col0, g.silu};
+    };
+    const dim3 grid(B, HW / GA_PIX);
+    const GnTargetDev a = dev(first), b = dev(second);
+    if (second.out && first.cpg == 4) hipLaunchKernelGGL((groupnorm_apply_split_kernel<4, 8>), grid, dim3(GA_TPB), 0, S(stream), x, part, HW, eps, a, b);
+    else if (second.out) hipLaunchKernelGGL((groupnorm_apply_split_kernel<8, 8>), grid, dim3(GA_TPB), 0, S(stream), x, part, HW, eps, a, b);
+    else if (first.cpg == 4) hipLaunchKernelGGL((groupnorm_apply_split_kernel<4, 0>), grid, dim3(GA_TPB), 0, S(stream), x, part, HW, eps, a, b);
+    else hipLaunchKernelGGL((groupnorm_apply_split_kernel<8, 0>), grid, dim3(GA_TPB), 0, S(stream), x, part, HW, eps, a, b);
+    BSI_CHECK_LAUNCH("bsi_groupnorm_apply_split");
     return BSI_OK;
 }
 

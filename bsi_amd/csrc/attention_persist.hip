@@ -321,6 +321,18 @@ int launch_p(const __bf16* qkv, int ld_qkv, int B, int heads, __bf16* out, int l
 }  // namespace
 
 // tokens == 256, dh == 64 (checked by the caller in attention.hip)
+// The attention layer's dropout mask in the form the persistent kernels consume (test hook and stand-alone use): `pairs` (batch, head)
+// pairs of 256 x 256 weights -> [pairs][16][64] 64-bit words (layout: header); bit-for-bit the mask bsi_dropout_mask exports for the
+// same (p, seed, site) with rows = pairs * 256, cols = 256.
+extern "C" int bsi_attention_dropout_words(float p, unsigned long long seed, unsigned site, int pairs, void* words, bsi_stream_t stream) {
+    BSI_CHECK_ARG(words && pairs > 0 && p > 0.f && p < 1.f, "bsi_attention_dropout_words: bad args");
+    const int blocks16 = pairs * 16;
+    hipLaunchKernelGGL(attn_dropmask_kernel, dim3((blocks16 + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), make_drop(p, seed, site),
+                       blocks16, reinterpret_cast<unsigned long long*>(words));
+    BSI_CHECK_LAUNCH("bsi_attention_dropout_words");
+    return BSI_OK;
+}
+
 // maskw (dropout only): [B * heads][16][64] 64-bit words, FILLED HERE (attn_dropmask_kernel) unless mask_ready, consumed by this launch and by
 // bsi_attention_bwd_drop.  Dropout without a word buffer is not this kernel's business (the caller takes the chunked kernel).
 int bsi_attention_fwd_persistent(const void* qkv, int ld_qkv, int B, int heads, void* out, int ld_out, float* lse, DropCfg dc,

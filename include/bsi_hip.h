@@ -591,6 +591,9 @@ int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*
  * bsi_dropout_mask exposes the mask of a [rows, cols] site (uint8 keep flags) for tests. */
 int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned rows, unsigned cols, uint8_t* out /*[rows*cols]*/,
                      bsi_stream_t stream);
+/* The same mask of an attention site (rows = pairs * 256, cols = 256) as the lane-mask words the 256-token attention kernels consume:
+ * words[pair][qb 0..15][kt 0..15][r 0..3] (64 bit each), bit 16 g + c = keep(query 16 qb + c, key 16 kt + 4 g + r); 8 KB per pair. */
+int bsi_attention_dropout_words(float p, unsigned long long seed, unsigned site, int pairs, void* words, bsi_stream_t stream);
 /* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
  * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that
  * block's gradient all-reduce on another stream while the backward continues.  Pass NULL to clear. */

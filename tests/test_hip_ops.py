@@ -411,6 +411,103 @@ def test_gemm_split_k_small_m(N, M, Nn, K):
         assert float(((outs[0] - outs[2]).abs() / (outs[2].abs() + 0.05)).max()) < 1.6e-2  # split vs ordinary: a bf16 ulp
 
 
+@pytest.mark.parametrize("Nn,K", [(1024, 1024), (6144, 1024), (1024, 6144)])
+def test_gemm_split_k_fp32_per_sample_rows(N, Nn, K):
+    """The per-sample GEMMs of the train step (adaLN MLP, dit.py:77-81: M = images) with the fp32 epilogue through bsi_gemm_bf16_ws:
+    against fp64, and -- the slice count depends on K only -- the rows of a batch equal the rows of its first half BIT FOR BIT
+    (a batch and its shards must see the same conditioning table)."""
+    gen = torch.Generator().manual_seed(Nn + K)
+    M = 96
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn(Nn, generator=gen)
+    ref = A.double() @ W.double().t() + bias.double()
+    dA, dW, db = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias)
+    lib = N.lib()
+    need = lib.bsi_gemm_splitk_f32_workspace_bytes(M, Nn, K)
+    assert need > 0, "these shapes are meant to split"
+    ws = empty(need, dtype=torch.uint8)
+    outs = {}
+    for rows in (M, M // 2):
+        out = torch.full((rows, Nn), float("nan"), dtype=torch.float32, device=DEV)
+        a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), M=rows, N=Nn, K=K, lda=K, ldw=K, ldo=Nn,
+                       epilogue=N.EPI_BIAS_F32)
+        N.check(lib.bsi_gemm_bf16_ws(C.byref(a), N.ptr(ws), need, N.stream()))
+        outs[rows] = out.cpu()
+    assert rel_linf(outs[M], ref) < 2e-5                      # fp32 accumulation of bf16 products
+    assert torch.equal(outs[M][: M // 2], outs[M // 2])       # independent of how many rows were computed with it
+    plain = torch.empty((M, Nn), dtype=torch.float32, device=DEV)
+    a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=plain.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K, ldo=Nn,
+                   epilogue=N.EPI_BIAS_F32)
+    N.check(lib.bsi_gemm_bf16(C.byref(a), N.stream()))
+    assert rel_linf(outs[M], plain.cpu()) < 2e-5              # the unsplit kernel: same value up to the summation order
+
+
+def test_cu_reserve_changes_grids_not_results(N):
+    """bsi_set_cu_reserve (the data-parallel step's CU budget): the persistent kernels launch on fewer CUs and produce the same bits --
+    the forward GEMM (K = 64 ring), the weight-gradient GEMM (split count follows the budget), attention forward and backward."""
+    lib = N.lib()
+    full = lib.bsi_compute_cus()
+    assert lib.bsi_set_cu_reserve(12) != 0 and b"multiple of 8" in lib.bsi_last_error()   # one share per XCD
+    assert lib.bsi_set_cu_reserve(72) != 0
+    gen = torch.Generator().manual_seed(3)
+    M, Nn, K = 2048, 1024, 1024
+    A = dev(torch.randn((M, K), generator=gen).to(torch.bfloat16))
+    W = dev((torch.randn((Nn, K), generator=gen) / 32).to(torch.bfloat16))
+    bias = dev(torch.randn(Nn, generator=gen))
+    T, H, dh, B = 256, 4, 64, 70
+    qkv = dev(torch.randn((B, T, 3 * H * dh), generator=gen).to(torch.bfloat16))
+    dout = dev(torch.randn((B, T, H * dh), generator=gen).to(torch.bfloat16))
+
+    def run():
+        out = torch.empty((M, Nn), dtype=torch.bfloat16, device=DEV)
+        a = N.GemmArgs(A=A.data_ptr(), W=W.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K, ldo=Nn,
+                       epilogue=N.EPI_BIAS_GELU_BF16)
+        N.check(lib.bsi_gemm_bf16(C.byref(a), N.stream()))
+        dw = torch.empty((Nn, K), dtype=torch.float32, device=DEV)
+        ws = empty(lib.bsi_gemm_tn_workspace_bytes(M, Nn, K), dtype=torch.uint8)
+        N.check(lib.bsi_gemm_tn_bf16(N.ptr(out), Nn, N.ptr(A), K, M, Nn, K, N.ptr(dw), K, 0, N.ptr(ws), N.stream()))
+        ao = torch.empty((B, T, H * dh), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty((B, H, T), device=DEV)
+        N.check(lib.bsi_attention_fwd_lse(N.ptr(qkv), 3 * H * dh, B, T, H, dh, N.ptr(ao), H * dh, N.ptr(lse), N.stream()))
+        dq = torch.empty_like(qkv)
+        N.check(lib.bsi_attention_bwd(N.ptr(qkv), 3 * H * dh, N.ptr(ao), N.ptr(dout), H * dh, N.ptr(lse), B, T, H, dh, N.ptr(dq), 3 * H * dh,
+                                      N.stream()))
+        torch.cuda.synchronize()
+        return out.cpu(), dw.cpu(), ao.cpu(), dq.cpu()
+
+    base = run()
+    try:
+        N.check(lib.bsi_set_cu_reserve(32))
+        assert lib.bsi_compute_cus() == full - 32
+        held = run()
+    finally:
+        N.check(lib.bsi_set_cu_reserve(0))
+    assert lib.bsi_compute_cus() == full
+    assert torch.equal(base[0], held[0]) and torch.equal(base[2], held[2]) and torch.equal(base[3], held[3])
+    # the weight gradient's split count follows the CU count: a different (still fixed) summation order
+    assert rel_linf(held[1], base[1]) < 1e-5
+
+
+@pytest.mark.parametrize("p", [0.05, 0.3])
+def test_attention_dropout_words_equal_the_exported_mask(N, p):
+    """The lane-mask words of the 256-token attention kernels (bsi_attention_dropout_words) against bsi_dropout_mask for the same
+    (p, seed, site): word (pair, qb, kt, r), bit 16 g + c <-> element (row = pair * 256 + 16 qb + c, column = 16 kt + 4 g + r)."""
+    lib = N.lib()
+    pairs, seed, site = 6, 0x1234567890ABCDEF, 4
+    keep = torch.empty(pairs * 256 * 256, dtype=torch.uint8, device=DEV)
+    N.check(lib.bsi_dropout_mask(p, seed, site, pairs * 256, 256, N.ptr(keep), N.stream()))
+    words = torch.empty(pairs * 16 * 64, dtype=torch.int64, device=DEV)
+    N.check(lib.bsi_attention_dropout_words(p, seed, site, pairs, N.ptr(words), N.stream()))
+    torch.cuda.synchronize()
+    w = words.cpu().reshape(pairs, 16, 16, 4)
+    bits = ((w.unsqueeze(-1) >> torch.arange(64)) & 1).reshape(pairs, 16, 16, 4, 4, 16)   # pair, qb, kt, r, g, c
+    m = bits.permute(0, 1, 5, 2, 4, 3).reshape(pairs, 256, 256)                             # query 16 qb + c, key 16 kt + 4 g + r
+    k = keep.cpu().reshape(pairs, 256, 256).to(torch.int64)
+    assert torch.equal(m, k)
+    assert abs(float(k.float().mean()) - (1 - p)) < 5e-3
+
+
 def test_gemm_rejects_bad_shapes(N):
     a = N.GemmArgs(A=1, W=1, out=1, M=4, N=24, K=64, lda=64, ldw=64, ldo=24, epilogue=0)
     assert N.lib().bsi_gemm_bf16(C.byref(a), None) == -1

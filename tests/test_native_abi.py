@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.bsi_version() >= 100
 
 
+def test_cu_reserve_setter_contract():
+    """bsi_set_cu_reserve (DPTrainer's CU budget for the RCCL kernels): 0 or a multiple of 8 up to 64; no GPU needed."""
+    from bsi_amd import _native
+
+    lib = _native.lib()
+    assert lib.bsi_set_cu_reserve(0) == 0
+    for bad in (-8, 4, 12, 72):
+        assert lib.bsi_set_cu_reserve(bad) != 0
+    assert lib.bsi_set_cu_reserve(16) == 0 and lib.bsi_set_cu_reserve(0) == 0
+
+
 def test_bsi_surface_matches_reference():
     from bsi_amd import BSI, Discretization
 

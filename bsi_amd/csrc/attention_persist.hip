@@ -275,14 +275,17 @@ __global__ __launch_bounds__(1024) void attention_fwd_p_kernel(const __bf16* __r
                 u32x2 w;
                 w[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
                 w[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-                *reinterpret_cast<u32x2*>(scr + c16 * 128 + (((2 * dt + (g >> 1)) ^ (c16 & 7)) << 4) + (g & 1) * 8) = w;
+                // rows c and c + 8 of a 16-lane group meet in the same 16-B chunk (same c & 7): they take opposite 8-B halves of it
+                // (2-way bank conflict on every ds_write_b64 otherwise: 1.05 M LDS cycles per launch in the round-3 counters)
+                *reinterpret_cast<u32x2*>(scr + c16 * 128 + (((2 * dt + (g >> 1)) ^ (c16 & 7)) << 4) + (((g & 1) ^ (c16 >> 3)) << 3)) = w;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int rr = lane >> 3, ch = lane & 7;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 8 * i + rr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((ch ^ (row & 7)) << 4));
+                u32x4 v = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((ch ^ (row & 7)) << 4));
+                if (i == 1) v = u32x4{v[2], v[3], v[0], v[1]};  // rows 8..15 hold their chunk's halves swapped (see the writes)
                 *reinterpret_cast<u32x4*>(out + ((size_t)b * PT + q0 + row) * ld_out + h * PDH + ch * 8) = v;
             }
         }

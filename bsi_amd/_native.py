@@ -24,7 +24,11 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldo", C.c_int), ("epilogue", C.c_int),
                 ("gate", C.c_void_p), ("gate_rows", C.c_int), ("gate_stride", C.c_int),
-                ("tokens", C.c_int), ("pos", C.c_void_p), ("aux", C.c_void_p), ("out2", C.c_void_p)]
+                ("tokens", C.c_int), ("pos", C.c_void_p), ("aux", C.c_void_p), ("out2", C.c_void_p), ("colsum_rows", C.c_void_p)]
+
+
+class ColsumJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("out", C.c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -157,6 +161,8 @@ _PROTOS = {
     "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
     "bsi_gemm_splitk_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "bsi_gemm_splitk_f32_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "bsi_colsum_rows_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "bsi_colsum_rows_f32": (_i, [C.POINTER(ColsumJob), _i, _vp, _vp]),
     "bsi_gemm_bf16_ws": (_i, [C.POINTER(GemmArgs), _vp, C.c_size_t, _vp]),
     "bsi_gemm_set_variant": (_i, [_i]),
     "bsi_conv_set_grid_limit": (_i, [_i]),

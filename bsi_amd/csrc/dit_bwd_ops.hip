@@ -223,12 +223,18 @@ __global__ void ln_mod_bwd_kernel(const __bf16* __restrict__ dxn, const float* _
 constexpr int FRW = 16;         // rows per wave
 constexpr int FRB = 4 * FRW;    // rows per workgroup
 
-template <int VPL, bool HAS_LN, bool HAS_GATE>
+// HAS_BIAS (round 4, gate part only): the column sums of the bf16 ddelta rows this workgroup writes -- the bias gradient of the Linear
+// whose output gradient ddelta is (out-projection / fc2: autograd's grad_output.sum(0)) -- go to row blockIdx.x of `dbias_rows`
+// ([M / 64][d] fp32, summed in row order by bsi_colsum_rows_f32).  The weight-gradient GEMM then runs without its fused bias
+// gradient, which costs it 10-15 % (tools/tn_bench.py); here the pass is HBM bound and the sums ride along.
+template <int VPL, bool HAS_LN, bool HAS_GATE, bool HAS_BIAS = false>
 __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
     const __bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats,
     const float* __restrict__ scale, int mod_stride, float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride,
     float* dX, const __bf16* __restrict__ delta, const float* __restrict__ gate, int gate_stride, float* __restrict__ dgate,
-    int dgate_stride, __bf16* __restrict__ ddelta, int M, int d, int tokens, DropCfg dc, size_t part_stride) {
+    int dgate_stride, __bf16* __restrict__ ddelta, int M, int d, int tokens, DropCfg dc, size_t part_stride,
+    float* __restrict__ dbias_rows = nullptr) {
+    static_assert(!HAS_BIAS || HAS_GATE, "the bias sums are those of ddelta");
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][nacc][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * FRB;
@@ -239,12 +245,13 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
     const size_t poff = part_stride ? (size_t)((row0 - b * tokens) / FRB) * part_stride : 0;
     const int d4 = d >> 2;
     const float inv_d = 1.0f / (float)d;
-    f32x4 sc1[VPL], gt[VPL], ash[VPL], asc[VPL], agt[VPL];
+    f32x4 sc1[VPL], gt[VPL], ash[VPL], asc[VPL], agt[VPL], abs_[HAS_BIAS ? VPL : 1];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         sc1[i] = z; gt[i] = z; ash[i] = z; asc[i] = z; agt[i] = z;
+        if constexpr (HAS_BIAS) abs_[i] = z;
         if (c < d4) {
             if constexpr (HAS_LN) {
                 const f32x4 s = reinterpret_cast<const f32x4*>(scale + (size_t)b * mod_stride)[c];
@@ -320,7 +327,13 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
                         dd[k] = gt[i][k] * dxv[i][k];
                         agt[i][k] = __fmaf_rn(dxv[i][k], dlv[i][k], agt[i][k]);
                     }
-                    __builtin_nontemporal_store(f32x4_to_bf16(dd), reinterpret_cast<u32x2*>(ddelta + (size_t)row * d) + c);
+                    const u32x2 ddb = f32x4_to_bf16(dd);
+                    __builtin_nontemporal_store(ddb, reinterpret_cast<u32x2*>(ddelta + (size_t)row * d) + c);
+                    if constexpr (HAS_BIAS) {  // the sum of the values the weight-gradient GEMM will read (bf16), as its fused form took it
+                        const f32x4 r = bf16x4_to_f32(ddb);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) abs_[i][k] += r[k];
+                    }
                 }
             }
         }
@@ -385,6 +398,33 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
 #pragma unroll
                         for (int k = 0; k < 4; ++k) atomicAdd(d2 + k, t2[k]);
                     }
+                }
+            }
+        }
+    }
+    if constexpr (HAS_BIAS) {  // second round through the same LDS (it stays at 3 x NACC x d floats: four workgroups per CU)
+        __syncthreads();
+        if (wave > 0) {
+            float* my = red + (size_t)(wave - 1) * NACC * d;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) reinterpret_cast<f32x4*>(my)[c] = abs_[i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < d4) {
+                    f32x4 t = abs_[i];
+                    for (int w = 0; w < 3; ++w) {
+                        const f32x4 o = reinterpret_cast<const f32x4*>(red + (size_t)w * NACC * d)[c];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] += o[k];
+                    }
+                    reinterpret_cast<f32x4*>(dbias_rows + (size_t)blockIdx.x * d)[c] = t;
                 }
             }
         }
@@ -632,7 +672,7 @@ extern "C" int bsi_ln_mod_bwd(const void* dxn, const float* x, const float* scal
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
                          float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream,
-                         size_t part_stride) {
+                         size_t part_stride, float* dbias_rows) {
     const bool ln = dxn != nullptr, gt = delta != nullptr;
     BSI_CHECK_ARG(part_stride % 4 == 0 && (part_stride == 0 || (dmod_stride % 4 == 0 && dgate_stride % 4 == 0)),
                   "bsi_ln_gate_bwd: partial planes need 16-B aligned strides");
@@ -646,9 +686,16 @@ int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, co
     const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
     __bf16* dd = reinterpret_cast<__bf16*>(ddelta);
     const size_t lds = (size_t)3 * ((ln ? 2 : 0) + (gt ? 1 : 0)) * d * sizeof(float);
+    BSI_CHECK_ARG(!dbias_rows || (gt && d > 256), "bsi_ln_gate_bwd: bias-gradient rows need the gate part (d > 256 instance)");
 #define LGB(V, L, G)                                                                                                         \
-    hipLaunchKernelGGL((ln_gate_bwd_kernel<V, L, G>), grid, dim3(TPB), lds, S(stream), g, x, stats, scale, mod_stride, dshift,   \
-                       dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc, part_stride)
+    do {                                                                                                                     \
+        if (dbias_rows && G)                                                                                                 \
+            hipLaunchKernelGGL((ln_gate_bwd_kernel<V, L, G, G>), grid, dim3(TPB), lds, S(stream), g, x, stats, scale, mod_stride, dshift, \
+                               dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc, part_stride, dbias_rows); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((ln_gate_bwd_kernel<V, L, G>), grid, dim3(TPB), lds, S(stream), g, x, stats, scale, mod_stride, dshift, \
+                               dscale, dmod_stride, dX, dl, gate, gate_stride, dgate, dgate_stride, dd, M, d, tokens, dc, part_stride); \
+    } while (0)
 #define LGB_V(L, G)                   \
     do {                              \
         if (d <= 256) LGB(1, L, G);   \

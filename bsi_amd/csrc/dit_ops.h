@@ -17,7 +17,8 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
                                const float* gate0 = nullptr, int write_x = 1, DropCfg mask_dc = DropCfg{}, void* maskw = nullptr);
 int bsi_ln_gate_bwd_drop(const void* dxn, const float* x, const float* stats, const float* scale, int mod_stride, float* dshift,
                          float* dscale, int dmod_stride, float* dX, const void* delta, const float* gate, int gate_stride,
-                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream, size_t part_stride = 0);
+                         float* dgate, int dgate_stride, void* ddelta, int M, int d, int tokens, DropCfg dc, bsi_stream_t stream, size_t part_stride = 0,
+                         float* dbias_rows = nullptr /* [M / 64][d]: column sums of ddelta per 64-row slab (bias gradient), gate part only */);
 // out_bf16[r][c] = bf16(sum over nparts planes), fixed order: the reproducible counterpart of the atomics (part_stride above)
 int bsi_sum_cast_rows_bf16(const float* parts, int nparts, size_t part_stride, int row_stride, int rows, int cols, void* out, int ld_out,
                            bsi_stream_t stream);
@@ -33,3 +34,5 @@ int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int 
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
                            int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
                            const void* maskw = nullptr);
+// gemm_bf16.hip: can the MUL_GELUGRAD GEMM of this shape write bsi_gemm_args::colsum_rows?
+bool bsi_gemm_emits_colsum(int M, int K);

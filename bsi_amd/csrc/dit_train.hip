@@ -119,6 +119,11 @@ struct BwdWs {
     char* tn;      // TN GEMM slabs
     char* cs;      // colsum slabs
     float* decw;   // fp32 [64, dim]   decoder weight gradient with its rows padded to a multiple of 8
+    // bias gradients taken where dY is produced (round 4): per-slab column sums, reduced once per block by bsi_colsum_rows_f32
+    float* rows_fc2;  // fp32 [M / 64][dim]      sums of the dd2 rows (written by the kernel that writes ws.dd for the MLP branch)
+    float* rows_out;  // fp32 [M / 64][dim]      sums of the dd1 rows
+    float* rows_fc1;  // fp32 [ceil(M / 128)][4 dim]  sums of the dhp rows (GEMM epilogue)
+    char* rows_scratch;
     size_t total;
 };
 
@@ -139,15 +144,21 @@ inline BwdWs carve_bwd(const Dims& d, int B, void* base) {
     w.tn = p + off; off += au(bsi_gemm_tn_workspace_bytes((int)M, 4 * (int)dim, (int)dim));
     w.cs = p + off; off += au(bsi_colsum_workspace_bytes(6 * (int)dim));
     w.decw = reinterpret_cast<float*>(p + off); off += au((size_t)64 * dim * 4);
+    const size_t r64 = (M + 63) / 64, r128 = (M + 127) / 128;
+    w.rows_fc2 = reinterpret_cast<float*>(p + off); off += au(r64 * dim * 4);
+    w.rows_out = reinterpret_cast<float*>(p + off); off += au(r64 * dim * 4);
+    w.rows_fc1 = reinterpret_cast<float*>(p + off); off += au(r128 * 4 * dim * 4);
+    w.rows_scratch = p + off;
+    off += au(2 * bsi_colsum_rows_scratch_bytes((int)r64, (int)dim) + bsi_colsum_rows_scratch_bytes((int)r128, 4 * (int)dim));
     w.total = off;
     return w;
 }
 
 int gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo, int M, int N, int K, int epi,
-         const void* aux, void* out2, const float* pos, int tokens, bsi_stream_t stream) {
+         const void* aux, void* out2, const float* pos, int tokens, bsi_stream_t stream, float* colsum_rows = nullptr) {
     bsi_gemm_args g{};
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
-    g.epilogue = epi; g.aux = aux; g.out2 = out2; g.pos = pos; g.tokens = tokens;
+    g.epilogue = epi; g.aux = aux; g.out2 = out2; g.pos = pos; g.tokens = tokens; g.colsum_rows = colsum_rows;
     return bsi_gemm_bf16(&g, stream);
 }
 
@@ -274,6 +285,14 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
     const size_t plane = (size_t)B * 6 * dim;  // floats per plane
     const int dstride = 6 * dim;               // row stride inside a plane
     auto dmod_of = [&](int l) { return ws.dmod + (size_t)(l & 1) * nplanes * plane; };
+    // Bias gradients of out-projection, fc2 and fc1: the kernels that WRITE those layers' output gradients (the LayerNorm / gate backward
+    // for dd1 and dd2, the GELU'-epilogue GEMM for dhp) also leave per-slab column sums; one small reduction per block adds the slabs in
+    // fixed order.  The weight-gradient GEMMs then run without the bias rider (gemm_tn.hip: -9..-14 % per launch).  The qkv and adaLN
+    // biases stay fused in their weight-gradient GEMMs (dqkv's producer, the attention backward, has no spare registers).
+    static const bool fused_bias = [] { const char* e = getenv("BSI_TRAIN_FUSED_BIAS"); return e && *e == '1'; }();
+    const bool rel_dd = !fused_bias && dim > 256;
+    const bool rel_fc1 = !fused_bias && bsi_gemm_emits_colsum(M, dim);
+    const int r64 = M / 64, r128 = (M + 127) / 128;
     // decoder: dX = d/dx_final, parameter gradients of patch_decoder (dit.py:163-165)
     {
         const int Pp = (d.P + 7) / 8 * 8;  // yb -> ws.dd, dYb -> ws.dsmall (Pp <= 64 <= dim columns)
@@ -293,7 +312,7 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         BlockTape bt = block_tape(tp, d, B, l);
         TRY(bsi_ln_gate_bwd_drop(nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, ws.dX, bt.d2,
                                  tp.mod + (size_t)l * 6 * dim + 5 * dim, mod_stride, dmod_of(l) + 5 * dim, dstride, ws.dd, M, dim,
-                                 d.tokens, DropCfg{}, stream, plane));
+                                 d.tokens, DropCfg{}, stream, plane, rel_dd ? ws.rows_fc2 : nullptr));
     }
     for (int l = d.depth - 1; l >= 0; --l) {
         const bsi_dit_block_weights& bw = w->blocks[l];
@@ -305,17 +324,31 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         (void)bw;
         // ---- MLP branch: x2 = xb + g_m * d2.  ws.dd = g_m * dX was produced by the fused kernel of the block above (or by the
         //      gate-only launch in front of the loop).  dh = dd2 . W2, times gelu'(hp)  -> dhp
-        TRY(gemm(ws.dd, dim, bT.fc2_wT, dim, nullptr, ws.dbig, 4 * dim, M, 4 * dim, dim, BSI_EPI_MUL_GELUGRAD_BF16, bt.hp, nullptr, nullptr, 0, stream));
-        TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, bg.fc2_b, 0, ws.tn, stream));
+        TRY(gemm(ws.dd, dim, bT.fc2_wT, dim, nullptr, ws.dbig, 4 * dim, M, 4 * dim, dim, BSI_EPI_MUL_GELUGRAD_BF16, bt.hp, nullptr, nullptr, 0, stream,
+                 rel_fc1 ? ws.rows_fc1 : nullptr));
+        if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.h, 4 * dim, M, dim, 4 * dim, bg.fc2_w, 4 * dim, bg.fc2_b, 0, ws.tn, stream));
         // dxn2 = dhp . W1
         TRY(gemm(ws.dbig, 4 * dim, bT.fc1_wT, 4 * dim, nullptr, ws.dsmall, dim, M, dim, 4 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));
-        TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, bg.fc1_b, 0, ws.tn, stream));
+        if (rel_fc1) TRY(bsi_gemm_tn_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 4 * dim, bt.xn2, dim, M, 4 * dim, dim, bg.fc1_w, dim, bg.fc1_b, 0, ws.tn, stream));
         // LayerNorm 2 backward (dX becomes dL/dxb) + attention branch xb = xa + g_a * d1: dd = g_a * dX, dg_a
         TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xb, bt.sb, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, dstride, ws.dX,
                                  bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, dstride, ws.dd, M, dim, d.tokens,
-                                 make_drop(dropout_p, seed, 2 * l + 1), stream, plane));
+                                 make_drop(dropout_p, seed, 2 * l + 1), stream, plane, rel_dd ? ws.rows_out : nullptr));
+        if (rel_dd || rel_fc1) {  // the three slab tables of this block are complete (rows_fc2 is rewritten by the LayerNorm-1 launch below)
+            bsi_colsum_job jobs[3];
+            int nj = 0;
+            if (rel_dd) {
+                jobs[nj++] = bsi_colsum_job{ws.rows_fc2, r64, dim, dim, bg.fc2_b};
+                jobs[nj++] = bsi_colsum_job{ws.rows_out, r64, dim, dim, bg.out_b};
+            }
+            if (rel_fc1) jobs[nj++] = bsi_colsum_job{ws.rows_fc1, r128, 4 * dim, 4 * dim, bg.fc1_b};
+            TRY(bsi_colsum_rows_f32(jobs, nj, ws.rows_scratch, stream));
+        }
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
-        TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
+        if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
                                    make_drop(dropout_p, seed, 2 * l), stream, bt.maskw));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
@@ -326,7 +359,8 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
             const float* mlb = tp.mod + (size_t)(l - 1) * 6 * dim;
             float* dmlb = dmod_of(l - 1);
             TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, dstride, ws.dX, below.d2,
-                                     mlb + 5 * dim, mod_stride, dmlb + 5 * dim, dstride, ws.dd, M, dim, d.tokens, DropCfg{}, stream, plane));
+                                     mlb + 5 * dim, mod_stride, dmlb + 5 * dim, dstride, ws.dd, M, dim, d.tokens, DropCfg{}, stream, plane,
+                                     rel_dd ? ws.rows_fc2 : nullptr));
         } else {
             TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xa, bt.sa, ml + dim, mod_stride, dml, dml + dim, dstride, ws.dX, nullptr, nullptr,
                                      0, nullptr, 0, nullptr, M, dim, d.tokens, DropCfg{}, stream, plane));

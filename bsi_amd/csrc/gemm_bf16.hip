@@ -43,6 +43,7 @@ struct GemmParams {
     const float* pos;
     const void* aux;  // MUL_GELUGRAD: pre-activation (bf16, layout of out)
     void* out2;       // BIAS_GELU_DUAL: pre-activation output (bf16, layout of out)
+    float* colsum;    // MUL_GELUGRAD (K = 64 kernel): [ceil(M / 128)][N] column sums of the output rows of a wave tile, or null
     int tiles_m, tiles_n;
     int gm;       // rasterisation: tiles are walked in bands of gm m-tiles, m fastest inside a band
     // split-K (small M, gemm_bf16_pring_kernel with an fp32 epilogue only): workgroup tile index = split * tiles_m*tiles_n + tile;
@@ -380,6 +381,11 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
         else if (j == 1 || j == 7) asm volatile("s_waitcnt vmcnt(4) ; data of %0 %1" : "+v"(d[0]), "+v"(d[1]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(6) ; data of %0 %1" : "+v"(d[0]), "+v"(d[1]) :: "memory");
     };
+    // optional column sums of the tile's output rows (GemmParams::colsum): 16 per lane, accumulated over the 8 row blocks
+    const bool colsum = EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr;
+    float cs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
     if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
         load_aux(0, ax[0]);
         load_aux(1, ax[1]);
@@ -425,8 +431,31 @@ __device__ __forceinline__ void wave_tile_epilogue_train(const GemmParams& p, f3
             w0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
             w1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
         }
+        if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+            if (colsum && mw0 + 16 * j + rho < p.M) {  // the sum of the bf16 values the weight-gradient GEMM will read
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[2 * e] += __uint_as_float(w0[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(w0[e] & 0xffff0000u);
+                    cs[8 + 2 * e] += __uint_as_float(w1[e] << 16);
+                    cs[8 + 2 * e + 1] += __uint_as_float(w1[e] & 0xffff0000u);
+                }
+            }
+        }
         store_pair(p.out, j, w0, w1);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (EPI == BSI_EPI_MUL_GELUGRAD_BF16) {
+        if (colsum) {  // the 16 lanes of a 16-lane row hold the same columns: DPP row sum, lane rho = 0 stores the wave tile's 16 sums
+            f32x4 o4[4];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o4[e >> 2][e & 3] = row16_sum(cs[e]);
+            if (rho == 0 && nb_ok && mw0 < p.M) {
+                float* dst = p.colsum + (size_t)(mw0 >> 7) * p.N + nb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = o4[q];
+            }
+        }
     }
 }
 
@@ -1131,6 +1160,9 @@ extern "C" int bsi_gemm_set_variant(int v) {
     return BSI_OK;
 }
 
+// does the MUL_GELUGRAD GEMM of this shape run the kernel whose epilogue can emit column sums (bsi_gemm_args::colsum_rows)?
+bool bsi_gemm_emits_colsum(int M, int K) { return g_variant == 12 && M > 128 && K >= 128 && K % 64 == 0; }
+
 extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
     BSI_CHECK_ARG(a != nullptr, "bsi_gemm_bf16: null args");
     BSI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "bsi_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -1152,6 +1184,9 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
     p.pos = a->pos;
     p.aux = a->aux;
     p.out2 = a->out2;
+    p.colsum = a->colsum_rows;
+    BSI_CHECK_ARG(!a->colsum_rows || (a->epilogue == BSI_EPI_MUL_GELUGRAD_BF16 && bsi_gemm_emits_colsum(a->M, a->K)),
+                  "bsi_gemm_bf16: colsum_rows is an output of the MUL_GELUGRAD epilogue of the K = 64 kernel (M > 128, K %% 64 == 0)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (a->epilogue) {
         case BSI_EPI_BIAS_F32: return launch_epi<BSI_EPI_BIAS_F32>(p, s);

@@ -794,6 +794,111 @@ extern "C" int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int 
     return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, out, ldc, colsum_out, accumulate, workspace, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Column sums of fp32 row tables (bias gradients whose per-slab partial rows the producers of dY write, round 4): out[c] = sum_r
+// src[r][c], rows added in a fixed order.  One kernel, run twice: stage 1 sums chunks of 64 rows into partial rows, stage 2 (the same
+// kernel on the partial rows: <= 64 of them = one chunk) writes the result.  Up to three tables per launch.
+namespace {
+struct ColsumJobs {
+    const float* src[3];
+    float* dst[3];
+    int rows[3], cols[3], ld[3], dst_ld[3];
+    int blk0[4];  // first block of job j (blk0[njobs] = grid)
+    int cblocks[3];  // column blocks (of 256 columns) of job j
+    int njobs;
+    int chunk;  // rows per block: CS_CHUNK in stage 1, all of them in stage 2
+};
+constexpr int CS_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const ColsumJobs jb) {
+    __shared__ f32x4 part[3][64];
+    int j = 0;
+    while (j + 1 < jb.njobs && (int)blockIdx.x >= jb.blk0[j + 1]) ++j;
+    const int lb = blockIdx.x - jb.blk0[j];
+    const int cb = lb % jb.cblocks[j], chunk = lb / jb.cblocks[j];
+    const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = cb * 256 + q * 4;
+    const int r0 = chunk * jb.chunk, r1 = jb.chunk > 0 ? min(jb.rows[j], r0 + jb.chunk) : jb.rows[j];
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < jb.cols[j]) {
+        const float* s = jb.src[j] + c;
+        const size_t ld = (size_t)jb.ld[j];
+        int r = r0 + g;
+        for (; r + 12 < r1; r += 16) {  // four independent loads in flight
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(s + (size_t)(r + 4 * u) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += v[u][e];
+        }
+        for (; r < r1; r += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s + (size_t)r * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+    }
+    if (g > 0) part[g - 1][q] = a;
+    __syncthreads();
+    if (g == 0 && c < jb.cols[j]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += part[k][q][e];
+        *reinterpret_cast<f32x4*>(jb.dst[j] + (size_t)chunk * jb.dst_ld[j] + c) = a;
+    }
+}
+}  // namespace
+
+extern "C" size_t bsi_colsum_rows_scratch_bytes(int rows, int cols) {  // one partial row per chunk of 64 rows
+    return rows > 0 && cols > 0 ? (size_t)((rows + CS_CHUNK - 1) / CS_CHUNK) * (size_t)cols * sizeof(float) : 0;
+}
+
+extern "C" int bsi_colsum_rows_f32(const bsi_colsum_job* jobs, int njobs, void* scratch, bsi_stream_t stream) {
+    BSI_CHECK_ARG(jobs && njobs >= 1 && njobs <= 3 && scratch, "bsi_colsum_rows_f32: 1..3 jobs and a scratch buffer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ColsumJobs a{}, b{};
+    a.njobs = b.njobs = njobs;
+    float* sc = reinterpret_cast<float*>(scratch);
+    int ga = 0, gb = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const bsi_colsum_job& jo = jobs[j];
+        BSI_CHECK_ARG(jo.src && jo.out && jo.rows > 0 && jo.cols > 0 && jo.cols % 4 == 0 && jo.ld % 4 == 0 && jo.ld >= jo.cols,
+                      "bsi_colsum_rows_f32: job %d: rows=%d cols=%d ld=%d", j, jo.rows, jo.cols, jo.ld);
+        const int chunks = (jo.rows + CS_CHUNK - 1) / CS_CHUNK, cblocks = (jo.cols + 255) / 256;
+        a.src[j] = jo.src; a.rows[j] = jo.rows; a.cols[j] = jo.cols; a.ld[j] = jo.ld; a.cblocks[j] = cblocks; a.blk0[j] = ga;
+        a.dst[j] = chunks > 1 ? sc : jo.out;  // a single chunk is the result already
+        a.dst_ld[j] = jo.cols;
+        ga += cblocks * chunks;
+        b.src[j] = sc; b.rows[j] = chunks > 1 ? chunks : 0; b.cols[j] = jo.cols; b.ld[j] = jo.cols; b.cblocks[j] = cblocks; b.blk0[j] = gb;
+        b.dst[j] = jo.out; b.dst_ld[j] = jo.cols;
+        gb += chunks > 1 ? cblocks : 0;
+        sc += (size_t)chunks * jo.cols;
+    }
+    a.blk0[njobs] = ga; b.blk0[njobs] = gb;
+    a.chunk = CS_CHUNK;
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(ga), dim3(256), 0, s, a);
+    BSI_CHECK_LAUNCH("bsi_colsum_rows_f32");
+    if (gb > 0) {
+        // stage 2 walks only the jobs that had more than one chunk: compact the table
+        ColsumJobs c{};
+        int n = 0, g2 = 0;
+        for (int j = 0; j < njobs; ++j)
+            if (b.rows[j] > 0) {
+                c.src[n] = b.src[j]; c.dst[n] = b.dst[j]; c.rows[n] = b.rows[j]; c.cols[n] = b.cols[j]; c.ld[n] = b.ld[j];
+                c.dst_ld[n] = b.dst_ld[j]; c.cblocks[n] = b.cblocks[j]; c.blk0[n] = g2;
+                g2 += b.cblocks[j];
+                ++n;
+            }
+        c.blk0[n] = g2; c.njobs = n;
+        c.chunk = 0;
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3(g2), dim3(256), 0, s, c);
+        BSI_CHECK_LAUNCH("bsi_colsum_rows_f32(stage 2)");
+    }
+    return BSI_OK;
+}
+
 extern "C" size_t bsi_colsum_workspace_bytes(int N) { return (size_t)64 * (size_t)((N + 3) / 4 * 4) * sizeof(float); }
 
 extern "C" int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,

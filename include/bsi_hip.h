@@ -218,6 +218,9 @@ typedef struct bsi_gemm_args {
     const float* pos; /* [tokens, N] (BIAS_POS) */
     const void* aux;  /* bf16 [M, ldo] (MUL_GELUGRAD) */
     void* out2;       /* bf16 [M, ldo] (BIAS_GELU_DUAL) */
+    float* colsum_rows; /* optional, MUL_GELUGRAD with M > 128 only: fp32 [ceil(M / 128)][N]; row s receives the column sums of output rows
+                           128 s .. 128 s + 127 (of the bf16 values written) -- summed over s (bsi_colsum_rows_f32) this is the bias
+                           gradient of the Linear whose output gradient `out` is (autograd's grad_output.sum(0) of fc1) */
 } bsi_gemm_args;
 int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
 /* Small-M latency path: same contract, plus a caller-owned scratch buffer.  When M <= 2048, K >= 2048 and the epilogue is a plain
@@ -240,6 +243,13 @@ int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int 
  * all-ones operand per stage in the workgroups of the first k tile, instead of a second pass over dY). */
 int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
                           float* colsum_out, int accumulate, void* workspace, bsi_stream_t stream);
+/* out[c] = sum over r < rows of src[r * ld + c] (fp32, c < cols, cols % 4 == 0), rows added in index order (deterministic): the second
+ * stage of the bias gradients whose per-slab column sums the producers of dY write (bsi_gemm_args::colsum_rows, the LayerNorm /
+ * gate backward).  Up to three jobs in one pair of launches.  scratch: the sum of bsi_colsum_rows_scratch_bytes(rows, cols) over the
+ * jobs.  ld % 4 == 0, src and out 16-byte aligned. */
+typedef struct bsi_colsum_job { const float* src; int rows, cols, ld; float* out; } bsi_colsum_job;
+size_t bsi_colsum_rows_scratch_bytes(int rows, int cols);
+int bsi_colsum_rows_f32(const bsi_colsum_job* jobs /*host*/, int njobs, void* scratch, bsi_stream_t stream);
 /* Bias gradient: out[n] (+)= sum_m Y[m,n] for bf16 Y [M, ld]. */
 size_t bsi_colsum_workspace_bytes(int N);
 int bsi_colsum_bf16(const void* Y, int ld, int M, int N, float* out, int accumulate, void* workspace,

@@ -341,6 +341,61 @@ def test_gemm_training_epilogues(N, M, Nn, K):
     assert torch.equal(first.view(torch.int16), out.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,Nn,K", [(512, 256, 256), (1000, 320, 192), (4096 + 40, 1024, 256)])
+def test_gemm_gelugrad_column_sums_and_row_table_reduction(N, M, Nn, K):
+    """bsi_gemm_args::colsum_rows: the MUL_GELUGRAD epilogue leaves, per 128-row slab, the column sums of the bf16 values it stores (the
+    fc1 bias gradient, autograd's grad_output.sum(0), taken where grad_output is produced), and bsi_colsum_rows_f32 adds the slabs
+    in fixed order.  The slab table must equal the sums of the OUTPUT's rows (fp32 adds of at most 128 values), the reduced vector
+    the column sum of the whole output; ragged M / N tails included; the main output is bit-identical with and without the rider."""
+    gen = torch.Generator().manual_seed(M + 5 * Nn + K)
+    A = bf16r(torch.randn((M, K), generator=gen))
+    W = bf16r(torch.randn((Nn, K), generator=gen) / math.sqrt(K))
+    aux = bf16r(torch.randn((M, Nn), generator=gen) * 1.5)
+    dA, dW, dx = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(aux.to(torch.bfloat16))
+    out = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    plain = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    slabs = (M + 127) // 128
+    rows = torch.full((slabs, Nn), float("nan"), dtype=torch.float32, device=DEV)
+    a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=None, out=plain.data_ptr(), aux=dx.data_ptr(), M=M, N=Nn, K=K,
+                   lda=K, ldw=K, ldo=Nn, epilogue=N.EPI_MUL_GELUGRAD_BF16)
+    N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+    a.out, a.colsum_rows = out.data_ptr(), rows.data_ptr()
+    N.check(N.lib().bsi_gemm_bf16(C.byref(a), N.stream()))
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+    o = out.cpu().double()
+    want_rows = torch.stack([o[128 * i:128 * (i + 1)].sum(0) for i in range(slabs)])
+    scale = o.abs().sum(0).max()
+    assert float((rows.cpu().double() - want_rows).abs().max()) < 2e-6 * float(scale)
+    res = torch.full((Nn,), float("nan"), dtype=torch.float32, device=DEV)
+    scratch = torch.empty(max(1, N.lib().bsi_colsum_rows_scratch_bytes(slabs, Nn)), dtype=torch.uint8, device=DEV)
+    job = N.ColsumJob(src=rows.data_ptr(), rows=slabs, cols=Nn, ld=Nn, out=res.data_ptr())
+    N.check(N.lib().bsi_colsum_rows_f32(C.byref(job), 1, N.ptr(scratch), N.stream()))
+    assert float((res.cpu().double() - o.sum(0)).abs().max()) < 2e-6 * float(scale)
+
+
+def test_colsum_rows_three_jobs_two_stages(N):
+    """bsi_colsum_rows_f32: three tables in one pair of launches -- one above 64 rows (two stages, ragged last chunk), one of a
+    single chunk (written directly), one with a leading dimension wider than its columns -- against fp64, and twice the same bits."""
+    gen = torch.Generator().manual_seed(11)
+    t0 = dev(torch.randn((2048 + 37, 1024), generator=gen))
+    t1 = dev(torch.randn((40, 260), generator=gen))
+    t2 = dev(torch.randn((130, 512), generator=gen))  # columns 0..299 of a 512-wide table
+    outs = [torch.full((n,), float("nan"), dtype=torch.float32, device=DEV) for n in (1024, 260, 300)]
+    jobs = (N.ColsumJob * 3)(N.ColsumJob(src=t0.data_ptr(), rows=t0.shape[0], cols=1024, ld=1024, out=outs[0].data_ptr()),
+                             N.ColsumJob(src=t1.data_ptr(), rows=40, cols=260, ld=260, out=outs[1].data_ptr()),
+                             N.ColsumJob(src=t2.data_ptr(), rows=130, cols=300, ld=512, out=outs[2].data_ptr()))
+    need = sum(N.lib().bsi_colsum_rows_scratch_bytes(r, c) for r, c in ((t0.shape[0], 1024), (40, 260), (130, 300)))
+    scratch = torch.empty(need, dtype=torch.uint8, device=DEV)
+    N.check(N.lib().bsi_colsum_rows_f32(jobs, 3, N.ptr(scratch), N.stream()))
+    first = [o.clone() for o in outs]
+    for o, t, c in zip(outs, (t0, t1, t2), (1024, 260, 300)):
+        assert rel_linf(o, t.cpu().double()[:, :c].sum(0)) < 2e-6
+    N.check(N.lib().bsi_colsum_rows_f32(jobs, 3, N.ptr(scratch), N.stream()))
+    for o, f in zip(outs, first):
+        assert torch.equal(o, f)
+    assert N.lib().bsi_colsum_rows_f32(jobs, 4, N.ptr(scratch), N.stream()) != 0
+
+
 @pytest.mark.parametrize("epi_name", ["bias", "gelu"])
 def test_gemm_persistent_tile_handover_full_size(N, epi_name):
     """768 tiles on 256 CUs: every persistent workgroup walks 3 tiles, so the DMA ring, the epilogue's store allowance and the

@@ -693,6 +693,10 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
     BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 4 == 0, "bsi_attention_bwd: bad leading dimensions");
     static const bool resident_only = getenv("BSI_ATTN_BWD_RESIDENT") != nullptr;  // A/B partner of the persistent kernel
+    static const bool two_pass = getenv("BSI_ATTN_BWD_TWO_PASS") != nullptr;        // A/B partner of the single-sweep kernel (round 4)
+    if (tokens == PT && !resident_only && !two_pass &&
+        (!dc.thr || (maskw && bsi_attention_uses_mask_words(tokens, dh))))  // the hash form of the mask stays with the two-pass kernel
+        return bsi_attention_bwd_exchange(qkv, ld_qkv, out, dout, ld_o, lse, B, heads, dqkv, ld_dqkv, dc, maskw, reinterpret_cast<hipStream_t>(stream));
     if (tokens == PT && !resident_only) {
         const int pairs = B * heads, ncu = compute_cus();
         const int grid = pairs < ncu ? pairs : ncu;

@@ -36,3 +36,6 @@ int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const v
                            const void* maskw = nullptr);
 // gemm_bf16.hip: can the MUL_GELUGRAD GEMM of this shape write bsi_gemm_args::colsum_rows?
 bool bsi_gemm_emits_colsum(int M, int K);
+// attention_bwd_x.hip: the single-sweep backward (256 tokens, head dim 64; dropout off, or on with the mask words)
+int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
+                               int heads, void* dqkv, int ld_dqkv, DropCfg dc, const void* maskw, hipStream_t stream);

@@ -19,7 +19,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src,loads", [("gemm_bf16.hip", 32), ("conv_igemm.hip", 128), ("attention_persist.hip", 16),
-                                       ("attention_bwd.hip", 100), ("gemm_tn.hip", 40)])  # round 3: asm fragment loads / transposed reads
+                                       ("attention_bwd.hip", 100), ("gemm_tn.hip", 40), ("attention_bwd_x.hip", 100)])  # round 3 / 4: asm fragment loads, transposed reads
 def test_inline_asm_loads_are_waited_for(src, loads):
     out = tempfile.mktemp(suffix=".s")
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",

@@ -35,6 +35,10 @@ constexpr int MK = ST + 4 * PT * 4;                   // dropout words of the cu
 constexpr int MK_BYTES = 8192;
 constexpr int LDS_BYTES = MK + MK_BYTES;              // 159744
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+#ifndef ATTN_ABL
+#define ATTN_ABL 0  // timing ablations of tools/experiments/attn_bwd_ablate.sh (wrong results): 1 softmax, 2 dV / dK, 4 dQ, 8 barrier, 16 S / dP, 32 next-pair fetches, 64 X write
+#endif
+constexpr int ABL = ATTN_ABL;
 
 __device__ __forceinline__ int sw(int r) { return ((r >> 1) & 3) << 1; }
 __device__ __forceinline__ const char* row_chunk(const char* tile, int r, int c) { return tile + r * RB + ((c ^ sw(r)) << 4); }
@@ -207,12 +211,43 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt][0] = dk[dt][1] = dv[dt][0] = dv[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // ---- dQ^T tile (head-dim block dtw, queries 32 tt + 16 jqw ..) of trip tt = K^T . dS^T over all 256 keys, from X[tt & 1]: all 16
+        //      transposed reads are issued at once, the first four MFMAs start when half of them are back (LDS returns in order).
+        //      (Running the tile one trip late, under the next trip's softmax, measured the same time at 15 registers more: not kept.)
+        Frag xb[8];
+        f32x4 dq, dq1;
+#define X_RD(J_) xb[J_].h[0] = tr_rd<(J_) * 32 * XP>(xr); xb[J_].h[1] = tr_rd<(J_) * 32 * XP + 16 * XP>(xr)
+        auto dq_tile = [&](int tt) {
+            const unsigned xr = xr0 + (tt & 1) * XSZ;
+            X_RD(0); X_RD(1); X_RD(2); X_RD(3);
+            X_RD(4); X_RD(5); X_RD(6); X_RD(7);
+            asm volatile("s_waitcnt lgkmcnt(8) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
+                         : "+v"(xb[0].h[0]), "+v"(xb[0].h[1]), "+v"(xb[1].h[0]), "+v"(xb[1].h[1]), "+v"(xb[2].h[0]), "+v"(xb[2].h[1]),
+                           "+v"(xb[3].h[0]), "+v"(xb[3].h[1]));
+            dq = dq1 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains of four: a dependent MFMA waits for its predecessor's result
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[0].v, xb[0].v, dq, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[1].v, xb[1].v, dq1, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[2].v, xb[2].v, dq, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[3].v, xb[3].v, dq1, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
+                         : "+v"(xb[4].h[0]), "+v"(xb[4].h[1]), "+v"(xb[5].h[0]), "+v"(xb[5].h[1]), "+v"(xb[6].h[0]), "+v"(xb[6].h[1]),
+                           "+v"(xb[7].h[0]), "+v"(xb[7].h[1]));
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[4].v, xb[4].v, dq, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[5].v, xb[5].v, dq1, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[6].v, xb[6].v, dq, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[7].v, xb[7].v, dq1, 0, 0, 0);
+            u32x2 w;  // 1 store
+            w[0] = pack_bf16x2((dq[0] + dq1[0]) * scale, (dq[1] + dq1[1]) * scale);
+            w[1] = pack_bf16x2((dq[2] + dq1[2]) * scale, (dq[3] + dq1[3]) * scale);
+            char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + 32 * tt + 16 * jqw) * ld_dqkv + h * DH + 16 * dtw) * 2;
+            *reinterpret_cast<u32x2*>(ob + out_off) = w;
+        };
 #pragma unroll 1
         for (int t = 0; t < 8; ++t) {
             const int qc = 32 * t;
             // ---- S = Q . K^T, dP = dO . V^T for 32 queries x this wave's 32 keys (key on the lane, four queries per register quad)
             f32x4 s[2][2], dp[2][2];
-            if (t == 0) WAIT_V(21 + NM);  // fetched in trip 7 of the previous pair, in front of its 3 + 1 + NM + 1 fetches and the 16 stores
+            if (t == 0) WAIT_V(20 + NM);  // fetched in trip 7 of the previous pair, in front of its 3 + 1 + NM fetches and the 16 stores
             bf16x8 vf[2][2];
 #pragma unroll
             for (int jk = 0; jk < 2; ++jk)
@@ -232,14 +267,26 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     const bf16x8 da = *reinterpret_cast<const bf16x8*>(row_chunk(Dl, row, 4 * ks + g));
 #pragma unroll
                     for (int jk = 0; jk < 2; ++jk) {
+                        if constexpr (ABL & 16) {
+                            s[qt][jk][0] += __builtin_bit_cast(f32x4, qa)[0] + __builtin_bit_cast(f32x4, kf[jk][ks])[0];
+                            dp[qt][jk][0] += __builtin_bit_cast(f32x4, da)[0] + __builtin_bit_cast(f32x4, vf[jk][ks])[0];
+                            continue;
+                        }
                         s[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[jk][ks], s[qt][jk], 0, 0, 0);
                         dp[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[jk][ks], dp[qt][jk], 0, 0, 0);
                     }
                 }
             }
+            // ---- the transposed Q / dO fragments of the first two head-dim blocks (for dK / dV) do not depend on the softmax: their reads go
+            //      out in front of it, the other two blocks' right behind it, and each group of eight MFMAs waits only for its own eight
+            const unsigned qco = (unsigned)qc * RB;
+            Frag dot[4], qt_[4];
+#define QD_RD(DT_)                                                                                                   \
+    dot[DT_].h[0] = tr_rd<DL>(tq[DT_] + qco); dot[DT_].h[1] = tr_rd<DL + 16 * RB>(tq[DT_] + qco);                   \
+    qt_[DT_].h[0] = tr_rd<0>(tq[DT_] + qco);  qt_[DT_].h[1] = tr_rd<16 * RB>(tq[DT_] + qco)
+            if constexpr (!(ABL & 2)) { QD_RD(0); QD_RD(1); }
             // ---- P = exp2(S * scale * log2e - lse * log2e), dS / scale = P * (dP - delta) (the softmax scale, a power of two, multiplies
             //      the dQ and dK tiles at their stores: bit-identical, one multiply per score element less); dropped P for dV
-            const unsigned qco = (unsigned)qc * RB;
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const f32x4 lr = *reinterpret_cast<const f32x4*>(lse_s + pb * PT + qc + 16 * qt + 4 * g);
@@ -254,6 +301,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     }
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {  // packed arithmetic: two queries per instruction
+                        if constexpr (ABL & 1) continue;
                         const f32x2_ arg = __builtin_elementwise_fma(f32x2_{s[qt][jk][r], s[qt][jk][r + 1]}, f32x2_{sl2, sl2}, f32x2_{-lr[r], -lr[r + 1]});
                         const f32x2_ pv = f32x2_{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
                         f32x2_ dpv = f32x2_{dp[qt][jk][r], dp[qt][jk][r + 1]};
@@ -291,7 +339,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     dsf[jk].v[4 + r] = (__bf16)dp[1][jk][r];
                 }
             // ---- dS^T block to the exchange buffer: X[key][query], 4 queries (8 B) per store
-            {
+            if constexpr (!(ABL & 64)) {
                 char* xw = xw0 + (t & 1) * XSZ;
 #pragma unroll
                 for (int jk = 0; jk < 2; ++jk) {
@@ -299,81 +347,63 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = u32x2{dsf[jk].u[2], dsf[jk].u[3]};
                 }
             }
-            // ---- dV^T += dO^T . P, dK^T += Q^T . dS: transposed Q / dO fragments as inline asm, two 32-B blocks of the head dimension
-            //      at a time: 8 reads, one wait that names them, 8 MFMAs
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                Frag dot[2], qt_[2];
-#pragma unroll
-                for (int d2 = 0; d2 < 2; ++d2) {
-                    const int dt = 2 * half + d2;
-                    dot[d2].h[0] = tr_rd<DL>(tq[dt] + qco); dot[d2].h[1] = tr_rd<DL + 16 * RB>(tq[dt] + qco);
-                    qt_[d2].h[0] = tr_rd<0>(tq[dt] + qco);  qt_[d2].h[1] = tr_rd<16 * RB>(tq[dt] + qco);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
+            // ---- dV^T += dO^T . P, dK^T += Q^T . dS
+            if constexpr (ABL & 2) {
+                dv[0][0][0] += __builtin_bit_cast(f32x4, pf[0].v)[0] + __builtin_bit_cast(f32x4, pf[1].v)[0];
+                dk[0][0][0] += __builtin_bit_cast(f32x4, dsf[0].v)[0] + __builtin_bit_cast(f32x4, dsf[1].v)[0];
+            } else {
+                QD_RD(2); QD_RD(3);
+                asm volatile("s_waitcnt lgkmcnt(8) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
                              : "+v"(dot[0].h[0]), "+v"(dot[0].h[1]), "+v"(dot[1].h[0]), "+v"(dot[1].h[1]), "+v"(qt_[0].h[0]),
                                "+v"(qt_[0].h[1]), "+v"(qt_[1].h[0]), "+v"(qt_[1].h[1]));
 #pragma unroll
-                for (int d2 = 0; d2 < 2; ++d2) {
-                    const int dt = 2 * half + d2;
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int jk = 0; jk < 2; ++jk) {
-                        dv[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[d2].v, pf[jk].v, dv[dt][jk], 0, 0, 0);
-                        dk[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_[d2].v, dsf[jk].v, dk[dt][jk], 0, 0, 0);
+                        dv[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt].v, pf[jk].v, dv[dt][jk], 0, 0, 0);
+                        dk[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_[dt].v, dsf[jk].v, dk[dt][jk], 0, 0, 0);
                     }
-                }
+                asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
+                             : "+v"(dot[2].h[0]), "+v"(dot[2].h[1]), "+v"(dot[3].h[0]), "+v"(dot[3].h[1]), "+v"(qt_[2].h[0]),
+                               "+v"(qt_[2].h[1]), "+v"(qt_[3].h[0]), "+v"(qt_[3].h[1]));
+#pragma unroll
+                for (int dt = 2; dt < 4; ++dt)
+#pragma unroll
+                    for (int jk = 0; jk < 2; ++jk) {
+                        dv[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt].v, pf[jk].v, dv[dt][jk], 0, 0, 0);
+                        dk[dt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_[dt].v, dsf[jk].v, dk[dt][jk], 0, 0, 0);
+                    }
             }
-            PBARRIER();  // every wave's dS block is in X[t & 1]; the trip's Q / dO rows and dropout words are dead
+#undef QD_RD
+            if constexpr (!(ABL & 8)) PBARRIER();  // every wave's dS block is in X[t & 1]; the trip's Q / dO rows and dropout words are dead
 
             // ---- the next pair's share of this trip: statistics of four queries, the Q / dO rows and dropout words of this trip's slot
             //      (trip 0: also the K tile; trip 7: this wave's V rows; both IN FRONT of the statistics loads, so that one count serves
-            //      every trip).  Issue order per trip: [4 loads | 4 DMA] | 3 loads | DMA, words | store.
+            //      every trip).  Issue order per trip: dQ store | [4 loads | 4 DMA] | 3 loads | DMA, words.
             //      ONE wait statement carries the loaded registers: with a second one in the other arm of an if / else, hipcc merged the
             //      arms by COPYING the loaded registers in front of one arm's wait -- stale statistics in a few pairs per thousand
             //      (tools/check_asm_loads.py scans for that pattern).
-            if (t >= 1) {
+            if constexpr (!(ABL & 4)) dq_tile(t);
+            if constexpr (!(ABL & 32)) {
+            if (!(ABL & 128) && t >= 1) {  // 128: no wait for / use of the statistics loads
                 WAIT_S(YOUNGER);
                 consume_stats(pb ^ 1);
             }
             if (t == 7) issue_v(nxt);
-            if (t == 0) issue_k(nxt);
-            issue_stats(nxt, t);
-            issue_qd(nxt, t);
-            issue_mask(nxt, t);
-            // ---- dQ^T tile (head-dim block dtw, queries qc + 16 jqw ..) = K^T . dS^T over all 256 keys
-            {
-                const unsigned xr = xr0 + (t & 1) * XSZ;
-                Frag xb[8];
-                f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-#define X_RD(J_) xb[J_].h[0] = tr_rd<(J_) * 32 * XP>(xr); xb[J_].h[1] = tr_rd<(J_) * 32 * XP + 16 * XP>(xr)
-                X_RD(0); X_RD(1); X_RD(2); X_RD(3);
-                asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
-                             : "+v"(xb[0].h[0]), "+v"(xb[0].h[1]), "+v"(xb[1].h[0]), "+v"(xb[1].h[1]), "+v"(xb[2].h[0]), "+v"(xb[2].h[1]),
-                               "+v"(xb[3].h[0]), "+v"(xb[3].h[1]));
-                X_RD(4); X_RD(5); X_RD(6); X_RD(7);
-                f32x4 dq1 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains of four: a dependent MFMA waits for its predecessor's result
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[0].v, xb[0].v, dq, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[1].v, xb[1].v, dq1, 0, 0, 0);
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[2].v, xb[2].v, dq, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[3].v, xb[3].v, dq1, 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
-                             : "+v"(xb[4].h[0]), "+v"(xb[4].h[1]), "+v"(xb[5].h[0]), "+v"(xb[5].h[1]), "+v"(xb[6].h[0]), "+v"(xb[6].h[1]),
-                               "+v"(xb[7].h[0]), "+v"(xb[7].h[1]));
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[4].v, xb[4].v, dq, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[5].v, xb[5].v, dq1, 0, 0, 0);
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[6].v, xb[6].v, dq, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[7].v, xb[7].v, dq1, 0, 0, 0);
-#undef X_RD
-                u32x2 w;
-                w[0] = pack_bf16x2((dq[0] + dq1[0]) * scale, (dq[1] + dq1[1]) * scale);
-                w[1] = pack_bf16x2((dq[2] + dq1[2]) * scale, (dq[3] + dq1[3]) * scale);
-                char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + qc + 16 * jqw) * ld_dqkv + h * DH + 16 * dtw) * 2;
-                *reinterpret_cast<u32x2*>(ob + out_off) = w;  // 1 store
+            if (!(ABL & 256) && t == 0) issue_k(nxt);  // 256: no LDS-DMA
+            if constexpr (!(ABL & 512)) issue_stats(nxt, t);  // 512: no statistics loads
+            if constexpr (!(ABL & 256)) {
+                issue_qd(nxt, t);
+                issue_mask(nxt, t);
+            }
             }
         }
         // ---- end of the pair: the statistics of trip 7, then dK and dV of this wave's keys
-        WAIT_S(YOUNGER);
-        consume_stats(pb ^ 1);
+#undef X_RD
+        if constexpr (!(ABL & (32 | 128))) {
+            WAIT_S(YOUNGER - 1);  // no dQ store behind the fetches of trip 7
+            consume_stats(pb ^ 1);
+        }
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {  // 16 stores
             char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + r0 + 16 * jk) * ld_dqkv + h * DH) * 2;

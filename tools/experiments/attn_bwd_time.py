@@ -1,26 +1,31 @@
-"""Times the two attention-backward kernels on the DiT-L training shape (B x 16 heads, 256 tokens, dh 64, no dropout)."""
-import os, sys, torch
+"""Time the attention backward (DiT geometry, dropout words) through the engine-internal entry point: B x H pairs, median of N launches."""
+import ctypes as C, os, sys, statistics, torch
 sys.path.insert(0, os.getcwd())
 from bsi_amd import _native as N
 lib = N.lib()
-B, T, H, dh = int(os.environ.get("B", "512")), 256, 16, 64
+class DropCfg(C.Structure):
+    _fields_ = [("thr", C.c_uint), ("s0", C.c_uint), ("s1", C.c_uint), ("scale", C.c_float)]
+bwd = getattr(lib, "_Z22bsi_attention_bwd_dropPKviS0_S0_iPKfiiiiPvi7DropCfgS3_S0_")
+bwd.restype = C.c_int
+bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, DropCfg, C.c_void_p, C.c_void_p]
+B, T, H, dh = int(os.environ.get("B", "512")), 256, int(os.environ.get("H", "16")), 64
 d = H * dh
+torch.manual_seed(0)
 qkv = torch.randn((B, T, 3 * d), device="cuda").to(torch.bfloat16)
+out = torch.randn((B, T, d), device="cuda").to(torch.bfloat16)
 dout = torch.randn((B, T, d), device="cuda").to(torch.bfloat16)
-out = torch.empty((B, T, d), device="cuda", dtype=torch.bfloat16)
-lse = torch.empty((B, H, T), device="cuda")
-dqkv = torch.empty((B, T, 3 * d), device="cuda", dtype=torch.bfloat16)
-N.check(lib.bsi_attention_fwd_lse(N.ptr(qkv), 3 * d, B, T, H, dh, N.ptr(out), d, N.ptr(lse), N.stream()))
-res = {}
-for name, fn in (("resident", lib.bsi_attention_bwd), ("stream", lib.bsi_attention_bwd_long)):
-    for _ in range(2):
-        N.check(fn(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, N.stream()))
+lse = torch.randn((B, H, T), device="cuda") + 6.0
+mw = torch.randint(0, 256, (B * H * 8192,), dtype=torch.uint8, device="cuda")
+dqkv = torch.zeros((B, T, 3 * d), device="cuda", dtype=torch.bfloat16)
+drop = int(os.environ.get("DROP", "1"))
+dc = DropCfg(429496729 if drop else 0, 1, 2, 1.0 / 0.9)
+def go():
+    N.check(bwd(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, dc, N.stream(), N.ptr(mw) if drop else None))
+for _ in range(3): go()
+torch.cuda.synchronize()
+ts = []
+for _ in range(int(os.environ.get("N", "12"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        N.check(fn(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, N.stream()))
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    res[name] = dqkv.float().clone()
-    print(f"{name:9s} {ms*1e3:8.1f} us   {14*B*H*T*T*dh/ms/1e9:.0f} TF (7 products)")
-print("max diff", float((res["resident"] - res["stream"]).abs().max()))
+    e0.record(); go(); e1.record(); e1.synchronize()
+    ts.append(1e3 * e0.elapsed_time(e1))
+print(f"{os.environ.get('TAG', '')} B={B} H={H} drop={drop}: median {statistics.median(ts):.1f} us  min {min(ts):.1f}")

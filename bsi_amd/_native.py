@@ -194,6 +194,8 @@ _PROTOS = {
                               _vp, _vp, _vp, _vp, _f, C.c_ulonglong, _vp]),
     "bsi_dropout_mask": (_i, [_f, C.c_ulonglong, C.c_uint, C.c_uint, C.c_uint, _vp, _vp]),
     "bsi_attention_dropout_words": (_i, [_f, C.c_ulonglong, C.c_uint, _i, _vp, _vp]),
+    "bsi_attention_fwd_dropout": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
+    "bsi_attention_bwd_dropout": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "bsi_dit_backward_set_events": (_i, [_vp, _i]),
     "bsi_sqnorm_workspace_bytes": (_sz, []),
     "bsi_grad_sqnorm": (_i, [_vp, _sz, _vp, _vp, _vp]),

@@ -353,3 +353,19 @@ int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int 
     return attention_fwd_impl(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, dc, stream,
                               bsi_attention_uses_mask_words(tokens, dh) ? maskw : nullptr, mask_ready);
 }
+
+// Training attention with the counter-based dropout of the DiT blocks as entry points of their own (the engine calls the two
+// functions above): words = NULL, or the 8 KB per (image, head) of lane-mask words (256 tokens, head dim 64) that the forward writes and
+// the backward reads -- what bsi_dit_train_forward / bsi_dit_backward keep on their tape.
+extern "C" int bsi_attention_fwd_dropout(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out, float* lse,
+                                         float p, unsigned long long seed, unsigned site, void* words, bsi_stream_t stream) {
+    BSI_CHECK_ARG(p >= 0.f && p < 1.f, "bsi_attention_fwd_dropout: dropout probability %g outside [0, 1)", (double)p);
+    BSI_CHECK_ARG(lse, "bsi_attention_fwd_dropout: the log-sum-exp output is required (the backward reads it)");
+    return bsi_attention_fwd_train(qkv, ld_qkv, B, tokens, heads, dh, out, ld_out, lse, make_drop(p, seed, site), stream, words, false);
+}
+extern "C" int bsi_attention_bwd_dropout(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
+                                         int tokens, int heads, int dh, void* dqkv, int ld_dqkv, float p, unsigned long long seed, unsigned site,
+                                         const void* words, bsi_stream_t stream) {
+    BSI_CHECK_ARG(p >= 0.f && p < 1.f, "bsi_attention_bwd_dropout: dropout probability %g outside [0, 1)", (double)p);
+    return bsi_attention_bwd_drop(qkv, ld_qkv, out, dout, ld_o, lse, B, tokens, heads, dh, dqkv, ld_dqkv, make_drop(p, seed, site), stream, words);
+}

@@ -604,6 +604,15 @@ int bsi_dropout_mask(float p, unsigned long long seed, unsigned site, unsigned r
 /* The same mask of an attention site (rows = pairs * 256, cols = 256) as the lane-mask words the 256-token attention kernels consume:
  * words[pair][qb 0..15][kt 0..15][r 0..3] (64 bit each), bit 16 g + c = keep(query 16 qb + c, key 16 kt + 4 g + r); 8 KB per pair. */
 int bsi_attention_dropout_words(float p, unsigned long long seed, unsigned site, int pairs, void* words, bsi_stream_t stream);
+/* dit.py:43-44 in training: F.scaled_dot_product_attention(q, k, v, dropout_p = p) and its autograd, with the mask above (row =
+ * (b * heads + h) * tokens + query, col = key).  words: NULL (both sides evaluate the hash), or -- 256 tokens, head dim 64 only -- a
+ * buffer of 8 KB per (image, head) that the forward FILLS with the lane-mask words and the backward READS (what the training engine
+ * keeps on its tape); pass the same value to both.  lse as bsi_attention_fwd_lse.  p = 0 is plain attention. */
+int bsi_attention_fwd_dropout(const void* qkv, int ld_qkv, int B, int tokens, int heads, int dh, void* out, int ld_out, float* lse,
+                              float p, unsigned long long seed, unsigned site, void* words, bsi_stream_t stream);
+int bsi_attention_bwd_dropout(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
+                              int tokens, int heads, int dh, void* dqkv, int ld_dqkv, float p, unsigned long long seed, unsigned site,
+                              const void* words, bsi_stream_t stream);
 /* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
  * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that
  * block's gradient all-reduce on another stream while the backward continues.  Pass NULL to clear. */

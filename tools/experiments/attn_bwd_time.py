@@ -1,13 +1,8 @@
-"""Time the attention backward (DiT geometry, dropout words) through the engine-internal entry point: B x H pairs, median of N launches."""
+"""Time the attention backward (DiT geometry, dropout words) through bsi_attention_bwd_dropout: B x H pairs, median of N launches."""
 import ctypes as C, os, sys, statistics, torch
 sys.path.insert(0, os.getcwd())
 from bsi_amd import _native as N
 lib = N.lib()
-class DropCfg(C.Structure):
-    _fields_ = [("thr", C.c_uint), ("s0", C.c_uint), ("s1", C.c_uint), ("scale", C.c_float)]
-bwd = getattr(lib, "_Z22bsi_attention_bwd_dropPKviS0_S0_iPKfiiiiPvi7DropCfgS3_S0_")
-bwd.restype = C.c_int
-bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, DropCfg, C.c_void_p, C.c_void_p]
 B, T, H, dh = int(os.environ.get("B", "512")), 256, int(os.environ.get("H", "16")), 64
 d = H * dh
 torch.manual_seed(0)
@@ -18,9 +13,9 @@ lse = torch.randn((B, H, T), device="cuda") + 6.0
 mw = torch.randint(0, 256, (B * H * 8192,), dtype=torch.uint8, device="cuda")
 dqkv = torch.zeros((B, T, 3 * d), device="cuda", dtype=torch.bfloat16)
 drop = int(os.environ.get("DROP", "1"))
-dc = DropCfg(429496729 if drop else 0, 1, 2, 1.0 / 0.9)
 def go():
-    N.check(bwd(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, dc, N.stream(), N.ptr(mw) if drop else None))
+    N.check(lib.bsi_attention_bwd_dropout(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d,
+                                          0.1 if drop else 0.0, 1234, 0, N.ptr(mw) if drop else None, N.stream()))
 for _ in range(3): go()
 torch.cuda.synchronize()
 ts = []

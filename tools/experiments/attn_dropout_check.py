@@ -1,18 +1,10 @@
 """Isolated check of the attention forward / backward with dropout on the DiT geometry (256 tokens, dh 64): the persistent
 kernels fed with mask words against the chunked / resident kernels that evaluate the hash themselves, and against a torch
-restatement using bsi_dropout_mask.  Calls the engine-internal C++ entry points by their mangled names."""
+restatement using bsi_dropout_mask.  Through bsi_attention_fwd_dropout / bsi_attention_bwd_dropout."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from bsi_amd import _native as N
 lib = N.lib()
-class DropCfg(C.Structure):
-    _fields_ = [("thr", C.c_uint), ("s0", C.c_uint), ("s1", C.c_uint), ("scale", C.c_float)]
-fwd = getattr(lib, "_Z23bsi_attention_fwd_trainPKviiiiiPviPf7DropCfgS1_S1_b")
-fwd.restype = C.c_int
-fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, DropCfg, C.c_void_p, C.c_void_p, C.c_bool]
-bwd = getattr(lib, "_Z22bsi_attention_bwd_dropPKviS0_S0_iPKfiiiiPvi7DropCfgS3_S0_")
-bwd.restype = C.c_int
-bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, DropCfg, C.c_void_p, C.c_void_p]
 B, T, H, dh = int(os.environ.get("B", "4")), 256, int(os.environ.get("H", "2")), 64
 d = H * dh
 p = float(os.environ.get("P", "0.3"))
@@ -25,22 +17,15 @@ keep = torch.empty(B * H * T * T, dtype=torch.uint8, device="cuda")
 N.check(lib.bsi_dropout_mask(p, seed, site, B * H * T, T, N.ptr(keep), N.stream()))
 keep = keep.reshape(B, H, T, T).float()
 print("keep rate", float(keep.mean()))
-# rebuild make_drop in python (common.h)
-def mix32(x):
-    x &= 0xffffffff; x ^= x >> 16; x = (x * 0x7feb352d) & 0xffffffff; x ^= x >> 15; x = (x * 0x846ca68b) & 0xffffffff; x ^= x >> 16; return x
-s = (seed + 0x9E3779B97F4A7C15 * (site + 1)) & 0xffffffffffffffff
-t = p * 4294967296.0 + 32768.0
-thr = 4294967295 if t >= 4294967295.0 else int(t)
-thr = max(thr, 65536)
-if (thr >> 16) > 65535: thr = 65535 << 16
-dc = DropCfg(thr, mix32(s & 0xffffffff), mix32(((s >> 32) ^ 0x85ebca6b) & 0xffffffff), 65536.0 / (65536 - (thr >> 16)))
+scale = 65536.0 / (65536 - round(p * 65536))
 def run(words):
     out = torch.zeros((B, T, d), device="cuda", dtype=torch.bfloat16)
     lse = torch.zeros((B, H, T), device="cuda")
     dqkv = torch.zeros((B, T, 3 * d), device="cuda", dtype=torch.bfloat16)
     mw = torch.zeros(B * H * 8192, dtype=torch.uint8, device="cuda") if words else None
-    N.check(fwd(N.ptr(qkv), 3 * d, B, T, H, dh, N.ptr(out), d, N.ptr(lse), dc, N.stream(), N.ptr(mw) if words else None, False))
-    N.check(bwd(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, dc, N.stream(), N.ptr(mw) if words else None))
+    N.check(lib.bsi_attention_fwd_dropout(N.ptr(qkv), 3 * d, B, T, H, dh, N.ptr(out), d, N.ptr(lse), p, seed, site, N.ptr(mw) if words else None, N.stream()))
+    N.check(lib.bsi_attention_bwd_dropout(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, T, H, dh, N.ptr(dqkv), 3 * d, p, seed, site,
+                                          N.ptr(mw) if words else None, N.stream()))
     torch.cuda.synchronize()
     return out.float(), lse, dqkv.float(), mw
 o1, l1, g1, mw = run(True)
@@ -70,7 +55,7 @@ print("mask words == bsi_dropout_mask:", bool((m == keep.cpu()).all()), "mismatc
 # torch restatement
 q, k, v = [x.float().reshape(B, T, H, dh).transpose(1, 2) for x in qkv.split(d, dim=-1)]
 q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
-P = torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) * keep * dc.scale
+P = torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) * keep * scale
 o = (P @ v).transpose(1, 2).reshape(B, T, d)
 o.backward(dout.float())
 gref = torch.cat([x.grad.transpose(1, 2).reshape(B, T, d) for x in (q, k, v)], -1)

@@ -1277,6 +1277,54 @@ def test_groupnorm_backward(N, B, HW, C1, C2, silu):
     assert rel_linf(dg - 1, gad.grad) < 2e-5 and rel_linf(db - 1, bed.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,C1,C2,silu", [(3, 128, 0, 1), (2, 128, 128, 1), (2, 128, 128, 0)])
+def test_groupnorm_backward_with_saved_statistics(N, B, C1, C2, silu):
+    """bsi_groupnorm_bwd_cast_nhwc on 32 x 32 images with the forward's (mean, rstd) -- the form the training engine calls -- against
+    fp64 autograd AND against bsi_groupnorm_bwd_nhwc (statistics recomputed) on the same inputs; the bf16 copy of the x1 gradient is
+    the rounded fp32 one."""
+    from oracle.unet_oracle import group_norm
+    HW, side = 1024, 32
+    gen = torch.Generator().manual_seed(B + C1 + C2 + silu)
+    Cc = C1 + C2
+    x1 = torch.randn((B, HW, C1), generator=gen) * 2 + 0.5
+    x2 = torch.randn((B, HW, C2), generator=gen) if C2 else None
+    ga, be = torch.randn(Cc, generator=gen), torch.randn(Cc, generator=gen)
+    da = bf16r(torch.randn((B, HW, Cc), generator=gen))
+    add = torch.randn((B, HW, Cc), generator=gen)
+    add_b = torch.randn((B, HW, C1), generator=gen)
+    xcat = torch.cat([x1, x2], 2) if C2 else x1
+    xc = xcat.double().requires_grad_(True)
+    gad, bed = ga.double().requires_grad_(True), be.double().requires_grad_(True)
+    y = group_norm(xc.permute(0, 2, 1).reshape(B, Cc, side, side), 32, gad, bed)
+    if silu:
+        y = do.silu(y)
+    y.backward(da.double().permute(0, 2, 1).reshape(B, Cc, side, side))
+    want = xc.grad + add.double()
+    want[:, :, :C1] += add_b.double()
+    xg = xcat.reshape(B, HW, 32, Cc // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)   # [image, group, elements], fp32 as the forward sees them
+    mean = xg.mean(dim=2)
+    rstd = 1.0 / torch.sqrt(((xg - mean[:, :, None]) ** 2).mean(dim=2) + 1e-5)
+    stats = dev(torch.stack((mean, rstd), dim=2).contiguous())
+    dda, dx1, dx2 = dev(da.to(torch.bfloat16)), dev(x1), (dev(x2) if C2 else None)
+    dga, dbe, dadd, daddb = dev(ga), dev(be), dev(add), dev(add_b)
+
+    def run(fn, extra):
+        out1, out2 = empty(B, HW, C1), (empty(B, HW, C2) if C2 else None)
+        dg, db = torch.ones(Cc, device=DEV), torch.ones(Cc, device=DEV)  # accumulated on top of existing values
+        N.check(fn(N.ptr(dda), N.ptr(dx1), C1, N.ptr(dx2) if C2 else None, C2, B, HW, N.ptr(dga), N.ptr(dbe), 1e-5, silu, N.ptr(dadd),
+                   N.ptr(daddb), N.ptr(out1), N.ptr(out2) if C2 else None, N.ptr(dg), N.ptr(db), *extra, N.stream()))
+        return out1, out2, dg, db
+    obf = empty(B, HW, C1, dtype=torch.bfloat16)
+    o1, o2, dg, db = run(N.lib().bsi_groupnorm_bwd_cast_nhwc, (N.ptr(obf), N.ptr(stats)))
+    r1, r2, rg, rb = run(N.lib().bsi_groupnorm_bwd_nhwc, ())
+    assert rel_linf(o1, want[:, :, :C1]) < 2e-5, rel_linf(o1, want[:, :, :C1])
+    assert rel_linf(o1, r1.cpu().double()) < 5e-6
+    if C2:
+        assert rel_linf(o2, want[:, :, C1:]) < 2e-5 and rel_linf(o2, r2.cpu().double()) < 5e-6
+    assert rel_linf(dg - 1, gad.grad) < 2e-5 and rel_linf(db - 1, bed.grad) < 2e-5
+    assert torch.equal(obf.view(torch.int16), o1.to(torch.bfloat16).view(torch.int16))
+
+
 @pytest.mark.parametrize("B,HW,Nc,p", [(3, 64, 64, 0.0), (2, 1024, 128, 0.1)])
 def test_film_silu_dropout_forward_backward(N, B, HW, Nc, p):
     gen = torch.Generator().manual_seed(B + HW + Nc)

@@ -63,6 +63,16 @@ for k, cs in res.items():
     print(k, {c: round(v["mean"], 3) for c, v in cs.items()})
 PY
 rm -rf $O/pmc_*/
+# attention backward: the single-sweep kernel against the two-pass one, with and without dropout (512 images x 16 heads)
+for rep in 1 2; do
+  TAG="single sweep" python tools/experiments/attn_bwd_time.py | grep median
+  TAG="single sweep, no dropout" DROP=0 python tools/experiments/attn_bwd_time.py | grep median
+  BSI_ATTN_BWD_TWO_PASS=1 TAG="two passes" python tools/experiments/attn_bwd_time.py | grep median
+  BSI_ATTN_BWD_TWO_PASS=1 TAG="two passes, no dropout" DROP=0 python tools/experiments/attn_bwd_time.py | grep median
+done > $O/attn_bwd_single_sweep_ab.txt 2>&1
+# CU sharing rehearsal on the final tree
+STEPS=4 ROUNDS=2 timeout 900 python tools/experiments/squat_ab.py 256 > $O/cu_reserve_squatter_ab_b256.txt 2>&1
+STEPS=4 ROUNDS=2 timeout 600 python tools/experiments/squat_ab.py 64 > $O/cu_reserve_squatter_ab_b64.txt 2>&1
 # the GPU suite on the final tree: tail with every BOUND / PARITY line
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -80 > $O/gpu_suite_summary.txt; tail -3 $O/gpu_suite_summary.txt
 cp gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null

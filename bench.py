@@ -595,7 +595,13 @@ def main():
         if world == 1 and not a.no_secondary:
             line["secondary"] = secondary_in_child(a)
         if not a.no_cpu_baseline and world == 1:
+            t_cpu = time.perf_counter()
             line["cpu_baseline"] = cpu_baseline(a.k)
+            line["cpu_baseline"]["wall_seconds_gpu_idle"] = time.perf_counter() - t_cpu
+        # what an outside clock sees around this process: the GPU idles while the model is built, while the CPU baseline runs
+        # (wall_seconds_gpu_idle above) and while the secondary child starts; `value` is timed between barriers around the calls only
+        line["wall_note"] = ("value / ms_per_step are timed around the sampling calls; model construction, the CPU baseline "
+                             "(cpu_baseline.wall_seconds_gpu_idle) and process start-up of the secondary child run with the GPU idle")
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

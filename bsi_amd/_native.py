@@ -27,6 +27,11 @@ class GemmArgs(C.Structure):
                 ("tokens", C.c_int), ("pos", C.c_void_p), ("aux", C.c_void_p), ("out2", C.c_void_p), ("colsum_rows", C.c_void_p)]
 
 
+class CastDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                ("ld_t", C.c_int), ("tile0", C.c_int), ("reserved", C.c_int)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("out", C.c_void_p)]
 
@@ -184,6 +189,8 @@ _PROTOS = {
     "bsi_ln_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "bsi_silu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "bsi_cast_transpose_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "bsi_cast_batch_tiles": (_i, [_i, _i, _i]),
+    "bsi_cast_batch_bf16": (_i, [_vp, _i, _i, _vp]),
     "bsi_cast_rows_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "bsi_silu_bf16": (_i, [_vp, _sz, _vp, _vp]),
     "bsi_dit_tape_bytes": (_sz, [C.POINTER(DitConfig), _i]),

@@ -627,9 +627,80 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, int rows, in
     }
 }
 
+// Every bf16 shadow of a model's fp32 weight matrices in ONE launch (round 4; before: one 8-us launch per matrix and layout, 265 per
+// DiT-L optimizer step): a workgroup takes a 64 x 64 tile of one matrix, reads it once (coalesced 256-B rows) and writes the row-major
+// shadow (columns cols .. ld-1 zero) and / or the transposed one (through LDS, 128-B rows on both sides).
+constexpr int CB_T = 64;
+__global__ __launch_bounds__(256) void cast_batch_kernel(const bsi_cast_desc* __restrict__ descs, int n) {
+    __shared__ float tile[CB_T][CB_T + 1];
+    int lo = 0, hi = n - 1;  // last descriptor whose first tile is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const bsi_cast_desc d = descs[lo];
+    const int t = blockIdx.x - d.tile0;
+    const int ldmax = d.dst && d.ld > d.cols ? d.ld : d.cols;  // the row-major shadow may be padded (zero columns)
+    const int tcols = (ldmax + CB_T - 1) / CB_T;
+    const int r0 = (t / tcols) * CB_T, c0 = (t % tcols) * CB_T;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 quads of columns x 16 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < d.rows) {
+            if (c + 3 < d.cols && (d.cols & 3) == 0) v = *reinterpret_cast<const f32x4*>(d.src + (size_t)r * d.cols + c);
+            else
+                for (int e = 0; e < 4; ++e) v[e] = c + e < d.cols ? d.src[(size_t)r * d.cols + c + e] : 0.f;
+            if (d.dst) {
+                __bf16* o = reinterpret_cast<__bf16*>(d.dst) + (size_t)r * d.ld + c;
+                if (c + 3 < d.ld && (d.ld & 3) == 0) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(v[0], v[1]);
+                    w[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(o) = w;
+                } else {
+                    for (int e = 0; e < 4 && c + e < d.ld; ++e) o[e] = (__bf16)v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ty + 16 * k][4 * tx + e] = v[e];
+    }
+    if (!d.dst_t) return;  // wave-uniform
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 16 * k, r = r0 + 4 * tx;  // out_t[c][r .. r + 3]
+        if (c >= d.cols || r >= d.rows) continue;
+        __bf16* o = reinterpret_cast<__bf16*>(d.dst_t) + (size_t)c * d.ld_t + r;
+        if (r + 3 < d.rows && (d.ld_t & 3) == 0) {
+            u32x2 w;
+            w[0] = pack_bf16x2(tile[4 * tx][ty + 16 * k], tile[4 * tx + 1][ty + 16 * k]);
+            w[1] = pack_bf16x2(tile[4 * tx + 2][ty + 16 * k], tile[4 * tx + 3][ty + 16 * k]);
+            *reinterpret_cast<u32x2*>(o) = w;
+        } else {
+            for (int e = 0; e < 4 && r + e < d.rows; ++e) o[e] = (__bf16)tile[4 * tx + e][ty + 16 * k];
+        }
+    }
+}
+
 }  // namespace
 
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int bsi_cast_batch_tiles(int rows, int cols, int ld) {  // tiles of one descriptor (host helper for tile0)
+    const int ldmax = ld > cols ? ld : cols;
+    return ((rows + CB_T - 1) / CB_T) * ((ldmax + CB_T - 1) / CB_T);
+}
+
+extern "C" int bsi_cast_batch_bf16(const bsi_cast_desc* descs, int n, int tiles, bsi_stream_t stream) {
+    BSI_CHECK_ARG(descs && n > 0 && tiles > 0, "bsi_cast_batch_bf16: descriptor table (device), n=%d, tiles=%d", n, tiles);
+    hipLaunchKernelGGL(cast_batch_kernel, dim3(tiles), dim3(256), 0, S(stream), descs, n);
+    BSI_CHECK_LAUNCH("bsi_cast_batch_bf16");
+    return BSI_OK;
+}
 
 extern "C" int bsi_gate_bwd(const float* dX, const void* delta, float* x, const float* gate, int gate_stride, float* dgate,
                             int dgate_stride, int M, int d, int tokens, void* ddelta, bsi_stream_t stream) {

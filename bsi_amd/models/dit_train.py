@@ -19,21 +19,25 @@ _BLOCK_PARAMS = (("attn.to_qkv.weight", "qkv_w"), ("attn.to_qkv.bias", "qkv_b"),
 
 
 def transposed_pack(model):
-    """bf16 W^T shadows ([in][out]) of the block weights, cached per parameter version like `native_pack`."""
+    """bf16 W^T shadows ([in][out]) of the block weights for the input-gradient GEMMs: persistent buffers that join the model's
+    cast plan (`DenoisingDiT.native_pack`) on first use, after which ONE launch per parameter version refreshes both layouts."""
     key = model._weights_key()
     if getattr(model, "_pack_t", None) is not None and model._pack_t_key == key:
         return model._pack_t
-    lib = N.lib()
-    cfg, _, _, _ = model.native_pack()
+    cfg, _, _, _ = model.native_pack()  # builds / refreshes the plan; if it already carries the transposes, they are current now
+    if model._pack_t is not None and model._pack_t_key == key:
+        return model._pack_t
+    plan = model._plan
     dev = model.dit.patch_encoder.weight.device
     keep = []
+    by_src = {d[0].data_ptr(): d for d in plan["descs"]}
 
     def shadow_t(w: Tensor):
-        w = w.detach().contiguous()
+        d = by_src[w.detach().data_ptr()]
         rows, cols = w.shape
         out = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev)
-        N.check(lib.bsi_cast_transpose_bf16(N.ptr(w), rows, cols, N.ptr(out), rows, N.stream()))
         keep.append(out)
+        d[2], d[6] = out, rows
         return out.data_ptr()
 
     blocks = (N.DitBlockWeightsT * cfg.depth)()
@@ -46,8 +50,12 @@ def transposed_pack(model):
         b.ada2_wT = shadow_t(blk.adaLN_modulation[2].weight)
     wt = N.DitWeightsT()
     wt.blocks = C.cast(blocks, C.POINTER(N.DitBlockWeightsT))
-    model._pack_t = (wt, blocks, keep)
-    model._pack_t_key = key
+    plan["pack_t"] = (wt, blocks, keep)
+    model._finish_table(plan)
+    table, n, tiles = plan["table"]
+    with torch.no_grad():
+        N.check(N.lib().bsi_cast_batch_bf16(N.ptr(table), n, tiles, N.stream()))  # first time: fills the transposes (and re-casts the rest)
+    model._pack_t, model._pack_t_key = plan["pack_t"], key
     return model._pack_t
 
 

@@ -412,6 +412,13 @@ int bsi_conv_weight_pack_t(const float* w, int Cout, int Cin, int taps, int ld, 
 /* Both re-arrangements for many convolutions in ONE launch (a train step re-packs every convolution weight after the optimizer
  * update).  descs: n descriptors in DEVICE memory; transposed = 0: bsi_conv_weight_pack(w, Cout, Cin, taps, cin_pad, ld, col0, out),
  * transposed = 1: bsi_conv_weight_pack_t(w, Cout, Cin, taps, ld, out) (cin_pad, col0 ignored). */
+/* All bf16 shadows of a model's fp32 weight matrices in one launch: for descriptor i, dst (or NULL) = row-major [rows][ld] (columns
+ * cols .. ld-1 zero: the padded patch-encoder weight), dst_t (or NULL) = the transpose [cols][ld_t] (ld_t >= rows).  descs is a DEVICE
+ * array; tile0 = the sum of bsi_cast_batch_tiles(rows, cols, dst ? ld : cols) over the descriptors in front, tiles = the total.
+ * Replaces 265 launches of bsi_cast_bf16 / bsi_cast_transpose_bf16 per DiT-L optimizer step. */
+typedef struct bsi_cast_desc { const float* src; void* dst; void* dst_t; int rows, cols, ld, ld_t, tile0, reserved; } bsi_cast_desc;
+int bsi_cast_batch_tiles(int rows, int cols, int ld);
+int bsi_cast_batch_bf16(const bsi_cast_desc* descs /*device*/, int n, int tiles, bsi_stream_t stream);
 typedef struct bsi_conv_pack_desc {
     const float* w;
     void* out;

@@ -882,6 +882,36 @@ def test_fused_ln_gate_backward(N, Bs, tokens, d):
     assert rel_linf(gate.grad, torch.zeros(Bs, d, dtype=torch.float64).index_add_(0, rows, x.grad * delta.double())) < 1e-12
 
 
+def test_cast_batch_writes_every_shadow_in_one_launch(N):
+    """bsi_cast_batch_bf16: row-major (one of them padded with zero columns), transposed and both-at-once shadows of five matrices with
+    ragged shapes in one launch, bit-identical to bsi_cast_bf16 / bsi_cast_transpose_bf16 per matrix."""
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(300, 84, 96, True, False), (64, 64, 64, True, True), (1024, 1024, 1024, True, True), (130, 257, 257, False, True),
+              (7, 5, 8, True, True)]
+    lib = N.lib()
+    srcs, plain, trans, descs, tiles = [], [], [], [], 0
+    for rows, cols, ld, want_p, want_t in shapes:
+        w = dev(torch.randn((rows, cols), generator=gen))
+        o = torch.full((rows, ld), float("nan"), dtype=torch.bfloat16, device=DEV) if want_p else None
+        t = torch.full((cols, rows), float("nan"), dtype=torch.bfloat16, device=DEV) if want_t else None
+        descs.append(N.CastDesc(w.data_ptr(), o.data_ptr() if want_p else None, t.data_ptr() if want_t else None, rows, cols, ld, rows, tiles, 0))
+        tiles += lib.bsi_cast_batch_tiles(rows, cols, ld if want_p else cols)
+        srcs.append(w); plain.append(o); trans.append(t)
+    arr = (N.CastDesc * len(descs))(*descs)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    N.check(lib.bsi_cast_batch_bf16(N.ptr(table), len(descs), tiles, N.stream()))
+    for (rows, cols, ld, want_p, want_t), w, o, t in zip(shapes, srcs, plain, trans):
+        if want_p:
+            ref = torch.empty((rows, ld), dtype=torch.bfloat16, device=DEV)
+            N.check(lib.bsi_cast_bf16(N.ptr(w), rows, cols, N.ptr(ref), ld, N.stream()))
+            assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), (rows, cols)
+            assert float(o[:, cols:].float().abs().sum()) == 0.0
+        if want_t:
+            ref = torch.empty((cols, rows), dtype=torch.bfloat16, device=DEV)
+            N.check(lib.bsi_cast_transpose_bf16(N.ptr(w), rows, cols, N.ptr(ref), rows, N.stream()))
+            assert torch.equal(t.view(torch.int16), ref.view(torch.int16)), (rows, cols)
+
+
 def test_cast_transpose_and_silu_bwd(N):
     gen = torch.Generator().manual_seed(9)
     w = torch.randn((300, 84), generator=gen)

@@ -685,18 +685,26 @@ __global__ __launch_bounds__(512) void attention_bwd_p_kernel(const __bf16* __re
 
 }  // namespace
 
+static bool single_sweep(int tokens, int dh, DropCfg dc, const void* maskw) {
+    static const bool resident_only = getenv("BSI_ATTN_BWD_RESIDENT") != nullptr;  // A/B partner of the persistent kernels
+    static const bool two_pass = getenv("BSI_ATTN_BWD_TWO_PASS") != nullptr;        // A/B partner of the single-sweep kernel (round 4)
+    return tokens == PT && dh == DH && !resident_only && !two_pass &&
+           (!dc.thr || (maskw && bsi_attention_uses_mask_words(tokens, dh)));  // the hash form of the mask stays with the two-pass kernel
+}
+bool bsi_attention_bwd_emits_bias(int tokens, int dh, DropCfg dc, const void* maskw) { return single_sweep(tokens, dh, dc, maskw); }
+
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
                            int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
-                           const void* maskw) {
+                           const void* maskw, float* bias_rows) {
     BSI_CHECK_ARG(qkv && out && dout && lse && dqkv && B > 0 && heads > 0, "bsi_attention_bwd: bad args");
     BSI_CHECK_ARG(dh == 64, "bsi_attention_bwd: head dim %d unsupported (64)", dh);
     BSI_CHECK_ARG(tokens > 0 && tokens % 64 == 0 && tokens <= 256, "bsi_attention_bwd: tokens=%d must be 64..256, multiple of 64", tokens);
     BSI_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 4 == 0, "bsi_attention_bwd: bad leading dimensions");
     static const bool resident_only = getenv("BSI_ATTN_BWD_RESIDENT") != nullptr;  // A/B partner of the persistent kernel
-    static const bool two_pass = getenv("BSI_ATTN_BWD_TWO_PASS") != nullptr;        // A/B partner of the single-sweep kernel (round 4)
-    if (tokens == PT && !resident_only && !two_pass &&
-        (!dc.thr || (maskw && bsi_attention_uses_mask_words(tokens, dh))))  // the hash form of the mask stays with the two-pass kernel
-        return bsi_attention_bwd_exchange(qkv, ld_qkv, out, dout, ld_o, lse, B, heads, dqkv, ld_dqkv, dc, maskw, reinterpret_cast<hipStream_t>(stream));
+    BSI_CHECK_ARG(!bias_rows || single_sweep(tokens, dh, dc, maskw), "bsi_attention_bwd: bias rows are an output of the single-sweep kernel only");
+    if (single_sweep(tokens, dh, dc, maskw))
+        return bsi_attention_bwd_exchange(qkv, ld_qkv, out, dout, ld_o, lse, B, heads, dqkv, ld_dqkv, dc, maskw, reinterpret_cast<hipStream_t>(stream),
+                                          bias_rows);
     if (tokens == PT && !resident_only) {
         const int pairs = B * heads, ncu = compute_cus();
         const int grid = pairs < ncu ? pairs : ncu;

@@ -7,8 +7,8 @@
 // 27-30 issue cycles per score element against 448 MFMAs per wave and pair).  Here a wave owns 32 KEYS and walks the queries
 // 32 at a time (the second pass of that kernel, unchanged arithmetic): P^T and dS^T are the B operands of
 // dV^T = dO^T . P and dK^T = Q^T . dS as they leave the lane, and the packed dS block ALSO goes to an LDS exchange buffer
-// X[key][query] (8 waves x 32 keys x 32 queries of bf16 = 16 KB per trip, row pitch 96 B: the 8 rows an LDS cycle of a
-// transposed read touches start in 8 disjoint 8-bank windows).  Behind the trip's barrier wave w forms ONE 16 x 16 tile of
+// X[key][query] (8 waves x 32 keys x 32 queries of bf16 = 16 KB per trip; the two 32-B halves of a row swap places every four rows, so
+// that the 8 rows an LDS cycle of a transposed read touches fall into 8 disjoint 8-bank windows).  Behind the trip's barrier wave w forms ONE 16 x 16 tile of
 // dQ^T = K^T . dS^T for those 32 queries -- head-dim block w & 3, query block w >> 2 -- over all 256 keys: eight MFMAs whose A
 // operands (its K^T rows, 32 registers) were read once per pair and whose B operands are transposed reads of X.  No score element
 // is formed twice, nothing is summed across waves, no atomics: deterministic.
@@ -27,13 +27,14 @@
 namespace {
 
 constexpr int DH = 64, RB = 128, PT = 256;
-constexpr int XP = 96, XSZ = PT * XP;                 // exchange buffer: row pitch, bytes per buffer (24 KB)
+constexpr int XP = 64, XSZ = PT * XP;                 // exchange buffer: 32 queries of bf16 per key row, 16 KB per buffer (layout below)
 constexpr int QL = 0, DL = PT * RB, KL = 2 * PT * RB; // Q and dO first: 16-bit ds offsets
 constexpr int XL = 3 * PT * RB;                       // X[2]
 constexpr int ST = XL + 2 * XSZ;                      // lse_s[2][PT], dlt_s[2][PT]
 constexpr int MK = ST + 4 * PT * 4;                   // dropout words of the current pair (8 KB, refilled rolling)
 constexpr int MK_BYTES = 8192;
-constexpr int LDS_BYTES = MK + MK_BYTES;              // 159744
+constexpr int BP = MK + MK_BYTES;                     // bias partials of the pair: [8 waves][192] floats (dQ 64 | dK 64 | dV 64)
+constexpr int LDS_BYTES = BP + 8 * 192 * 4;           // 149504
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 #ifndef ATTN_ABL
 #define ATTN_ABL 0  // timing ablations of tools/experiments/attn_bwd_ablate.sh (wrong results): 1 softmax, 2 dV / dK, 4 dQ, 8 barrier, 16 S / dP, 32 next-pair fetches, 64 X write
@@ -57,9 +58,13 @@ template <int DROP>
 __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __restrict__ qkv, int ld_qkv, const __bf16* __restrict__ o,
                                                               const __bf16* __restrict__ dout, int ld_o, const float* __restrict__ lse,
                                                               int pairs, int heads, __bf16* __restrict__ dqkv, int ld_dqkv, float scale,
-                                                              DropCfg dc, const char* __restrict__ maskw) {
+                                                              DropCfg dc, const char* __restrict__ maskw, float* __restrict__ bias_rows) {
+    // bias_rows (or null): [B][3 * heads * 64] fp32, row b = the column sums of image b's dqkv rows (bf16 values as stored) -- the
+    // per-image slabs of the qkv bias gradient, added over the images by bsi_colsum_rows_f32 (the weight-gradient GEMM then runs
+    // without its bias rider: 884 -> 788 us).  Per pair: a DPP row sum per accumulator register, 192 floats per wave through LDS.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lse_s = reinterpret_cast<float*>(lds + ST);
+    float* bp_s = reinterpret_cast<float*>(lds + BP);
     float* dlt_s = lse_s + 2 * PT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -176,8 +181,13 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) tq[dt] = lds_u32(lds) + (4 * g + qp) * RB + ((dt ^ swh) << 5) + (pp >> 1) * 16 + 8 * (pp & 1);
     const unsigned tkw = lds_u32(lds) + KL + (4 * g + qp) * RB + ((dtw ^ swh) << 5) + (pp >> 1) * 16 + 8 * (pp & 1);  // K^T rows of this wave's dQ^T tile
-    const unsigned xr0 = lds_u32(lds) + XL + (4 * g + qp) * XP + jqw * 32 + pp * 8;  // X as B operand: key rows, this wave's query block
-    char* const xw0 = lds + XL + (r0 + c16) * XP + g * 8;                              // X as written: this lane's key, queries 4 g ..
+    // X[key][32 queries]: a row is two 32-B halves (query blocks 0 and 1), stored at half ^ ((key >> 2) & 1).  A transposed read covers
+    // 8 consecutive key rows per LDS cycle (16-lane groups g = 0, 1), 32 B of one query block each: rows 0-3 take one half of four 64-B
+    // slots, rows 4-7 the other half of the same slots -- conflict free without padding (a padded pitch of 96 B measured 25 M conflict
+    // cycles per launch from the two-address stores); a store instruction fills whole rows.
+    const unsigned xr0 = lds_u32(lds) + XL + (4 * g + qp) * XP + ((jqw ^ (g & 1)) << 5) + pp * 8;  // as B operand: key rows 4 g + qp, this wave's query block
+    char* const xw0 = lds + XL + (r0 + c16) * XP + g * 8;                                             // as written: this lane's key, queries 4 g ..
+    const bool xswap = (c16 >> 2) & 1;  // this lane's key rows store query block 1 in the first half
     union Frag { bf16x8 v; s16x4 h[2]; u32x4 u; };
     const char* Ql = lds + QL;
     const char* Dl = lds + DL;
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
         //      (Running the tile one trip late, under the next trip's softmax, measured the same time at 15 registers more: not kept.)
         Frag xb[8];
         f32x4 dq, dq1;
+        f32x4 qsum = f32x4{0.f, 0.f, 0.f, 0.f};  // sums over this wave's queries of the dQ values it stores (bias_rows)
 #define X_RD(J_) xb[J_].h[0] = tr_rd<(J_) * 32 * XP>(xr); xb[J_].h[1] = tr_rd<(J_) * 32 * XP + 16 * XP>(xr)
         auto dq_tile = [&](int tt) {
             const unsigned xr = xr0 + (tt & 1) * XSZ;
@@ -241,6 +252,10 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             w[1] = pack_bf16x2((dq[2] + dq1[2]) * scale, (dq[3] + dq1[3]) * scale);
             char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + 32 * tt + 16 * jqw) * ld_dqkv + h * DH + 16 * dtw) * 2;
             *reinterpret_cast<u32x2*>(ob + out_off) = w;
+            if (bias_rows) {
+                qsum[0] += __uint_as_float(w[0] << 16); qsum[1] += __uint_as_float(w[0] & 0xffff0000u);
+                qsum[2] += __uint_as_float(w[1] << 16); qsum[3] += __uint_as_float(w[1] & 0xffff0000u);
+            }
         };
 #pragma unroll 1
         for (int t = 0; t < 8; ++t) {
@@ -343,8 +358,9 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 char* xw = xw0 + (t & 1) * XSZ;
 #pragma unroll
                 for (int jk = 0; jk < 2; ++jk) {
-                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP) = u32x2{dsf[jk].u[0], dsf[jk].u[1]};
-                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = u32x2{dsf[jk].u[2], dsf[jk].u[3]};
+                    const u32x2 q0 = u32x2{dsf[jk].u[0], dsf[jk].u[1]}, q1 = u32x2{dsf[jk].u[2], dsf[jk].u[3]};  // query blocks 0 / 1
+                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP) = xswap ? q1 : q0;
+                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = xswap ? q0 : q1;
                 }
             }
             // ---- dV^T += dO^T . P, dK^T += Q^T . dS
@@ -417,9 +433,49 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 wv_[1] = pack_bf16x2(dv[dt][jk][2] * vs, dv[dt][jk][3] * vs);
                 *reinterpret_cast<u32x2*>(ob + (heads * DH + 16 * dt) * 2 + out_off) = wk_;
                 *reinterpret_cast<u32x2*>(ob + (2 * heads * DH + 16 * dt) * 2 + out_off) = wv_;
+                if (bias_rows) {  // the accumulators are dead now: they carry the stored (rounded) values into the sums over jk below
+                    dk[dt][jk] = f32x4{__uint_as_float(wk_[0] << 16), __uint_as_float(wk_[0] & 0xffff0000u), __uint_as_float(wk_[1] << 16),
+                                       __uint_as_float(wk_[1] & 0xffff0000u)};
+                    dv[dt][jk] = f32x4{__uint_as_float(wv_[0] << 16), __uint_as_float(wv_[0] & 0xffff0000u), __uint_as_float(wv_[1] << 16),
+                                       __uint_as_float(wv_[1] & 0xffff0000u)};
+                }
             }
         }
+        if (bias_rows) {  // column sums over this wave's 32 keys (dK, dV) / its 128 queries (dQ): lane c16 = 0 of row group g holds d = 4 g + r
+            float* bp = bp_s + wave * 192;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sq = row16_sum(qsum[r]);
+                if (c16 == 0) bp[16 * dtw + 4 * g + r] = sq;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sk = row16_sum(dk[dt][0][r] + dk[dt][1][r]), sv = row16_sum(dv[dt][0][r] + dv[dt][1][r]);
+                    if (c16 == 0) {
+                        bp[64 + 16 * dt + 4 * g + r] = sk;
+                        bp[128 + 16 * dt + 4 * g + r] = sv;
+                    }
+                }
+        }
         PBARRIER();  // the next pair's statistics are written, its K tile is whole (this wave's share was complete at the wait of trip 2)
+        if (bias_rows && tid < 192) {  // the eight waves' partials in wave order; a dQ column has two contributors (the waves of its head-dim block)
+            int to = tid;
+            asm volatile("" : "+v"(to));  // LDS addresses formed here, not hoisted out of the pair loop (two were spilled)
+            const int part = to >> 6, d = to & 63;
+            float a;
+            if (part == 0) {
+                a = bp_s[(d >> 4) * 192 + d] + bp_s[((d >> 4) + 4) * 192 + d];
+            } else {
+                a = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) a += bp_s[w8 * 192 + to];
+            }
+            float* br = bias_rows;
+            asm volatile("" : "+s"(br));  // a scalar base at the point of use (hoisted as a vector pair it was spilled: a scratch reload here drains vmcnt)
+            br[(size_t)b * (3 * heads * DH) + part * heads * DH + h * DH + d] = a;  // (one more store on waves 0-2: the counted waits only over-wait)
+        }
         if (pr + (int)gridDim.x >= pairs) break;
         pr += gridDim.x;
         pb ^= 1;
@@ -434,7 +490,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
 
 // (the dispatcher in attention_bwd.hip decides when this kernel runs)
 int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
-                               int heads, void* dqkv, int ld_dqkv, DropCfg dc, const void* maskw, hipStream_t stream) {
+                               int heads, void* dqkv, int ld_dqkv, DropCfg dc, const void* maskw, hipStream_t stream, float* bias_rows) {
     const int pairs = B * heads, ncu = compute_cus();
     const int grid = pairs < ncu ? pairs : ncu;
     const float sc = 1.0f / sqrtf((float)DH);
@@ -442,7 +498,7 @@ int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, con
         set_max_lds(reinterpret_cast<const void*>(kern), LDS_BYTES);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, reinterpret_cast<const __bf16*>(qkv), ld_qkv,
                            reinterpret_cast<const __bf16*>(out), reinterpret_cast<const __bf16*>(dout), ld_o, lse, pairs, heads,
-                           reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc, reinterpret_cast<const char*>(maskw));
+                           reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc, reinterpret_cast<const char*>(maskw), bias_rows);
     };
     if (dc.thr) go(attention_bwd_x_kernel<2>);
     else go(attention_bwd_x_kernel<0>);

@@ -33,9 +33,12 @@ int bsi_attention_fwd_train(const void* qkv, int ld_qkv, int B, int tokens, int 
                             float* lse, DropCfg dc, bsi_stream_t stream, void* maskw = nullptr, bool mask_ready = false);
 int bsi_attention_bwd_drop(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse,
                            int B, int tokens, int heads, int dh, void* dqkv, int ld_dqkv, DropCfg dc, bsi_stream_t stream,
-                           const void* maskw = nullptr);
+                           const void* maskw = nullptr, float* bias_rows = nullptr);
 // gemm_bf16.hip: can the MUL_GELUGRAD GEMM of this shape write bsi_gemm_args::colsum_rows?
 bool bsi_gemm_emits_colsum(int M, int K);
 // attention_bwd_x.hip: the single-sweep backward (256 tokens, head dim 64; dropout off, or on with the mask words)
+// bias_rows (or null): [B][3 * heads * 64] fp32 per-image column sums of dqkv (the qkv bias gradient's slabs)
 int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
-                               int heads, void* dqkv, int ld_dqkv, DropCfg dc, const void* maskw, hipStream_t stream);
+                               int heads, void* dqkv, int ld_dqkv, DropCfg dc, const void* maskw, hipStream_t stream, float* bias_rows = nullptr);
+// does bsi_attention_bwd_drop with these arguments run the kernel that can write bias_rows?
+bool bsi_attention_bwd_emits_bias(int tokens, int dh, DropCfg dc, const void* maskw);

@@ -123,6 +123,7 @@ struct BwdWs {
     float* rows_fc2;  // fp32 [M / 64][dim]      sums of the dd2 rows (written by the kernel that writes ws.dd for the MLP branch)
     float* rows_out;  // fp32 [M / 64][dim]      sums of the dd1 rows
     float* rows_fc1;  // fp32 [ceil(M / 128)][4 dim]  sums of the dhp rows (GEMM epilogue)
+    float* rows_qkv;  // fp32 [B][3 dim]          sums of the dqkv rows of an image (single-sweep attention backward)
     char* rows_scratch;
     size_t total;
 };
@@ -148,8 +149,10 @@ inline BwdWs carve_bwd(const Dims& d, int B, void* base) {
     w.rows_fc2 = reinterpret_cast<float*>(p + off); off += au(r64 * dim * 4);
     w.rows_out = reinterpret_cast<float*>(p + off); off += au(r64 * dim * 4);
     w.rows_fc1 = reinterpret_cast<float*>(p + off); off += au(r128 * 4 * dim * 4);
+    w.rows_qkv = reinterpret_cast<float*>(p + off); off += au((size_t)B * 3 * dim * 4);
     w.rows_scratch = p + off;
-    off += au(2 * bsi_colsum_rows_scratch_bytes((int)r64, (int)dim) + bsi_colsum_rows_scratch_bytes((int)r128, 4 * (int)dim));
+    off += au(2 * bsi_colsum_rows_scratch_bytes((int)r64, (int)dim) + bsi_colsum_rows_scratch_bytes((int)r128, 4 * (int)dim) +
+              bsi_colsum_rows_scratch_bytes(B, 3 * (int)dim));
     w.total = off;
     return w;
 }
@@ -287,12 +290,15 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
     auto dmod_of = [&](int l) { return ws.dmod + (size_t)(l & 1) * nplanes * plane; };
     // Bias gradients of out-projection, fc2 and fc1: the kernels that WRITE those layers' output gradients (the LayerNorm / gate backward
     // for dd1 and dd2, the GELU'-epilogue GEMM for dhp) also leave per-slab column sums; one small reduction per block adds the slabs in
-    // fixed order.  The weight-gradient GEMMs then run without the bias rider (gemm_tn.hip: -9..-14 % per launch).  The qkv and adaLN
-    // biases stay fused in their weight-gradient GEMMs (dqkv's producer, the attention backward, has no spare registers).
+    // fixed order.  The weight-gradient GEMMs then run without the bias rider (gemm_tn.hip: -9..-14 % per launch).  The qkv bias follows
+    // where the single-sweep attention backward runs (per-image sums of the dqkv rows it stores); the adaLN biases stay fused.
     static const bool fused_bias = [] { const char* e = getenv("BSI_TRAIN_FUSED_BIAS"); return e && *e == '1'; }();
     const bool rel_dd = !fused_bias && dim > 256;
     const bool rel_fc1 = !fused_bias && bsi_gemm_emits_colsum(M, dim);
     const int r64 = M / 64, r128 = (M + 127) / 128;
+    auto rel_qkv_of = [&](int l) {  // depends on the block only through its dropout site (on or off for all)
+        return !fused_bias && bsi_attention_bwd_emits_bias(d.tokens, 64, make_drop(dropout_p, seed, 2 * l), block_tape(tp, d, B, l).maskw);
+    };
     // decoder: dX = d/dx_final, parameter gradients of patch_decoder (dit.py:163-165)
     {
         const int Pp = (d.P + 7) / 8 * 8;  // yb -> ws.dd, dYb -> ws.dsmall (Pp <= 64 <= dim columns)
@@ -336,23 +342,26 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
         TRY(bsi_ln_gate_bwd_drop(ws.dsmall, bt.xb, bt.sb, ml + 4 * dim, mod_stride, dml + 3 * dim, dml + 4 * dim, dstride, ws.dX,
                                  bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, dstride, ws.dd, M, dim, d.tokens,
                                  make_drop(dropout_p, seed, 2 * l + 1), stream, plane, rel_dd ? ws.rows_out : nullptr));
-        if (rel_dd || rel_fc1) {  // the three slab tables of this block are complete (rows_fc2 is rewritten by the LayerNorm-1 launch below)
-            bsi_colsum_job jobs[3];
+        TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
+        if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
+        const bool rel_qkv = rel_qkv_of(l);
+        TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
+                                   make_drop(dropout_p, seed, 2 * l), stream, bt.maskw, rel_qkv ? ws.rows_qkv : nullptr));
+        if (rel_dd || rel_fc1 || rel_qkv) {  // the slab tables of this block are complete (rows_fc2 is rewritten by the LayerNorm-1 launch below)
+            bsi_colsum_job jobs[4];
             int nj = 0;
             if (rel_dd) {
                 jobs[nj++] = bsi_colsum_job{ws.rows_fc2, r64, dim, dim, bg.fc2_b};
                 jobs[nj++] = bsi_colsum_job{ws.rows_out, r64, dim, dim, bg.out_b};
             }
             if (rel_fc1) jobs[nj++] = bsi_colsum_job{ws.rows_fc1, r128, 4 * dim, 4 * dim, bg.fc1_b};
+            if (rel_qkv) jobs[nj++] = bsi_colsum_job{ws.rows_qkv, B, 3 * dim, 3 * dim, bg.qkv_b};
             TRY(bsi_colsum_rows_f32(jobs, nj, ws.rows_scratch, stream));
         }
-        TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
-        if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
-        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
-        TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
-                                   make_drop(dropout_p, seed, 2 * l), stream, bt.maskw));
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
-        TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
+        if (rel_qkv) TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
         // LayerNorm 1 backward (dX becomes dL/dxa) + the MLP branch of the block below: xa = xb' + g_m' * d2'
         if (l > 0) {
             BlockTape below = block_tape(tp, d, B, l - 1);

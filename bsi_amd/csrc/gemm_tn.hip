@@ -797,21 +797,21 @@ extern "C" int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Column sums of fp32 row tables (bias gradients whose per-slab partial rows the producers of dY write, round 4): out[c] = sum_r
 // src[r][c], rows added in a fixed order.  One kernel, run twice: stage 1 sums chunks of 64 rows into partial rows, stage 2 (the same
-// kernel on the partial rows: <= 64 of them = one chunk) writes the result.  Up to three tables per launch.
+// kernel on the partial rows: one chunk) writes the result.  Up to four tables per launch.
 namespace {
 struct ColsumJobs {
-    const float* src[3];
-    float* dst[3];
-    int rows[3], cols[3], ld[3], dst_ld[3];
-    int blk0[4];  // first block of job j (blk0[njobs] = grid)
-    int cblocks[3];  // column blocks (of 256 columns) of job j
+    const float* src[4];
+    float* dst[4];
+    int rows[4], cols[4], ld[4], dst_ld[4];
+    int blk0[5];  // first block of job j (blk0[njobs] = grid)
+    int cblocks[4];  // column blocks (of 256 columns) of job j
     int njobs;
     int chunk;  // rows per block: CS_CHUNK in stage 1, all of them in stage 2
 };
 constexpr int CS_CHUNK = 64;
 
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const ColsumJobs jb) {
-    __shared__ f32x4 part[3][64];
+    __shared__ f32x4 part[3][64];  // (the three other row lanes of a column quad)
     int j = 0;
     while (j + 1 < jb.njobs && (int)blockIdx.x >= jb.blk0[j + 1]) ++j;
     const int lb = blockIdx.x - jb.blk0[j];
@@ -856,7 +856,7 @@ extern "C" size_t bsi_colsum_rows_scratch_bytes(int rows, int cols) {  // one pa
 }
 
 extern "C" int bsi_colsum_rows_f32(const bsi_colsum_job* jobs, int njobs, void* scratch, bsi_stream_t stream) {
-    BSI_CHECK_ARG(jobs && njobs >= 1 && njobs <= 3 && scratch, "bsi_colsum_rows_f32: 1..3 jobs and a scratch buffer");
+    BSI_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4 && scratch, "bsi_colsum_rows_f32: 1..4 jobs and a scratch buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ColsumJobs a{}, b{};
     a.njobs = b.njobs = njobs;

@@ -245,7 +245,7 @@ int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int ldq, int M,
                           float* colsum_out, int accumulate, void* workspace, bsi_stream_t stream);
 /* out[c] = sum over r < rows of src[r * ld + c] (fp32, c < cols, cols % 4 == 0), rows added in index order (deterministic): the second
  * stage of the bias gradients whose per-slab column sums the producers of dY write (bsi_gemm_args::colsum_rows, the LayerNorm /
- * gate backward).  Up to three jobs in one pair of launches.  scratch: the sum of bsi_colsum_rows_scratch_bytes(rows, cols) over the
+ * gate backward, the attention backward).  Up to four jobs in one pair of launches.  scratch: the sum of bsi_colsum_rows_scratch_bytes(rows, cols) over the
  * jobs.  ld % 4 == 0, src and out 16-byte aligned. */
 typedef struct bsi_colsum_job { const float* src; int rows, cols, ld; float* out; } bsi_colsum_job;
 size_t bsi_colsum_rows_scratch_bytes(int rows, int cols);

@@ -393,7 +393,7 @@ def test_colsum_rows_three_jobs_two_stages(N):
     N.check(N.lib().bsi_colsum_rows_f32(jobs, 3, N.ptr(scratch), N.stream()))
     for o, f in zip(outs, first):
         assert torch.equal(o, f)
-    assert N.lib().bsi_colsum_rows_f32(jobs, 4, N.ptr(scratch), N.stream()) != 0
+    assert N.lib().bsi_colsum_rows_f32(jobs, 5, N.ptr(scratch), N.stream()) != 0
 
 
 @pytest.mark.parametrize("epi_name", ["bias", "gelu"])

@@ -7,8 +7,8 @@
 // 27-30 issue cycles per score element against 448 MFMAs per wave and pair).  Here a wave owns 32 KEYS and walks the queries
 // 32 at a time (the second pass of that kernel, unchanged arithmetic): P^T and dS^T are the B operands of
 // dV^T = dO^T . P and dK^T = Q^T . dS as they leave the lane, and the packed dS block ALSO goes to an LDS exchange buffer
-// X[key][query] (8 waves x 32 keys x 32 queries of bf16 = 16 KB per trip; the two 32-B halves of a row swap places every four rows, so
-// that the 8 rows an LDS cycle of a transposed read touches fall into 8 disjoint 8-bank windows).  Behind the trip's barrier wave w forms ONE 16 x 16 tile of
+// X[key][query] (8 waves x 32 keys x 32 queries of bf16 = 16 KB per trip, row pitch 96 B: the 8 rows an LDS cycle of a
+// transposed read touches start in 8 disjoint 8-bank windows).  Behind the trip's barrier wave w forms ONE 16 x 16 tile of
 // dQ^T = K^T . dS^T for those 32 queries -- head-dim block w & 3, query block w >> 2 -- over all 256 keys: eight MFMAs whose A
 // operands (its K^T rows, 32 registers) were read once per pair and whose B operands are transposed reads of X.  No score element
 // is formed twice, nothing is summed across waves, no atomics: deterministic.
@@ -27,19 +27,26 @@
 namespace {
 
 constexpr int DH = 64, RB = 128, PT = 256;
-constexpr int XP = 64, XSZ = PT * XP;                 // exchange buffer: 32 queries of bf16 per key row, 16 KB per buffer (layout below)
+constexpr int XP = 96, XSZ = PT * XP;                 // exchange buffer: row pitch (64 B of data + 32 B of pad), bytes per buffer (24 KB)
 constexpr int QL = 0, DL = PT * RB, KL = 2 * PT * RB; // Q and dO first: 16-bit ds offsets
 constexpr int XL = 3 * PT * RB;                       // X[2]
 constexpr int ST = XL + 2 * XSZ;                      // lse_s[2][PT], dlt_s[2][PT]
 constexpr int MK = ST + 4 * PT * 4;                   // dropout words of the current pair (8 KB, refilled rolling)
 constexpr int MK_BYTES = 8192;
-constexpr int BP = MK + MK_BYTES;                     // bias partials of the pair: [8 waves][192] floats (dQ 64 | dK 64 | dV 64)
-constexpr int LDS_BYTES = BP + 8 * 192 * 4;           // 149504
+constexpr int LDS_BYTES = MK + MK_BYTES;              // 159744
+// the bias partials of a pair ([8 waves][192] floats: dQ 64 | dK 64 | dV 64) live in the 32-byte pads of X[0]'s rows (8 floats per
+// row, 24 rows per wave): nothing else reads or writes those bytes, so they need no ordering against the exchange traffic
+constexpr int BPW = 24 * XP;  // bytes between two waves' partials; float i of wave w: XL + w * BPW + (i >> 3) * XP + 64 + (i & 7) * 4
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 #ifndef ATTN_ABL
 #define ATTN_ABL 0  // timing ablations of tools/experiments/attn_bwd_ablate.sh (wrong results): 1 softmax, 2 dV / dK, 4 dQ, 8 barrier, 16 S / dP, 32 next-pair fetches, 64 X write
 #endif
 constexpr int ABL = ATTN_ABL;
+#ifdef ATTN_NO_BIAS
+#define BIAS_ON false
+#else
+#define BIAS_ON (bias_rows != nullptr)
+#endif
 
 __device__ __forceinline__ int sw(int r) { return ((r >> 1) & 3) << 1; }
 __device__ __forceinline__ const char* row_chunk(const char* tile, int r, int c) { return tile + r * RB + ((c ^ sw(r)) << 4); }
@@ -64,7 +71,6 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     // without its bias rider: 884 -> 788 us).  Per pair: a DPP row sum per accumulator register, 192 floats per wave through LDS.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lse_s = reinterpret_cast<float*>(lds + ST);
-    float* bp_s = reinterpret_cast<float*>(lds + BP);
     float* dlt_s = lse_s + 2 * PT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -180,14 +186,11 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     unsigned tq[4];                           // Q tile (the dO tile is DL further: immediate)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) tq[dt] = lds_u32(lds) + (4 * g + qp) * RB + ((dt ^ swh) << 5) + (pp >> 1) * 16 + 8 * (pp & 1);
-    const unsigned tkw = lds_u32(lds) + KL + (4 * g + qp) * RB + ((dtw ^ swh) << 5) + (pp >> 1) * 16 + 8 * (pp & 1);  // K^T rows of this wave's dQ^T tile
-    // X[key][32 queries]: a row is two 32-B halves (query blocks 0 and 1), stored at half ^ ((key >> 2) & 1).  A transposed read covers
-    // 8 consecutive key rows per LDS cycle (16-lane groups g = 0, 1), 32 B of one query block each: rows 0-3 take one half of four 64-B
-    // slots, rows 4-7 the other half of the same slots -- conflict free without padding (a padded pitch of 96 B measured 25 M conflict
-    // cycles per launch from the two-address stores); a store instruction fills whole rows.
-    const unsigned xr0 = lds_u32(lds) + XL + (4 * g + qp) * XP + ((jqw ^ (g & 1)) << 5) + pp * 8;  // as B operand: key rows 4 g + qp, this wave's query block
-    char* const xw0 = lds + XL + (r0 + c16) * XP + g * 8;                                             // as written: this lane's key, queries 4 g ..
-    const bool xswap = (c16 >> 2) & 1;  // this lane's key rows store query block 1 in the first half
+    // X[key][32 queries] at a pitch of 96 B: the 8 consecutive key rows an LDS cycle of a transposed read touches start in 8 disjoint
+    // 8-bank windows.  (A 64-byte pitch with the row halves swapped every four rows has no bank conflict at all -- the padded pitch
+    // costs 25 M conflict cycles per launch in the two-address stores -- and measured 4 % SLOWER, 860 against 828 us: not kept.)
+    const unsigned xr0 = lds_u32(lds) + XL + (4 * g + qp) * XP + jqw * 32 + pp * 8;  // as B operand: key rows 4 g + qp, this wave's query block
+    const int xw0 = XL + (r0 + c16) * XP + g * 8;                                      // as written: this lane's key, queries 4 g .. (an LDS offset: one register)
     union Frag { bf16x8 v; s16x4 h[2]; u32x4 u; };
     const char* Ql = lds + QL;
     const char* Dl = lds + DL;
@@ -207,6 +210,10 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 kf[jk][ks] = *reinterpret_cast<const bf16x8*>(row_chunk(Kl, k, 4 * ks + g));
             }
         }
+        int lp = lane;
+        asm volatile("" : "+v"(lp));  // the K^T address is used here only: formed per pair instead of living in a register through the loops
+        const int gp = lp >> 4, qpp = (lp & 15) >> 2, ppp = lp & 3;
+        const unsigned tkw = lds_u32(lds) + KL + (4 * gp + qpp) * RB + ((dtw ^ ((2 * gp + (qpp >> 1)) & 3)) << 5) + (ppp >> 1) * 16 + 8 * (ppp & 1);
 #define KT_RD(J_) ktf[J_].h[0] = tr_rd<(J_) * 32 * RB>(tkw); ktf[J_].h[1] = tr_rd<(J_) * 32 * RB + 16 * RB>(tkw)
         KT_RD(0); KT_RD(1); KT_RD(2); KT_RD(3);
         asm volatile("s_waitcnt lgkmcnt(0) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             w[1] = pack_bf16x2((dq[2] + dq1[2]) * scale, (dq[3] + dq1[3]) * scale);
             char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + 32 * tt + 16 * jqw) * ld_dqkv + h * DH + 16 * dtw) * 2;
             *reinterpret_cast<u32x2*>(ob + out_off) = w;
-            if (bias_rows) {
+            if (BIAS_ON) {
                 qsum[0] += __uint_as_float(w[0] << 16); qsum[1] += __uint_as_float(w[0] & 0xffff0000u);
                 qsum[2] += __uint_as_float(w[1] << 16); qsum[3] += __uint_as_float(w[1] & 0xffff0000u);
             }
@@ -292,14 +299,14 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     }
                 }
             }
-            // ---- the transposed Q / dO fragments of the first two head-dim blocks (for dK / dV) do not depend on the softmax: their reads go
-            //      out in front of it, the other two blocks' right behind it, and each group of eight MFMAs waits only for its own eight
+            // ---- the transposed Q / dO fragments (for dK / dV): all 16 reads go out together behind the softmax and each group of eight MFMAs
+            //      waits only for its own eight.  (The first eight in FRONT of the softmax -- they do not depend on it -- measured 1 % faster
+            //      at 16 registers more, which the instances with the bias sums do not have.)
             const unsigned qco = (unsigned)qc * RB;
             Frag dot[4], qt_[4];
 #define QD_RD(DT_)                                                                                                   \
     dot[DT_].h[0] = tr_rd<DL>(tq[DT_] + qco); dot[DT_].h[1] = tr_rd<DL + 16 * RB>(tq[DT_] + qco);                   \
     qt_[DT_].h[0] = tr_rd<0>(tq[DT_] + qco);  qt_[DT_].h[1] = tr_rd<16 * RB>(tq[DT_] + qco)
-            if constexpr (!(ABL & 2)) { QD_RD(0); QD_RD(1); }
             // ---- P = exp2(S * scale * log2e - lse * log2e), dS / scale = P * (dP - delta) (the softmax scale, a power of two, multiplies
             //      the dQ and dK tiles at their stores: bit-identical, one multiply per score element less); dropped P for dV
 #pragma unroll
@@ -355,12 +362,11 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 }
             // ---- dS^T block to the exchange buffer: X[key][query], 4 queries (8 B) per store
             if constexpr (!(ABL & 64)) {
-                char* xw = xw0 + (t & 1) * XSZ;
+                char* xw = lds + xw0 + (t & 1) * XSZ;
 #pragma unroll
                 for (int jk = 0; jk < 2; ++jk) {
-                    const u32x2 q0 = u32x2{dsf[jk].u[0], dsf[jk].u[1]}, q1 = u32x2{dsf[jk].u[2], dsf[jk].u[3]};  // query blocks 0 / 1
-                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP) = xswap ? q1 : q0;
-                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = xswap ? q0 : q1;
+                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP) = u32x2{dsf[jk].u[0], dsf[jk].u[1]};
+                    *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = u32x2{dsf[jk].u[2], dsf[jk].u[3]};
                 }
             }
             // ---- dV^T += dO^T . P, dK^T += Q^T . dS
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 dv[0][0][0] += __builtin_bit_cast(f32x4, pf[0].v)[0] + __builtin_bit_cast(f32x4, pf[1].v)[0];
                 dk[0][0][0] += __builtin_bit_cast(f32x4, dsf[0].v)[0] + __builtin_bit_cast(f32x4, dsf[1].v)[0];
             } else {
-                QD_RD(2); QD_RD(3);
+                QD_RD(0); QD_RD(1); QD_RD(2); QD_RD(3);
                 asm volatile("s_waitcnt lgkmcnt(8) ; data of %0 %1 %2 %3 %4 %5 %6 %7"
                              : "+v"(dot[0].h[0]), "+v"(dot[0].h[1]), "+v"(dot[1].h[0]), "+v"(dot[1].h[1]), "+v"(qt_[0].h[0]),
                                "+v"(qt_[0].h[1]), "+v"(qt_[1].h[0]), "+v"(qt_[1].h[1]));
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 wv_[1] = pack_bf16x2(dv[dt][jk][2] * vs, dv[dt][jk][3] * vs);
                 *reinterpret_cast<u32x2*>(ob + (heads * DH + 16 * dt) * 2 + out_off) = wk_;
                 *reinterpret_cast<u32x2*>(ob + (2 * heads * DH + 16 * dt) * 2 + out_off) = wv_;
-                if (bias_rows) {  // the accumulators are dead now: they carry the stored (rounded) values into the sums over jk below
+                if (BIAS_ON) {  // the accumulators are dead now: they carry the stored (rounded) values into the sums over jk below
                     dk[dt][jk] = f32x4{__uint_as_float(wk_[0] << 16), __uint_as_float(wk_[0] & 0xffff0000u), __uint_as_float(wk_[1] << 16),
                                        __uint_as_float(wk_[1] & 0xffff0000u)};
                     dv[dt][jk] = f32x4{__uint_as_float(wv_[0] << 16), __uint_as_float(wv_[0] & 0xffff0000u), __uint_as_float(wv_[1] << 16),
@@ -441,36 +447,41 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 }
             }
         }
-        if (bias_rows) {  // column sums over this wave's 32 keys (dK, dV) / its 128 queries (dQ): lane c16 = 0 of row group g holds d = 4 g + r
-            float* bp = bp_s + wave * 192;
+        if (BIAS_ON) {  // column sums over this wave's 32 keys (dK, dV) / its 128 queries (dQ): lane c16 = 0 of row group g holds d = 4 g + r
+            int lb = lane;
+            asm volatile("" : "+v"(lb));  // one per-lane base formed here + immediates (hoisted addresses cost registers through both loops)
+            const int gb = lb >> 4;
+            char* bpl = lds + XL + wave * BPW + (gb >> 1) * XP + 64 + (gb & 1) * 16;  // float 4 g of this wave's partials; + 16 dt floats = + 2 dt rows
+            const bool first = (lb & 15) == 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sq = row16_sum(qsum[r]);
-                if (c16 == 0) bp[16 * dtw + 4 * g + r] = sq;
+                if (first) *reinterpret_cast<float*>(bpl + 2 * dtw * XP + 4 * r) = sq;
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float sk = row16_sum(dk[dt][0][r] + dk[dt][1][r]), sv = row16_sum(dv[dt][0][r] + dv[dt][1][r]);
-                    if (c16 == 0) {
-                        bp[64 + 16 * dt + 4 * g + r] = sk;
-                        bp[128 + 16 * dt + 4 * g + r] = sv;
+                    if (first) {
+                        *reinterpret_cast<float*>(bpl + (8 + 2 * dt) * XP + 4 * r) = sk;   // floats 64 ..
+                        *reinterpret_cast<float*>(bpl + (16 + 2 * dt) * XP + 4 * r) = sv;  // floats 128 ..
                     }
                 }
         }
         PBARRIER();  // the next pair's statistics are written, its K tile is whole (this wave's share was complete at the wait of trip 2)
-        if (bias_rows && tid < 192) {  // the eight waves' partials in wave order; a dQ column has two contributors (the waves of its head-dim block)
+        if (BIAS_ON && tid < 192) {  // the eight waves' partials in wave order; a dQ column has two contributors (the waves of its head-dim block)
             int to = tid;
             asm volatile("" : "+v"(to));  // LDS addresses formed here, not hoisted out of the pair loop (two were spilled)
             const int part = to >> 6, d = to & 63;
             float a;
+            const char* bq = lds + XL + (to >> 3) * XP + 64 + (to & 7) * 4;  // float `to` of wave 0's partials
             if (part == 0) {
-                a = bp_s[(d >> 4) * 192 + d] + bp_s[((d >> 4) + 4) * 192 + d];
+                a = *reinterpret_cast<const float*>(bq + (d >> 4) * BPW) + *reinterpret_cast<const float*>(bq + (d >> 4) * BPW + 4 * BPW);
             } else {
                 a = 0.f;
 #pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) a += bp_s[w8 * 192 + to];
+                for (int w8 = 0; w8 < 8; ++w8) a += *reinterpret_cast<const float*>(bq + w8 * BPW);
             }
             float* br = bias_rows;
             asm volatile("" : "+s"(br));  // a scalar base at the point of use (hoisted as a vector pair it was spilled: a scratch reload here drains vmcnt)

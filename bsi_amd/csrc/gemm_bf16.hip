@@ -928,7 +928,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 // whole stage G+1 must have landed -> 4 (only the new one in flight); + the stores of a recent epilogue.
                 if (issued) {
                     if (BF16_OUT && after_e > 0) {
-                        if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+                        if (EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr) {  // + the wave tile's 4 column-sum stores (operand-free waits)
+                            if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST + 4) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST + 4) : "memory");
+                        } else if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
                     } else if (ks == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

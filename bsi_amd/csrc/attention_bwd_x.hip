@@ -127,33 +127,36 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
         }
     };
     // ---- delta and log-sum-exp of four queries per wave and trip: query 32 wave + 4 t + g, 16 lanes x 4 head-dim elements
-    u32x2 sd, so;
-    float sl;
-    int sq = 0;
-    auto issue_stats = [&](int pr, int t) {  // 3 loads
+    //      Two register sets, used by the even and the odd trips: a set is consumed TWO trips after its loads went out (the trip loop is
+    //      unrolled by two for that), so the wait for it never meets a load younger than a whole trip.
+    struct StatSet { u32x2 sd, so; float sl; int sq; };
+    StatSet S0, S1;
+    S0.sq = S1.sq = 0;
+    auto issue_stats = [&](StatSet& S, int pr, int t) {  // 3 loads
         const int q0 = 32 * wave + 4 * t;
-        sq = q0 + g;
+        S.sq = q0 + g;
         const size_t ro = o_off(pr) + (size_t)q0 * ldbo;
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sd) : "v"(st_off), "s"(reinterpret_cast<const char*>(dout) + ro) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(so) : "v"(st_off), "s"(reinterpret_cast<const char*>(o) + ro) : "memory");
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(sl) : "v"(g * 4), "s"(lse + (size_t)pr * PT + q0) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(S.sd) : "v"(st_off), "s"(reinterpret_cast<const char*>(dout) + ro) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(S.so) : "v"(st_off), "s"(reinterpret_cast<const char*>(o) + ro) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(S.sl) : "v"(g * 4), "s"(lse + (size_t)pr * PT + q0) : "memory");
     };
-    auto consume_stats = [&](int buf) {
+    auto consume_stats = [&](StatSet& S, int buf) {
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            a = __fmaf_rn(__uint_as_float(sd[e] << 16), __uint_as_float(so[e] << 16), a);
-            a = __fmaf_rn(__uint_as_float(sd[e] & 0xffff0000u), __uint_as_float(so[e] & 0xffff0000u), a);
+            a = __fmaf_rn(__uint_as_float(S.sd[e] << 16), __uint_as_float(S.so[e] << 16), a);
+            a = __fmaf_rn(__uint_as_float(S.sd[e] & 0xffff0000u), __uint_as_float(S.so[e] & 0xffff0000u), a);
         }
         a = row16_sum(a);
         if (c16 == 0) {
-            dlt_s[buf * PT + sq] = a;
-            lse_s[buf * PT + sq] = sl * L2E;
+            dlt_s[buf * PT + S.sq] = a;
+            lse_s[buf * PT + S.sq] = S.sl * L2E;
         }
     };
-    // fetches a wave issues per trip behind its three statistics loads: Q / dO rows, [dropout words], the dQ store (+ 4 + 4 in trip 0)
-    constexpr int NM = DROP == 2 ? 1 : 0, YOUNGER = 2 + NM;
-#define WAIT_S(N_) asm volatile("s_waitcnt vmcnt(%3) ; data of %0 %1 %2" : "+v"(sd), "+v"(so), "+v"(sl) : "n"(N_) : "memory")
+    // vector-memory instructions a wave issues per trip, in order: dQ store | [4 V loads (trip 7)] | [4 K-tile DMA (trip 0)] | 3 statistics
+    // loads | Q / dO rows | [dropout words]
+    constexpr int NM = DROP == 2 ? 1 : 0;
+#define WAIT_S(S_, N_) asm volatile("s_waitcnt vmcnt(%3) ; data of %0 %1 %2" : "+v"(S_.sd), "+v"(S_.so), "+v"(S_.sl) : "n"(N_) : "memory")
 #define WAIT_V(N_) \
     asm volatile("s_waitcnt vmcnt(%4) ; data of %0 %1 %2 %3" : "+v"(vn[0][0]), "+v"(vn[0][1]), "+v"(vn[1][0]), "+v"(vn[1][1]) : "n"(N_) : "memory")
 #define PBARRIER()                                         \
@@ -174,9 +177,9 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     for (int t = 0; t < 8; ++t) {
         issue_qd(pr, t);
         issue_mask(pr, t);
-        issue_stats(pr, t);
-        WAIT_S(0);
-        consume_stats(0);
+        issue_stats(S0, pr, t);
+        WAIT_S(S0, 0);
+        consume_stats(S0, 0);
     }
     WAIT_V(0);
     PBARRIER();
@@ -258,14 +261,14 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             w[0] = pack_bf16x2((dq[0] + dq1[0]) * scale, (dq[1] + dq1[1]) * scale);
             w[1] = pack_bf16x2((dq[2] + dq1[2]) * scale, (dq[3] + dq1[3]) * scale);
             char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + 32 * tt + 16 * jqw) * ld_dqkv + h * DH + 16 * dtw) * 2;
+            asm volatile("" : "+s"(ob));  // a scalar base + the 32-bit lane offset (the per-lane 64-bit sum, hoisted out of both loops, was spilled)
             *reinterpret_cast<u32x2*>(ob + out_off) = w;
             if (BIAS_ON) {
                 qsum[0] += __uint_as_float(w[0] << 16); qsum[1] += __uint_as_float(w[0] & 0xffff0000u);
                 qsum[2] += __uint_as_float(w[1] << 16); qsum[3] += __uint_as_float(w[1] & 0xffff0000u);
             }
         };
-#pragma unroll 1
-        for (int t = 0; t < 8; ++t) {
+        auto trip = [&](const int t, StatSet& S) {
             const int qc = 32 * t;
             // ---- S = Q . K^T, dP = dO . V^T for 32 queries x this wave's 32 keys (key on the lane, four queries per register quad)
             f32x4 s[2][2], dp[2][2];
@@ -401,34 +404,44 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
 
             // ---- the next pair's share of this trip: statistics of four queries, the Q / dO rows and dropout words of this trip's slot
             //      (trip 0: also the K tile; trip 7: this wave's V rows; both IN FRONT of the statistics loads, so that one count serves
-            //      every trip).  Issue order per trip: dQ store | [4 loads | 4 DMA] | 3 loads | DMA, words.
+            //      every trip).
             //      ONE wait statement carries the loaded registers: with a second one in the other arm of an if / else, hipcc merged the
             //      arms by COPYING the loaded registers in front of one arm's wait -- stale statistics in a few pairs per thousand
             //      (tools/check_asm_loads.py scans for that pattern).
             if constexpr (!(ABL & 4)) dq_tile(t);
             if constexpr (!(ABL & 32)) {
-            if (!(ABL & 128) && t >= 1) {  // 128: no wait for / use of the statistics loads
-                WAIT_S(YOUNGER);
-                consume_stats(pb ^ 1);
+            if (!(ABL & 128) && t >= 2) {  // 128: no wait for / use of the statistics loads
+                // this set's loads went out in trip t - 2; younger: that trip's rows + words, trip t - 1 whole (store, 3 loads, rows,
+                // words), this trip's dQ store
+                WAIT_S(S, 7 + 2 * NM);
+                consume_stats(S, pb ^ 1);
             }
             if (t == 7) issue_v(nxt);
             if (!(ABL & 256) && t == 0) issue_k(nxt);  // 256: no LDS-DMA
-            if constexpr (!(ABL & 512)) issue_stats(nxt, t);  // 512: no statistics loads
+            if constexpr (!(ABL & 512)) issue_stats(S, nxt, t);  // 512: no statistics loads
             if constexpr (!(ABL & 256)) {
                 issue_qd(nxt, t);
                 issue_mask(nxt, t);
             }
             }
+        };
+#pragma unroll 1
+        for (int t2 = 0; t2 < 8; t2 += 2) {
+            trip(t2, S0);
+            trip(t2 + 1, S1);
         }
         // ---- end of the pair: the statistics of trip 7, then dK and dV of this wave's keys
 #undef X_RD
         if constexpr (!(ABL & (32 | 128))) {
-            WAIT_S(YOUNGER - 1);  // no dQ store behind the fetches of trip 7
-            consume_stats(pb ^ 1);
+            WAIT_S(S0, 10 + 2 * NM);  // trip 6's set: behind it its rows + words and trip 7's store, 4 V loads, 3 loads, rows, words
+            consume_stats(S0, pb ^ 1);
+            WAIT_S(S1, 1 + NM);       // trip 7's set: its rows + words (the one wait of a pair that meets loads less than a trip old)
+            consume_stats(S1, pb ^ 1);
         }
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {  // 16 stores
             char* ob = reinterpret_cast<char*>(dqkv) + (((size_t)b * PT + r0 + 16 * jk) * ld_dqkv + h * DH) * 2;
+            asm volatile("" : "+s"(ob));
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 u32x2 wk_, wv_;

@@ -122,6 +122,24 @@ class DenoisingVDMUNet(nn.Module):
         return N.UNetConfig(Cc, H, W, a["dim"], a["levels"], a["heads"], ff.n_min if ff is not None else 1,
                             ff.n_max if ff is not None else 0, self.pos_emb.size, a["c_dim"])
 
+    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad")
+
+    def __deepcopy__(self, memo):
+        """`copy.deepcopy(model)` (EMA copies, checkpoint tooling) after the model has run: the native caches hold ctypes tables with raw
+        device pointers into THIS model's buffers -- they are neither picklable nor valid for a copy, and are rebuilt on first use."""
+        import copy
+        saved = {k: self.__dict__.pop(k) for k in self._NATIVE_CACHES if k in self.__dict__}
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            new.__dict__ = copy.deepcopy(self.__dict__, memo)
+            for k in saved:
+                new.__dict__[k] = None
+        finally:
+            self.__dict__.update(saved)
+        return new
+
     def _weights_key(self):
         ps = list(self.parameters())
         return (ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))

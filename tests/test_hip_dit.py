@@ -75,6 +75,31 @@ def test_dit_forward_vs_golden_and_bf16_oracle():
     bound("test_dit_forward_vs_golden_and_bf16_oracle:75", rel_linf(y, yb), 4e-3)
 
 
+def test_models_deepcopy_after_use_and_copies_rebuild_their_caches():
+    """copy.deepcopy of a model that has already run (its native caches hold ctypes tables with raw device pointers): the copy comes
+    without the caches, rebuilds them on first use and gives the same output; the original keeps its caches."""
+    import copy
+    g = golden("g7_dit_fwd")
+    m = make_model()
+    mu, t = g["mu"].to(DEV), g["t"].to(DEV)
+    with torch.no_grad():
+        a = m(mu, t)
+        pack = m._pack
+        c = copy.deepcopy(m)
+        assert c._pack is None and c._plan is None and m._pack is pack
+        b = c(mu, t)
+        assert c._pack is not None and c._pack is not pack
+    assert torch.equal(a, b)
+    g = golden("g7_unet_fwd")
+    u = make_unet()
+    mu, t = g["mu"].to(DEV), g["t"].to(DEV)
+    with torch.no_grad():
+        a = u(mu, t)
+        c = copy.deepcopy(u)
+        assert c._pack is None and c._plan is None
+        assert torch.equal(a, c(mu, t))
+
+
 def test_dit_tokens_blockwise():
     """Residual stream after the blocks (fp32) against the oracle with bf16 rounding points."""
     g = golden("g7_dit_fwd")

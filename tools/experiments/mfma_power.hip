@@ -66,7 +66,10 @@ __global__ __launch_bounds__(512, 1) void mfma_kernel(const bf16x8* __restrict__
 // 12 = the k64r kernel's 128 x 64 wave tile, 8 = what a 128 x 128 wave tile would need per 32 MFMAs, 0 = none.
 // NDMA: global_load_lds_dwordx4 per wave and k32 step into a separate 32 KB of LDS (4 = the k64r kernel's stream: 32 KB per
 // workgroup and k32 step), walking `region` bytes of `stream` per workgroup (small = L2 hits, large = HBM).
-template <int ORDER, int NREAD, int NDMA>
+// NGL (round 4): the 4 W fragments of a k32 step come STRAIGHT FROM MEMORY into registers (global_load_dwordx4, a step ahead, rows of a
+// [256][1024] bf16 weight tile shared by 16 workgroups: L2 hits), not through LDS -- with NREAD = 8 and NDMA = 2 that is the k64r
+// kernel's mix with the W panel taken off the LDS path (fragment reads 12 -> 8, LDS-DMA 32 -> 16 KB per k32 step).
+template <int ORDER, int NREAD, int NDMA, int NGL = 0>
 __global__ __launch_bounds__(512, 1) void mfma_lds_kernel(const bf16x8* __restrict__ src, float* __restrict__ out, int iters,
                                                           long long* __restrict__ clk, const char* __restrict__ stream = nullptr,
                                                           unsigned region = 0) {
@@ -81,9 +84,25 @@ __global__ __launch_bounds__(512, 1) void mfma_lds_kernel(const bf16x8* __restri
     for (int i = 0; i < 8; ++i) a[i] = src[i * 512 + t];
     for (int i = 0; i < 4; ++i) b[i] = src[(8 + i) * 512 + t];
     f32x4 acc[8][4] = {};
+    // W tile of this workgroup: 16 distinct tiles of 512 KB behind `stream` + 64 MB, rows of 2 KB; wave (wm, wn): columns 64 wn ..; a
+    // fragment = 16 rows x 64 B (lane: row lane & 15, 16-B chunk lane >> 4)
+    const char* wt = stream + (64u << 20) + (size_t)(blockIdx.x & 15) * (512u << 10) + (size_t)(((t >> 6) & 3) * 64 + (t & 15)) * 2048 + ((t >> 4) & 3) * 16;
+    bf16x8 bn[4];
+    unsigned kk = 0;
+    if (NGL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const bf16x8*>(wt + j * 16 * 2048);
+    }
     const long long c0 = clock64();
     const long long w0 = wall_clock64();
     for (int it = 0; it < iters * 2; ++it) {
+        if (NGL) {  // this step's fragments arrived during the last one; the next step's go out now
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = bn[j];
+            kk = (kk + 64) & 2047;
+#pragma unroll
+            for (int j = 0; j < NGL; ++j) bn[j] = *reinterpret_cast<const bf16x8*>(wt + j * 16 * 2048 + kk);
+        }
         const int base = ((it * 12) & 127) * 32 + (t & 63);  // walks the image; lane-linear 16-byte reads (conflict free)
         if (NDMA) {
 #pragma unroll
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void mfma_lds_kernel(const bf16x8* __restri
             if (NREAD && n >= 32 - NREAD) {  // the reads sit behind the last use of the register they refill
                 const int f = n - (32 - NREAD);
                 if (f < 8) a[(ORDER == 2) ? f : f] = lds[(base + f * 64) % (24 * 512 / 2)];
-                else b[f - 8] = lds[(base + f * 64) % (24 * 512 / 2)];
+                else if (!NGL) b[f - 8] = lds[(base + f * 64) % (24 * 512 / 2)];
             }
         }
     }
@@ -192,10 +211,11 @@ int main(int argc, char** argv) {
     const char* names[] = {"16x16x32", "32x32x16", "16x16x32 boustrophedon", "16x16x32 diagonal", "16x16x32 + 12 LDS reads / 32",
                            "16x16x32 + 8 LDS reads / 32", "16x16x32 + 4 LDS reads / 32", "+ 12 LDS reads + 4 DMA / 32 (L2)",
                            "+ 12 LDS reads + 4 DMA / 32 (HBM)", "+ 8 LDS reads + 4 DMA / 32 (L2)", "+ 0 LDS reads + 4 DMA / 32 (L2)",
-                           "1 wave/SIMD 128x128: MFMAs only", "1 wave/SIMD: + 16 reads / 64", "1 wave/SIMD: + 16 reads + 8 DMA / 64"};
+                           "1 wave/SIMD 128x128: MFMAs only", "1 wave/SIMD: + 16 reads / 64", "1 wave/SIMD: + 16 reads + 8 DMA / 64",
+                           "W from memory: 8 LDS reads + 2 DMA + 4 global loads / 32", "W from memory, boustrophedon", "12 LDS reads + 4 DMA, boustrophedon"};
     char* stream;
-    hipMalloc(&stream, (size_t)grid * (4u << 20));
-    hipMemset(stream, 0x3f, (size_t)grid * (4u << 20));
+    hipMalloc(&stream, (size_t)grid * (4u << 20) + (80u << 20));
+    hipMemset(stream, 0x3f, (size_t)grid * (4u << 20) + (80u << 20));
     const int nshape = argc > 4 ? atoi(argv[4]) : 2;
     for (int rep = 0; rep < 3; ++rep)
         for (int shape = 0; shape < nshape; ++shape) {
@@ -214,7 +234,10 @@ int main(int argc, char** argv) {
             else if (shape == 10) hipLaunchKernelGGL((mfma_lds_kernel<0, 0, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
             else if (shape == 11) hipLaunchKernelGGL((mfma_w4_kernel<0, 0>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
             else if (shape == 12) hipLaunchKernelGGL((mfma_w4_kernel<16, 0>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
-            else hipLaunchKernelGGL((mfma_w4_kernel<16, 8>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 13) hipLaunchKernelGGL((mfma_w4_kernel<16, 8>), g, dim3(256), 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 14) hipLaunchKernelGGL((mfma_lds_kernel<0, 8, 2, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
+            else if (shape == 15) hipLaunchKernelGGL((mfma_lds_kernel<1, 8, 2, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
+            else hipLaunchKernelGGL((mfma_lds_kernel<1, 12, 4>), g, b, 0, 0, src, out, iters, clk, stream, 65536u);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
@@ -223,7 +246,7 @@ int main(int argc, char** argv) {
             hipMemcpy(c.data(), clk, grid * 16, hipMemcpyDeviceToHost);
             double cyc = 0, wall = 0;
             for (int i = 0; i < grid; ++i) { cyc += c[2 * i]; wall += c[2 * i + 1]; }
-            const double flops = (double)grid * (shape >= 11 ? 4 : 8) * iters * 64.0 * 16384.0;  // 64 MFMA-equivalents of 16x16x32 per wave and iteration
+            const double flops = (double)grid * ((shape >= 11 && shape <= 13) ? 4 : 8) * iters * 64.0 * 16384.0;  // 64 MFMA-equivalents of 16x16x32 per wave and iteration
             printf("%-32s grid %d data %s: %.2f ms  %.0f TFLOP/s  shader clock %.0f MHz  (%.3f TFLOP/s per MHz)\n",
                    names[shape], grid, zero ? "zeros" : "random", ms, flops / ms * 1e-9,
                    cyc / wall * 100.0, flops / ms * 1e-9 / (cyc / wall * 100.0));

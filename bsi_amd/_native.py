@@ -166,6 +166,7 @@ _PROTOS = {
     "bsi_gemm_bf16": (_i, [C.POINTER(GemmArgs), _vp]),
     "bsi_gemm_splitk_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "bsi_gemm_splitk_f32_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "bsi_gemm_bf16_grouped": (_i, [C.POINTER(GemmArgs), _i, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "bsi_colsum_rows_scratch_bytes": (C.c_size_t, [_i, _i]),
     "bsi_colsum_rows_f32": (_i, [C.POINTER(ColsumJob), _i, _vp, _vp]),
     "bsi_gemm_bf16_ws": (_i, [C.POINTER(GemmArgs), _vp, C.c_size_t, _vp]),

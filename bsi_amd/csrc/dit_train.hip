@@ -221,13 +221,39 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
 
     // adaLN tables, keeping the intermediate activations (dit.py:77-81)
     TRY(bsi_nyquist_embed(t, B, w->t_scale, w->t_bias, dim, nullptr, tp.emb, stream));
-    for (int l = 0; l < d.depth; ++l) {
-        const bsi_dit_block_weights& bw = w->blocks[l];
-        float* pre = tp.ada_pre + (size_t)l * B * dim;
-        char* sl = tp.ada_s + (size_t)l * B * dim * 2;
-        TRY(gemm_rows(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, tp.skws, tp.skws_bytes, stream));
-        TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
-        TRY(gemm_rows(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, tp.skws, tp.skws_bytes, stream));
+    // The adaLN MLP of every block depends on t only.  When the blocks' matrices and biases lie at uniform strides (the model's cast
+    // plan allocates the shadows that way; the biases do when the parameters live in one flat buffer, as under DPTrainer) the 2 x depth
+    // per-sample GEMMs are TWO grouped launches; otherwise one split-K GEMM per block and matrix as before.
+    bool grouped = d.depth > 1 && dim >= 96;
+    ptrdiff_t sw0 = 0, sb0 = 0, sw2 = 0, sb2 = 0;
+    if (grouped) {
+        auto diff = [](const void* a, const void* b) { return reinterpret_cast<const char*>(a) - reinterpret_cast<const char*>(b); };
+        const bsi_dit_block_weights* bk = w->blocks;
+        sw0 = diff(bk[1].ada0_w, bk[0].ada0_w); sb0 = diff(bk[1].ada0_b, bk[0].ada0_b);
+        sw2 = diff(bk[1].ada2_w, bk[0].ada2_w); sb2 = diff(bk[1].ada2_b, bk[0].ada2_b);
+        for (int l = 1; l < d.depth && grouped; ++l)
+            grouped = diff(bk[l].ada0_w, bk[0].ada0_w) == l * sw0 && diff(bk[l].ada0_b, bk[0].ada0_b) == l * sb0 &&
+                      diff(bk[l].ada2_w, bk[0].ada2_w) == l * sw2 && diff(bk[l].ada2_b, bk[0].ada2_b) == l * sb2;
+        grouped = grouped && sw0 % 16 == 0 && sb0 % 16 == 0 && sw2 % 16 == 0 && sb2 % 16 == 0;
+    }
+    if (grouped) {
+        bsi_gemm_args g{};
+        g.A = tp.emb; g.W = w->blocks[0].ada0_w; g.bias = w->blocks[0].ada0_b; g.out = tp.ada_pre;
+        g.M = B; g.N = dim; g.K = dim; g.lda = dim; g.ldw = dim; g.ldo = dim; g.epilogue = BSI_EPI_BIAS_F32;
+        TRY(bsi_gemm_bf16_grouped(&g, d.depth, 0, (size_t)sw0, (size_t)sb0, (size_t)B * dim * 4, stream));
+        TRY(bsi_silu_bf16(tp.ada_pre, (size_t)d.depth * B * dim, tp.ada_s, stream));
+        g.A = tp.ada_s; g.W = w->blocks[0].ada2_w; g.bias = w->blocks[0].ada2_b; g.out = tp.mod;
+        g.N = 6 * dim; g.ldo = mod_stride;
+        TRY(bsi_gemm_bf16_grouped(&g, d.depth, (size_t)B * dim * 2, (size_t)sw2, (size_t)sb2, (size_t)6 * dim * 4, stream));
+    } else {
+        for (int l = 0; l < d.depth; ++l) {
+            const bsi_dit_block_weights& bw = w->blocks[l];
+            float* pre = tp.ada_pre + (size_t)l * B * dim;
+            char* sl = tp.ada_s + (size_t)l * B * dim * 2;
+            TRY(gemm_rows(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, tp.skws, tp.skws_bytes, stream));
+            TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
+            TRY(gemm_rows(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, tp.skws, tp.skws_bytes, stream));
+        }
     }
     TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin, d.nfreq, d.kpad, tp.a0, s));
     TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, block_tape(tp, d, B, 0).xa, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32,

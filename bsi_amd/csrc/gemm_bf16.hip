@@ -50,6 +50,10 @@ struct GemmParams {
     // split s multiplies the K range [s*kslice, (s+1)*kslice) and writes its partial sums to out + s*slab_stride floats
     int splits, kslice;
     size_t slab_stride;
+    // grouped launch (gemm_bf16_pring_kernel, fp32 epilogue, exclusive with splits): `groups` problems of one shape whose operands lie at
+    // uniform byte strides; workgroup tile index = group * tiles_m*tiles_n + tile
+    int groups;
+    size_t g_a, g_w, g_bias, g_out;
 };
 
 // tile index -> (tm, tn): the tiles are walked in bands of gm m-tiles, m fastest inside a band.  An XCD runs 32 consecutive tiles
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
     char* scratch = lds + R * SLOT_BYTES + wave * 4096;
 
     const int tiles_mn = p.tiles_m * p.tiles_n;
-    const int nwg = p.splits > 1 ? tiles_mn * p.splits : tiles_mn;
+    const int nwg = p.splits > 1 ? tiles_mn * p.splits : p.groups > 1 ? tiles_mn * p.groups : tiles_mn;
     const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
     const int wpx = (gridDim.x + 7 - xcd) >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
@@ -633,6 +637,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             t -= sp * tiles_mn;
             kbytes = (size_t)sp * p.kslice * 2;
         }
+        const char* Ab = reinterpret_cast<const char*>(p.A);
+        const char* Wb = reinterpret_cast<const char*>(p.W);
+        if (p.groups > 1) {
+            const int gp = t / tiles_mn;
+            t -= gp * tiles_mn;
+            Ab += (size_t)gp * p.g_a;
+            Wb += (size_t)gp * p.g_w;
+        }
         int tm_, tn_;
         tile_coords(p, t, tm_, tn_);
         const int m0 = tm_ * BM, n0 = tn_ * BN;
@@ -644,13 +656,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
                 const int c = spos ^ ((-(r >> 2)) & 3);
                 int m = m0 + r;
                 m = m < p.M ? m : p.M - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda) + c * 16 + kbytes;
+                gsrc[q] = Ab + (size_t)m * p.lda * 2 + c * 16 + kbytes;
             } else {
                 const int rw = (slot - 16) * 16 + srow;
                 const int c = spos ^ ((-(rw >> 4)) & 3);
                 int n = n0 + rw;
                 n = n < p.N ? n : p.N - 1;
-                gsrc[q] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + c * 16 + kbytes;
+                gsrc[q] = Wb + (size_t)n * p.ldw * 2 + c * 16 + kbytes;
             }
         }
     };
@@ -685,6 +697,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
             tile_coords(p, t - sp * tiles_mn, tm_, tn_);
             GemmParams q = p;
             q.out = reinterpret_cast<float*>(p.out) + (size_t)sp * p.slab_stride;
+            wave_tile_epilogue<EPI>(q, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
+            return;
+        }
+        if (p.groups > 1) {  // this group's output and bias
+            const int gp = t / tiles_mn;
+            tile_coords(p, t - gp * tiles_mn, tm_, tn_);
+            GemmParams q = p;
+            q.out = reinterpret_cast<char*>(p.out) + (size_t)gp * p.g_out;
+            if (p.bias) q.bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (size_t)gp * p.g_bias);
             wave_tile_epilogue<EPI>(q, acc, tm_ * BM + wm * TM * 16, tn_ * BN + wn * 64, lane, scratch);
             return;
         }
@@ -757,7 +778,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const GemmParams p
         if (wm == 0) epilogue(tile);  // group A: after that barrier, merged with its next L phase
         {   // the store allowance of the next phases is valid only if every store of the epilogue was issued (no M / N tail)
             int tm_, tn_;
-            tile_coords(p, p.splits > 1 ? tile % tiles_mn : tile, tm_, tn_);
+            tile_coords(p, (p.splits > 1 || p.groups > 1) ? tile % tiles_mn : tile, tm_, tn_);
             after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 2 : 0;
         }
         if (!has_next) break;
@@ -1212,6 +1233,41 @@ extern "C" int bsi_gemm_bf16(const bsi_gemm_args* a, bsi_stream_t stream) {
             bsi_set_error("bsi_gemm_bf16: unknown epilogue %d", a->epilogue);
             return BSI_EINVAL;
     }
+}
+
+// `groups` GEMMs of one shape in ONE launch of the K = 32 ring kernel (fp32 output): operands, bias and output of group g lie g strides
+// (bytes) behind those of `a`.  The per-sample adaLN matrices of the DiT blocks (M = images: 2 x N / 256 tiles each) fill the chip
+// together; one at a time each needed split-K slabs and a finishing pass to do so.  Same kernel and K order whatever M is.
+extern "C" int bsi_gemm_bf16_grouped(const bsi_gemm_args* a, int groups, size_t stride_a, size_t stride_w, size_t stride_bias, size_t stride_out,
+                                     bsi_stream_t stream) {
+    BSI_CHECK_ARG(a && a->A && a->W && a->out && groups >= 1 && groups <= 4096, "bsi_gemm_bf16_grouped: null operand or groups=%d", groups);
+    BSI_CHECK_ARG(a->epilogue == BSI_EPI_BIAS_F32, "bsi_gemm_bf16_grouped: fp32 output with bias (BSI_EPI_BIAS_F32) only, got %d", a->epilogue);
+    BSI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K >= 96 && a->K % BK == 0 && a->N % 16 == 0, "bsi_gemm_bf16_grouped: M=%d N=%d K=%d (K >= 96, K %% %d == 0, N %% 16 == 0)",
+                  a->M, a->N, a->K, BK);
+    BSI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldo % 4 == 0 && a->ldo >= a->N,
+                  "bsi_gemm_bf16_grouped: bad leading dimensions lda=%d ldw=%d ldo=%d", a->lda, a->ldw, a->ldo);
+    BSI_CHECK_ARG(stride_a % 16 == 0 && stride_w % 16 == 0 && stride_bias % 16 == 0 && stride_out % 16 == 0, "bsi_gemm_bf16_grouped: strides must be multiples of 16 bytes");
+    GemmParams p{};
+    p.A = reinterpret_cast<const __bf16*>(a->A);
+    p.W = reinterpret_cast<const __bf16*>(a->W);
+    p.bias = a->bias;
+    p.out = a->out;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
+    p.tokens = 1;
+    p.groups = groups; p.g_a = stride_a; p.g_w = stride_w; p.g_bias = stride_bias; p.g_out = stride_out;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
+    if (p.gm < 1) p.gm = 1;
+    const int nwg = p.tiles_m * p.tiles_n * (groups > 1 ? groups : 1);
+    const int grid = nwg < compute_cus() ? nwg : compute_cus();
+    const size_t lds = 4 * (size_t)512 * 64 + 32768;
+    auto kern = gemm_bf16_pring_kernel<BSI_EPI_BIAS_F32>;
+    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+    BSI_CHECK_LAUNCH("bsi_gemm_bf16_grouped");
+    return BSI_OK;
 }
 
 extern "C" size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K) {

@@ -149,12 +149,13 @@ class DenoisingDiT(nn.Module):
         kpad = lib.bsi_dit_kpad(C.byref(cfg))
         keep, descs = [], []
 
-        def shadow(w: Tensor, ld=None):
+        def shadow(w: Tensor, ld=None, out=None):
             w = w.detach()
             assert w.is_contiguous()
             rows, cols = w.shape
             ld = ld or cols
-            out = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+            if out is None:
+                out = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
             keep.extend([w, out])
             descs.append([w, out, None, rows, cols, ld, 0])
             return out.data_ptr()
@@ -165,6 +166,10 @@ class DenoisingDiT(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        # the adaLN matrices of all blocks in one buffer each: uniform strides let the engine run them as one grouped GEMM
+        dim_ = self._cfg_args["dim"]
+        ada0_all = torch.empty((cfg.depth, dim_, dim_), dtype=torch.bfloat16, device=dev)
+        ada2_all = torch.empty((cfg.depth, 6 * dim_, dim_), dtype=torch.bfloat16, device=dev)
         blocks = (N.DitBlockWeights * cfg.depth)()
         for i, blk in enumerate(self.dit.blocks):
             b = blocks[i]
@@ -172,8 +177,8 @@ class DenoisingDiT(nn.Module):
             b.out_w, b.out_b = shadow(blk.attn.to_out.weight), f32(blk.attn.to_out.bias)
             b.fc1_w, b.fc1_b = shadow(blk.mlp[0].weight), f32(blk.mlp[0].bias)
             b.fc2_w, b.fc2_b = shadow(blk.mlp[2].weight), f32(blk.mlp[2].bias)
-            b.ada0_w, b.ada0_b = shadow(blk.adaLN_modulation[0].weight), f32(blk.adaLN_modulation[0].bias)
-            b.ada2_w, b.ada2_b = shadow(blk.adaLN_modulation[2].weight), f32(blk.adaLN_modulation[2].bias)
+            b.ada0_w, b.ada0_b = shadow(blk.adaLN_modulation[0].weight, out=ada0_all[i]), f32(blk.adaLN_modulation[0].bias)
+            b.ada2_w, b.ada2_b = shadow(blk.adaLN_modulation[2].weight, out=ada2_all[i]), f32(blk.adaLN_modulation[2].bias)
         w = N.DitWeights()
         w.enc_w, w.enc_b = shadow(self.dit.patch_encoder.weight, kpad), f32(self.dit.patch_encoder.bias)
         w.pos = f32(self.dit.patch_pos_embedding)

@@ -228,6 +228,10 @@ int bsi_gemm_bf16(const bsi_gemm_args* a /*host*/, bsi_stream_t stream);
  * tiles does not walk its whole K loop on a handful of CUs; otherwise (or with too small a workspace) it is bsi_gemm_bf16.
  * bsi_gemm_splitk_workspace_bytes returns the bytes that make the split possible for a shape (0 = never split). */
 size_t bsi_gemm_splitk_workspace_bytes(int M, int N, int K);
+/* `groups` GEMMs of one shape (a->M, N, K, leading dimensions; epilogue BSI_EPI_BIAS_F32) in one launch: A, W, bias and out of group g
+ * lie g * stride bytes behind those of `a` (stride_a = 0: a shared A).  dit.py:77-81 for all blocks at once: the adaLN MLP depends on t only. */
+int bsi_gemm_bf16_grouped(const bsi_gemm_args* a, int groups, size_t stride_a, size_t stride_w, size_t stride_bias, size_t stride_out,
+                          bsi_stream_t stream);
 /* The same for BSI_EPI_BIAS_F32 on per-sample GEMMs (M <= 2048 rows, K >= 1024: the adaLN MLP of a train step, dit.py:77-81): the
  * slice count depends on K only, so a result does not depend on how many rows were computed with it. */
 size_t bsi_gemm_splitk_f32_workspace_bytes(int M, int N, int K);

@@ -466,6 +466,42 @@ def test_gemm_split_k_small_m(N, M, Nn, K):
         assert float(((outs[0] - outs[2]).abs() / (outs[2].abs() + 0.05)).max()) < 1.6e-2  # split vs ordinary: a bf16 ulp
 
 
+@pytest.mark.parametrize("M,Nn,K,G,shared_a", [(512, 1024, 1024, 5, True), (512, 768, 256, 3, False), (8, 512, 1024, 4, False), (200, 320, 192, 2, True)])
+def test_gemm_grouped_matches_one_launch_per_group(N, M, Nn, K, G, shared_a):
+    """bsi_gemm_bf16_grouped: G problems of one shape (the per-sample adaLN matrices of the DiT blocks: shared or per-group A, per-group W,
+    bias and output at uniform byte strides, the output strided inside a wider table) in one launch against fp64, bit-identical to one
+    bsi_gemm_bf16 launch per group where that runs the same kernel (M > 128), and with every row independent of the batch it sits in
+    (rows of an M = 8 call equal the same rows inside the M-row call)."""
+    gen = torch.Generator().manual_seed(M + Nn + K + G)
+    A = bf16r(torch.randn((1 if shared_a else G, M, K), generator=gen))
+    W = bf16r(torch.randn((G, Nn, K), generator=gen) / math.sqrt(K))
+    bias = torch.randn((G, Nn), generator=gen)
+    dA, dW, db = dev(A.to(torch.bfloat16)), dev(W.to(torch.bfloat16)), dev(bias)
+    out = torch.full((M, G * Nn + 8), float("nan"), device=DEV)  # group g: columns g * Nn .. of a wider table (the adaLN chunk table)
+    ld = G * Nn + 8
+    a = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K, ldo=ld,
+                   epilogue=N.EPI_BIAS_F32)
+    N.check(N.lib().bsi_gemm_bf16_grouped(C.byref(a), G, 0 if shared_a else M * K * 2, Nn * K * 2, Nn * 4, Nn * 4, N.stream()))
+    for g in range(G):
+        ref = A[0 if shared_a else g].double() @ W[g].double().t() + bias[g].double()
+        got = out[:, g * Nn:(g + 1) * Nn]
+        assert rel_linf(got, ref) < 2e-5, (g, rel_linf(got, ref))
+        if M > 128 and K >= 96:
+            one = torch.empty((M, Nn), device=DEV)
+            b = N.GemmArgs(A=dA[0 if shared_a else g].data_ptr(), W=dW[g].data_ptr(), bias=db[g].data_ptr(), out=one.data_ptr(), M=M, N=Nn, K=K,
+                           lda=K, ldw=K, ldo=Nn, epilogue=N.EPI_BIAS_F32)
+            N.check(N.lib().bsi_gemm_bf16(C.byref(b), N.stream()))
+            assert torch.equal(one, got.contiguous())
+    assert torch.isnan(out[:, G * Nn:]).all()
+    if M >= 16:  # batch independence: the first 8 rows as a call of their own
+        small = torch.empty((8, ld), device=DEV)
+        a8 = N.GemmArgs(A=dA.data_ptr(), W=dW.data_ptr(), bias=db.data_ptr(), out=small.data_ptr(), M=8, N=Nn, K=K, lda=K, ldw=K, ldo=ld,
+                        epilogue=N.EPI_BIAS_F32)
+        N.check(N.lib().bsi_gemm_bf16_grouped(C.byref(a8), G, 0 if shared_a else M * K * 2, Nn * K * 2, Nn * 4, Nn * 4, N.stream()))
+        assert torch.equal(small[:, :G * Nn], out[:8, :G * Nn])
+    assert N.lib().bsi_gemm_bf16_grouped(C.byref(a), G, 8, Nn * K * 2, Nn * 4, Nn * 4, N.stream()) != 0  # stride not a multiple of 16
+
+
 @pytest.mark.parametrize("Nn,K", [(1024, 1024), (6144, 1024), (1024, 6144)])
 def test_gemm_split_k_fp32_per_sample_rows(N, Nn, K):
     """The per-sample GEMMs of the train step (adaLN MLP, dit.py:77-81: M = images) with the fp32 epilogue through bsi_gemm_bf16_ws:

@@ -50,8 +50,13 @@ class DiT(nn.Module):
         return self.dec(F.layer_norm(x, (dim,)))
 
 
+import os
 torch.manual_seed(0)
 m = DiT().to(dev)
+MODE = "eager"
+if os.environ.get("COMPILE"):  # the reference's `compile: true` option (bsi/tasks/bsi.py:91): torch.compile of the loss / sampling functions
+    m = torch.compile(m)
+    MODE = "torch.compile"
 tok = torch.randn((B, T, KIN), device=dev)
 t = torch.rand(B, device=dev)
 # ---- sampling yardstick
@@ -62,7 +67,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
     n = 20
     for _ in range(n): y = m(tok, t)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"torch eager, bf16 autocast, DiT-L/2 forward at {B} images: {1e3 * dt:.1f} ms per evaluation -> {B / (129 * dt):.1f} images/s at 129 evaluations per image")
+print(f"torch {MODE}, bf16 autocast, DiT-L/2 forward at {B} images: {1e3 * dt:.1f} ms per evaluation -> {B / (129 * dt):.1f} images/s at 129 evaluations per image")
 # ---- training yardstick
 m.train()
 opt = torch.optim.AdamW(m.parameters(), lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, fused=True)
@@ -82,4 +87,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5
 for _ in range(n): loss = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"torch eager, bf16 autocast, DiT-L/2 train step (fwd + bwd + clip + fused AdamW + EMA) at batch {B}: {1e3 * dt:.1f} ms -> {1 / dt:.2f} steps/s  (peak memory {torch.cuda.max_memory_allocated() / 2**30:.0f} GiB)")
+print(f"torch {MODE}, bf16 autocast, DiT-L/2 train step (fwd + bwd + clip + fused AdamW + EMA) at batch {B}: {1e3 * dt:.1f} ms -> {1 / dt:.2f} steps/s  (peak memory {torch.cuda.max_memory_allocated() / 2**30:.0f} GiB)")

@@ -372,6 +372,55 @@ def secondary_bench(a, bsi, dev, budget_s):
     entry("dit_l2_sample_256_device_noise", 12, dit_batch(256, device_noise=True))
     entry("vdm_unet", 25, unet)
     entry("dit_l4_64x64_k256", 40, dit64)
+
+    def torch_yardstick():
+        """What plain PyTorch (eager, bf16 autocast, nn.Linear / F.scaled_dot_product_attention / F.layer_norm -- the way the
+        reference runs its DiT) needs for one denoiser evaluation of the headline workload on THIS GPU, measured live: a yardstick
+        for `value`, not a parity check (random weights, no wrapper ops).  tools/experiments/torch_yardstick.py has the train step
+        and the torch.compile arm."""
+        import torch.nn as nn
+        import torch.nn.functional as F
+        dim, depth, heads, T, kin, P = 1024, 24, 16, 256, 84, 12
+
+        class Blk(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.qkv, self.out = nn.Linear(dim, 3 * dim), nn.Linear(dim, dim)
+                self.fc1, self.fc2 = nn.Linear(dim, 4 * dim), nn.Linear(4 * dim, dim)
+                self.ada = nn.Sequential(nn.Linear(dim, dim), nn.SiLU(), nn.Linear(dim, 6 * dim))
+
+            def forward(self, x, c):
+                sa, ca, ga, sm, cm, gm = self.ada(c).unsqueeze(1).chunk(6, dim=-1)
+                h = F.layer_norm(x, (dim,)) * (1 + ca) + sa
+                q, k, v = self.qkv(h).reshape(x.shape[0], T, 3, heads, dim // heads).permute(2, 0, 3, 1, 4)
+                a_ = F.scaled_dot_product_attention(q, k, v)
+                x = torch.addcmul(x, ga, self.out(a_.transpose(1, 2).reshape(x.shape[0], T, dim)))
+                h = F.layer_norm(x, (dim,)) * (1 + cm) + sm
+                return torch.addcmul(x, gm, self.fc2(F.gelu(self.fc1(h), approximate="tanh")))
+
+        class Net(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.enc, self.dec = nn.Linear(kin, dim), nn.Linear(dim, P)
+                self.blocks = nn.ModuleList(Blk() for _ in range(depth))
+                self.tw = nn.Parameter(torch.randn(dim))
+
+            def forward(self, tok, t_):
+                c = torch.sin(t_[:, None] * self.tw)
+                x = self.enc(tok)
+                for blk in self.blocks:
+                    x = blk(x, c)
+                return self.dec(F.layer_norm(x, (dim,)))
+
+        b = 512
+        net = Net().to(dev).eval()
+        tok, t_ = torch.randn((b, T, kin), device=dev), torch.rand(b, device=dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            dt, _ = timed(lambda: net(tok, t_), lambda: net(tok, t_), reps=5)
+        return {"workload": "DiT-L/2 forward in plain PyTorch (eager, bf16 autocast, SDPA), 512 images, one evaluation", "ms_per_evaluation": 1e3 * dt,
+                "images_per_s_at_129_evaluations": b / (129 * dt), "note": "yardstick on this GPU for the headline value; not the reference's code"}
+
+    entry("torch_eager_yardstick", 20, torch_yardstick)
     out["seconds"] = time.perf_counter() - t_start
     return out
 

@@ -79,7 +79,10 @@ def parse():
                     help="(internal) run only the secondary block and print its JSON: the main process starts this as a fresh child "
                          "so that a hang or a GPU fault in a secondary kernel cannot take the measured headline with it")
     ap.add_argument("--launch-timeout", type=int, default=3600, help="seconds before a self-launched multi-rank run is abandoned")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.cu_reserve < 0 or a.cu_reserve % 8 or a.cu_reserve > 64:
+        ap.error("--cu-reserve must be 0 or a multiple of 8 up to 64 (bsi_set_cu_reserve)")
+    return a
 
 
 def build_model(dev):
@@ -159,18 +162,80 @@ def cpu_baseline(k, reps=3):
                       "evaluations per image"}
 
 
+def _timed_train(tr, x, g, n, barrier, dev, world):
+    """n optimizer steps between barriers; max over ranks; (seconds, (fwd+bwd+exchange ms, optimizer ms), last loss)."""
+    tr.stage_ms()
+    tr.time_stages = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = tr.train_step(x, g)
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = tr.stage_ms()
+    tr.time_stages = False
+    if world > 1:
+        tm = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tm.item())
+    return dt, stages, loss
+
+
+def _without_exchange(tr, x, g, n, barrier, dev):
+    """The same steps WITHOUT the gradient exchange (compute alone).  Those steps would apply each rank's own gradient / world and
+    let the replicas drift apart, so the trainer's state (parameters, moments, EMA, step count) is snapshotted and restored."""
+    bufs = [tr.fp.flat, tr.m, tr.v] + ([tr.ema_fp.flat] if tr.ema_fp else [])
+    snap = [t.clone() for t in bufs]
+    step0, ex = tr.step_count, tr.exchange
+    tr.exchange = False
+    try:
+        tr.train_step(x, g)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            tr.train_step(x, g)
+        barrier()
+        d2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(d2, op=torch.distributed.ReduceOp.MAX)
+    finally:
+        tr.exchange = ex
+        for dst, src in zip(bufs, snap):
+            dst.copy_(src)
+        tr.step_count = step0
+        tr.stage_ms()
+    return 1e3 * float(d2.item()) / n
+
+
+def _bucket_busbw(dev, world, barrier, elems=20 * 1024 * 1024, reps=5):
+    """Ring bus bandwidth of ONE gradient bucket (80 MB fp32, the size of a DiT-L/2 block's bucket) all-reduced in isolation."""
+    t = torch.ones(elems, dtype=torch.float32, device=dev)
+    torch.distributed.all_reduce(t)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.distributed.all_reduce(t)
+    barrier()
+    sec = (time.perf_counter() - t0) / reps
+    return {"bytes": 4 * elems, "ms": 1e3 * sec, "busbw_GBps": 2 * (world - 1) / world * 4 * elems / 1e9 / sec}
+
+
 def train_bench(a, bsi, model, dev, world, rank, barrier):
     """Second half of the BASELINE metric: optimizer steps/s of the ImageNet32 DiT-L/2 recipe
     (config/experiment/imagenet32.yaml: global batch 512, AdamW lr 5e-4 betas (0.9, 0.99) wd 1e-2, dropout 0.05,
-    clip 1.0, EMA, warm-up + cosine LR) — BSI.train_loss forward + hand-written backward + gradient all-reduce over
-    RCCL + fused clip/AdamW/EMA.  The global batch is split per rank as bsi/data/h5image.py:312 (strong scaling)."""
+    clip 1.0, EMA, warm-up + cosine LR) — BSI.train_loss forward + hand-written backward + gradient exchange over
+    RCCL + fused clip/AdamW/EMA.  The global batch is split per rank as bsi/data/h5image.py:312 (strong scaling).
+
+    N > 1: the step is measured in three variants so that the first hardware run can be read -- all-reduce with the CU reserve off,
+    all-reduce with `--cu-reserve` CUs left to RCCL during the backward, and the sharded step (reduce-scatter / slice update /
+    all-gather) -- each with the same steps without the exchange (exposed communication = the difference); `value` is the fastest
+    all-reduce variant, named in `headline_variant`.  Plus the bus bandwidth of one 80 MB bucket all-reduced in isolation and the
+    RCCL channel cap in force."""
     from bsi_amd.dp import DPTrainer, split_batch, warmup_cosine_lr
 
     nb = split_batch(a.train_batch, world, rank)
     model.train()
     sched = lambda s: warmup_cosine_lr(s, base_lr=5e-4, warmup_steps=1000, max_steps=1000000, start_lr=1e-8, end_lr=5e-5)  # noqa: E731
-    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, lr_schedule=sched,
-                   cu_reserve=a.cu_reserve if world > 1 else 0)
+    recipe = dict(lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, lr_schedule=sched)
     g = torch.Generator(dev).manual_seed(99 + rank)
 
     def images(n):
@@ -178,88 +243,79 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
         return (torch.round(255 * u) / 255) * 2 - 1    # synthetic 8-bit images in [-1, 1]
 
     x = images(nb)
-    loss = tr.train_step(x, g)                          # warm-up (also builds the transposed weight shadows)
-    tr.time_stages = True
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.train_steps):
-        loss = tr.train_step(x, g)
-    barrier()
-    dt = time.perf_counter() - t0
-    stages = tr.stage_ms()
+    variants = [("allreduce", dict(cu_reserve=0))]
     if world > 1:
-        tm = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tm.item())
-    assert torch.isfinite(loss)
+        if a.cu_reserve:
+            variants.append((f"allreduce_cu_reserve_{a.cu_reserve}", dict(cu_reserve=a.cu_reserve)))
+        variants.append(("sharded_update", dict(cu_reserve=0, shard_update=True)))
+    runs, comm_runs = {}, {}
+    for i, (name, kw) in enumerate(variants):
+        try:
+            tr = DPTrainer(bsi, **recipe, **kw)
+            loss = tr.train_step(x, g)                      # warm-up (also builds the transposed weight shadows)
+            dt, stages, loss = _timed_train(tr, x, g, a.train_steps, barrier, dev, world)
+            assert torch.isfinite(loss)
+            runs[name] = {"ms_per_step": 1e3 * dt / a.train_steps, "fwd_bwd_exchange_ms": stages[0] if stages else None,
+                          "optimizer_ms": stages[1] if stages else None, "loss": float(loss)}
+            if world > 1:
+                ms_no = _without_exchange(tr, x, g, max(1, min(3, a.train_steps)), barrier, dev)
+                comm_runs[name] = {"ms_per_step": runs[name]["ms_per_step"], "ms_per_step_without_exchange": ms_no,
+                                   "exposed_comm_ms": runs[name]["ms_per_step"] - ms_no, "optimizer_ms": runs[name]["optimizer_ms"]}
+            nbytes = 4 * tr.fp.flat.numel()
+            nbuckets = len(tr.xchg.plan)
+            del tr
+        except Exception as e:  # noqa: BLE001  (every rank runs the same code on the same inputs: a variant fails on all ranks or none)
+            if i == 0:
+                raise
+            runs[name] = comm_runs[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    head = min((n for n in runs if n.startswith("allreduce") and "error" not in runs[n]), key=lambda n: runs[n]["ms_per_step"])
+    ms = runs[head]["ms_per_step"]
     comm = None
     if world > 1:
-        # communication breakdown (so that a multi-GPU number comes with a diagnosis): the same steps WITHOUT the gradient
-        # exchange.  Those steps would apply each rank's own gradient / world and let the replicas drift apart, so the
-        # trainer's state (parameters, moments, EMA, step count) is snapshotted before and restored after them.
-        n2 = max(1, min(3, a.train_steps))
-        snap = [t.clone() for t in (tr.fp.flat, tr.m, tr.v)] + ([tr.ema_fp.flat.clone()] if tr.ema_fp else [])
-        step0 = tr.step_count
-        tr.exchange = False
-        tr.train_step(x, g)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n2):
-            tr.train_step(x, g)
-        barrier()
-        d2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(d2, op=torch.distributed.ReduceOp.MAX)
-        tr.exchange = True
-        for dst, src in zip([tr.fp.flat, tr.m, tr.v] + ([tr.ema_fp.flat] if tr.ema_fp else []), snap):
-            dst.copy_(src)
-        tr.step_count = step0
-        tr.stage_ms()
-        del snap
-        ms_no = 1e3 * float(d2.item()) / n2
-        nbytes = 4 * tr.fp.flat.numel()
-        exposed = 1e3 * dt / a.train_steps - ms_no
-        comm = {"allreduce_bytes": nbytes, "buckets": len(tr.xchg.plan), "cu_reserve": tr.cu_reserve,
+        c = comm_runs[head]
+        comm = {"allreduce_bytes": nbytes, "buckets": nbuckets, "cu_reserve": a.cu_reserve if "cu_reserve" in head else 0,
                 "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
-                "ms_per_step_without_exchange": ms_no, "exposed_comm_ms": exposed,
-                # a lower bound of the ring bus bandwidth, meaningful only when a measurable part of the exchange is exposed
-                "ring_busbw_GBps_if_fully_exposed": ((2 * (world - 1) / world * nbytes / 1e9) / (exposed * 1e-3)) if exposed > 0.5 else None}
+                "ms_per_step_without_exchange": c["ms_per_step_without_exchange"], "exposed_comm_ms": c["exposed_comm_ms"],
+                "variants": comm_runs, "bucket_allreduce_alone": _bucket_busbw(dev, world, barrier)}
     per_rank = None
     if world == 1 and a.train_batch >= 8:
         # The per-rank workloads of the multi-GPU configurations (BASELINE configs[3]: the global batch split over 2 / 4 / 8
         # ranks, bsi/data/h5image.py:309-312), measured on this one GPU: the compute half of the 2- / 4- / 8-GPU step, with and
-        # without the CU reserve the data-parallel step runs under, optimizer time split out (it does not shrink with the shard).
-        per_rank = []
-        for w_ in (2, 4, 8):
-            b_ = a.train_batch // w_
-            xs = images(b_)
-            rec = {"world": w_, "per_gpu_batch": b_}
-            for key, r_ in (("", 0), ("_cu_reserve", a.cu_reserve)):
-                tr.cu_reserve = r_
-                tr.train_step(xs, g)
-                tr.stage_ms()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                n_ = max(3, min(a.train_steps, 5))
-                for _ in range(n_):
+        # without the CU reserve, and the optimizer as that rank of a sharded step runs it (1 / world of every bucket; the
+        # replicated optimizer is `optimizer_ms` of the headline).  Isolated: a failure here leaves the headline untouched.
+        try:
+            per_rank = []
+            for w_ in (2, 4, 8):
+                b_ = a.train_batch // w_
+                xs = images(b_)
+                rec = {"world": w_, "per_gpu_batch": b_, "cu_reserve": a.cu_reserve}
+                for key, r_ in (("", 0), ("_cu_reserve", a.cu_reserve)):
+                    if key and not r_:
+                        continue
+                    tr = DPTrainer(bsi, **recipe, cu_reserve=r_, rehearse=(w_, 0), shard_update=True)
                     tr.train_step(xs, g)
-                torch.cuda.synchronize()
-                ms = 1e3 * (time.perf_counter() - t1) / n_
-                fb, opt = tr.stage_ms()
-                rec["ms_per_step" + key] = ms
-                rec["fwd_bwd_ms" + key] = fb
-                rec["optimizer_ms" + key] = opt
-            rec["cu_reserve"] = a.cu_reserve
-            rec["model_tflops"] = b_ * 3 * FWD_GFLOP_PER_IMG / rec["ms_per_step"]
-            per_rank.append(rec)
-        tr.cu_reserve = 0
+                    n_ = max(3, min(a.train_steps, 5))
+                    dt_, st_, _ = _timed_train(tr, xs, g, n_, barrier, dev, 1)
+                    rec["ms_per_step" + key] = 1e3 * dt_ / n_
+                    rec["fwd_bwd_ms" + key] = st_[0]
+                    rec["optimizer_ms_sharded" + key] = st_[1]
+                    del tr
+                    torch.cuda.empty_cache()
+                rec["optimizer_ms_replicated"] = runs[head]["optimizer_ms"]
+                rec["model_tflops"] = b_ * 3 * FWD_GFLOP_PER_IMG / rec["ms_per_step"]
+                per_rank.append(rec)
+        except Exception as e:  # noqa: BLE001
+            per_rank = {"error": f"{type(e).__name__}: {e}"}
     model.eval()
-    steps_per_s = a.train_steps / dt
+    steps_per_s = 1e3 / ms
     return {"comm": comm, "metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+all-reduce+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
-            "value": steps_per_s, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.train_steps, "global_batch": a.train_batch,
+            "value": steps_per_s, "unit": "steps/s", "ms_per_step": ms, "global_batch": a.train_batch, "headline_variant": head,
             "per_gpu_batch": nb, "images_per_s": steps_per_s * a.train_batch, "scaling": "strong",
             "model_tflops_per_gpu": steps_per_s * a.train_batch * 3 * FWD_GFLOP_PER_IMG / 1e3 / world,
-            "fwd_bwd_exchange_ms": stages[0] if stages else None, "optimizer_ms": stages[1] if stages else None,
-            "per_rank_workloads_on_one_gpu": per_rank, "loss": float(loss)}
+            "fwd_bwd_exchange_ms": runs[head]["fwd_bwd_exchange_ms"], "optimizer_ms": runs[head]["optimizer_ms"],
+            "variants": runs if world > 1 else None,
+            "per_rank_workloads_on_one_gpu": per_rank, "loss": runs[head]["loss"]}
 
 
 def secondary_bench(a, bsi, dev, budget_s):
@@ -368,6 +424,7 @@ def secondary_bench(a, bsi, dev, budget_s):
 
     entry("dit_l2_elbo", 10, elbo)
     entry("dit_l2_sample_256", 12, dit_batch(256))
+    entry("dit_l2_sample_128", 8, dit_batch(128))
     entry("dit_l2_sample_64", 6, dit_batch(64))
     entry("dit_l2_sample_256_device_noise", 12, dit_batch(256, device_noise=True))
     entry("vdm_unet", 25, unet)
@@ -446,6 +503,39 @@ def secondary_in_child(a):
         return json.loads(out.decode().strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def summary(line):
+    """The numbers a reader of the line's TAIL must not miss (the driver keeps the last 2000 characters): sampling value, the train
+    half of the metric, the per-rank rehearsal, the secondary values -- compact, last key of the line."""
+    def get(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+
+    def r2(v):
+        return round(v, 2) if isinstance(v, (int, float)) else v
+
+    tr, sec = line.get("train") or {}, line.get("secondary") or {}
+    pr = tr.get("per_rank_workloads_on_one_gpu")
+    out = {"sample_images_per_s": r2(line.get("value")), "sample_frac_of_peak": r2(line.get("model_frac_of_peak")),
+           "fc1_roofline_frac": round(get(line, "roofline", "frac") or 0, 3), "n_gpus": line.get("n_gpus"),
+           "train_steps_per_s": r2(tr.get("value")), "train_ms_per_step": r2(tr.get("ms_per_step")),
+           "train_frac_of_peak": r2((tr.get("model_tflops_per_gpu") or 0) / PEAK_BF16_TFLOPS) if tr.get("value") else None,
+           "train_optimizer_ms": r2(tr.get("optimizer_ms")), "train_error": tr.get("error"),
+           "train_variants_ms": {k: r2(v.get("ms_per_step")) for k, v in (tr.get("variants") or {}).items()} or None,
+           "exposed_comm_ms": r2(get(tr, "comm", "exposed_comm_ms")),
+           "bucket_busbw_GBps": r2(get(tr, "comm", "bucket_allreduce_alone", "busbw_GBps")),
+           # per rank of a 2 / 4 / 8-GPU step on this one GPU: [world, fwd+bwd ms, fwd+bwd ms under the CU reserve, sharded optimizer ms]
+           "per_rank_ms": [[r["world"], r2(r.get("fwd_bwd_ms")), r2(r.get("fwd_bwd_ms_cu_reserve")), r2(r.get("optimizer_ms_sharded"))]
+                           for r in pr] if isinstance(pr, list) else pr,
+           "sample_256_128_64": [r2(get(sec, k, "value")) for k in ("dit_l2_sample_256", "dit_l2_sample_128", "dit_l2_sample_64")],
+           "elbo_images_per_s": r2(get(sec, "dit_l2_elbo", "value")),
+           "unet_images_per_s": r2(get(sec, "vdm_unet", "sample", "value")), "unet_train_steps_per_s": r2(get(sec, "vdm_unet", "train", "value")),
+           "dit64_images_per_s": r2(get(sec, "dit_l4_64x64_k256", "value")),
+           "torch_eager_images_per_s": r2(get(sec, "torch_eager_yardstick", "images_per_s_at_129_evaluations")),
+           "cpu_images_per_s": round(get(line, "cpu_baseline", "value") or 0, 4)}
+    return out
 
 
 def launch_ranks(a, command=None):
@@ -651,6 +741,7 @@ def main():
         # (wall_seconds_gpu_idle above) and while the secondary child starts; `value` is timed between barriers around the calls only
         line["wall_note"] = ("value / ms_per_step are timed around the sampling calls; model construction, the CPU baseline "
                              "(cpu_baseline.wall_seconds_gpu_idle) and process start-up of the secondary child run with the GPU idle")
+        line["summary"] = summary(line)  # LAST key: a reader that keeps only the tail of the line still sees both halves of the metric
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

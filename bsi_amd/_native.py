@@ -32,6 +32,10 @@ class CastDesc(C.Structure):
                 ("ld_t", C.c_int), ("tile0", C.c_int), ("reserved", C.c_int)]
 
 
+class Seg(C.Structure):  # bsi_seg (include/bsi_hip.h)
+    _fields_ = [("p_off", C.c_size_t), ("g_off", C.c_size_t), ("len", C.c_size_t), ("my_chunk", C.c_size_t), ("out_chunk", C.c_size_t)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("out", C.c_void_p)]
 
@@ -243,6 +247,9 @@ _PROTOS = {
     "bsi_dit_adaln": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                              _vp, _vp, _vp, _vp]),
+    "bsi_sqnorm_segments": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),
+    "bsi_sqnorm_finish": (_i, [_vp, _sz, _vp, _vp]),
+    "bsi_clip_adamw_ema_segments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "bsi_clock_probe": (_i, [_vp, _i, _vp]),
     "bsi_set_cu_reserve": (_i, [_i]),
     "bsi_compute_cus": (_i, []),

@@ -60,6 +60,13 @@ struct Tape {
     size_t block_bytes, total;
 };
 
+// The dropout-mask words of the attention weights (8 KB per (image, head) and block) exist only for the geometry whose attention
+// kernels consume them (bsi_attention_uses_mask_words: 256 tokens, head dim 64); elsewhere the region is empty and BlockTape::maskw
+// is NULL, so no kernel can read words that were never written (forward and backward carve the tape with this one function).
+inline size_t mask_words_bytes(const Dims& d, int B) {
+    return bsi_attention_uses_mask_words(d.tokens, 64) ? au((size_t)B * d.heads * 8192) : 0;
+}
+
 inline Tape carve_tape(const Dims& d, int B, void* base) {
     Tape t;
     char* p = reinterpret_cast<char*>(base);
@@ -78,7 +85,7 @@ inline Tape carve_tape(const Dims& d, int B, void* base) {
     }
     t.blocks = p + off;
     t.block_bytes = au(M * dim * 2) * 5 + au(M * 3 * dim * 2) + au(M * 4 * dim * 2) * 2 + au((size_t)B * d.heads * d.tokens * 4) +
-                    au(M * dim * 4) * 2 + au(M * 2 * 4) * 2 + au((size_t)B * d.heads * 8192);
+                    au(M * dim * 4) * 2 + au(M * 2 * 4) * 2 + mask_words_bytes(d, B);
     off += t.block_bytes * d.depth;
     t.total = off;
     return t;
@@ -102,7 +109,7 @@ inline BlockTape block_tape(const Tape& t, const Dims& d, int B, int l) {
     b.xb = reinterpret_cast<float*>(p + off); off += au(M * dim * 4);
     b.sa = reinterpret_cast<float*>(p + off); off += au(M * 2 * 4);
     b.sb = reinterpret_cast<float*>(p + off); off += au(M * 2 * 4);
-    b.maskw = p + off;
+    b.maskw = mask_words_bytes(d, B) ? p + off : nullptr;
     return b;
 }
 
@@ -234,7 +241,8 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         for (int l = 1; l < d.depth && grouped; ++l)
             grouped = diff(bk[l].ada0_w, bk[0].ada0_w) == l * sw0 && diff(bk[l].ada0_b, bk[0].ada0_b) == l * sb0 &&
                       diff(bk[l].ada2_w, bk[0].ada2_w) == l * sw2 && diff(bk[l].ada2_b, bk[0].ada2_b) == l * sb2;
-        grouped = grouped && sw0 % 16 == 0 && sb0 % 16 == 0 && sw2 % 16 == 0 && sb2 % 16 == 0;
+        // positive strides only: they travel as size_t (a block order that runs DOWN in memory takes the per-block path)
+        grouped = grouped && sw0 > 0 && sb0 > 0 && sw2 > 0 && sb2 > 0 && sw0 % 16 == 0 && sb0 % 16 == 0 && sw2 % 16 == 0 && sb2 % 16 == 0;
     }
     if (grouped) {
         bsi_gemm_args g{};

@@ -52,35 +52,66 @@ def ema_weight(call_index: int, *, beta: float = 0.9999, update_after_step: int 
     return 1.0 - decay
 
 
+SEG_ALIGN = 4            # elements: every slice of the flat buffers starts and ends on a 16-byte boundary (float4 kernels, RCCL)
+SQNORM_CHUNK = 16384     # = BSI_SQNORM_CHUNK (include/bsi_hip.h): elements per partial of the squared gradient norm
+
+
 class GradExchange:
     """Gradient exchange of one optimizer step over the flat gradient buffer — the ONE code path `DPTrainer.train_step`
     runs when world > 1, written device-agnostically (RCCL on GPUs, gloo in the CPU tests).
 
-    `plan` is the ordered list of buckets `(begin, end, gate)`: the buckets are sum-all-reduced in this order; `gate` is the
+    `plan` is the ordered list of buckets `(begin, end, gate)`: the buckets are exchanged in this order; `gate` is the
     index of the backward event the bucket has to wait for (block l of the DiT: its gradients are complete when the backward
     has enqueued block l), or None for buckets that need the whole backward (patch encoder, decoder, or the single bucket
     of a model without per-block events).  Replaces DDP's bucketed reducer for this path (bsi/tasks/bsi.py:163-166:
     `DistributedDataParallel(model, static_graph=True)`); the 1/world of DDP's average is applied by the fused optimizer
-    kernel (`bsi_clip_adamw_ema`, grad_scale), not here."""
+    kernel (`bsi_clip_adamw_ema_segments`, grad_scale), not here.
 
-    def __init__(self, plan, group=None):
+    Two forms of the exchange over the same plan (`world` = the number of slices a bucket is cut into; every bucket length is a
+    multiple of world * SEG_ALIGN):
+      * `run`: sum-all-reduce of every bucket (what DDP does);
+      * `run_reduce_scatter` + `run_all_gather`: rank r receives only the sum of slice r of every bucket (into its compact
+        shard buffer), updates that slice of the parameters, and the updated slices are all-gathered (ZeRO-1 style; the same
+        bytes on the wire as the all-reduce, the optimizer pass divided by world)."""
+
+    def __init__(self, plan, group=None, world=1):
         self.plan = [(int(b), int(e), g) for b, e, g in plan if e > b]
         self.group = group
+        self.world = int(world)
+        for b, e, _ in self.plan:
+            assert (e - b) % (self.world * SEG_ALIGN) == 0 and b % SEG_ALIGN == 0, "bucket is not a whole number of aligned slices"
+        # slice geometry: bucket k is cut into `world` slices of s_k elements; slice (k, r) owns chunks
+        # [chunk0_k + r * nch_k, + nch_k) of the squared-norm partial array and, on rank r, elements [goff_k, + s_k) of the shard buffer
+        self.layout, chunk, goff = [], 0, 0
+        for b, e, _ in self.plan:
+            sl = (e - b) // self.world
+            nch = -(-sl // SQNORM_CHUNK)
+            self.layout.append((b, sl, nch, chunk, goff))
+            chunk += nch * self.world
+            goff += sl
+        self.total_chunks, self.shard_elems = chunk, goff
 
     @classmethod
-    def for_params(cls, fp, block_prefixes, group=None):
-        """Plan for a `FlatParams` layout: one bucket per prefix of `block_prefixes` (in forward order; reduced LAST block
+    def for_params(cls, fp, block_prefixes, group=None, world=1):
+        """Plan for a `FlatParams` layout: one bucket per prefix of `block_prefixes` (in forward order; exchanged LAST block
         first, as the backward completes them, gate = block index), then everything before the first block and everything
-        after the last one as two ungated buckets.  With no block prefixes: one ungated bucket over the whole buffer."""
+        after the last one as two ungated buckets.  With no block prefixes: one ungated bucket over the whole buffer.
+        Bucket boundaries are the block boundaries rounded UP to a multiple of world * SEG_ALIGN elements, so that every
+        bucket is a whole number of aligned slices: bucket l then ends a few elements inside block l + 1 (complete before
+        block l, the backward runs last-to-first) and leaves the first few elements of block l to bucket l - 1 (gated later)."""
         n = fp.flat.numel()
+        a = world * SEG_ALIGN
+        assert n % a == 0, "FlatParams must be padded to a multiple of world * SEG_ALIGN"
         if not block_prefixes:
-            return cls([(0, n, None)], group)
+            return cls([(0, n, None)], group, world)
         spans = [fp.span(pre) for pre in block_prefixes]
         for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
             assert e0 == b1, "block parameter spans must be adjacent in the flat buffer"
-        plan = [(b, e, l) for l, (b, e) in reversed(list(enumerate(spans)))]
-        plan += [(0, spans[0][0], None), (spans[-1][1], n, None)]
-        return cls(plan, group)
+        up = lambda x: min(n, -(-x // a) * a)  # noqa: E731
+        cuts = [up(b) for b, _ in spans] + [up(spans[-1][1])]
+        plan = [(cuts[l], cuts[l + 1], l) for l in reversed(range(len(spans)))]
+        plan += [(0, cuts[0], None), (cuts[-1], n, None)]
+        return cls(plan, group, world)
 
     def covers(self, n):
         """True when the buckets tile [0, n) exactly once."""
@@ -91,26 +122,63 @@ class GradExchange:
             pos = e
         return pos == n
 
-    def run(self, flat_g, wait_gate=None, wait_all=None):
-        """All-reduce (sum) every bucket of `flat_g` in plan order.  `wait_gate(l)` is called before the first bucket gated
-        on event l, `wait_all()` once before the first ungated bucket (on GPUs: stream waits; in a synchronous backward they
-        may be None)."""
+    def segments(self, ranks, compact):
+        """Rows (p_off, g_off, len, my_chunk, out_chunk) of the `bsi_seg` table for the slices of `ranks` (an iterable of
+        slice indices; range(world) = the whole buffer) in plan order.  compact: the gradient of slice (k, r) lies at goff_k of
+        the rank's shard buffer (reduce-scatter output; one rank only) instead of at its place in the flat gradient."""
+        ranks = list(ranks)
+        assert not compact or len(ranks) == 1
+        rows, mine = [], 0
+        for b, sl, nch, chunk0, goff in self.layout:
+            for r in ranks:
+                off = b + r * sl
+                rows.append((off, goff if compact else off, sl, mine, chunk0 + r * nch))
+                mine += nch
+        return rows, mine
+
+    def _gated(self, wait_gate, wait_all):
         waited_all = False
-        for b, e, gate in self.plan:
+        for k, (b, e, gate) in enumerate(self.plan):
             if gate is None:
                 if not waited_all and wait_all is not None:
                     wait_all()
                 waited_all = True
             elif wait_gate is not None:
                 wait_gate(gate)
+            yield k, b, e
+
+    def run(self, flat_g, wait_gate=None, wait_all=None):
+        """All-reduce (sum) every bucket of `flat_g` in plan order.  `wait_gate(l)` is called before the first bucket gated
+        on event l, `wait_all()` once before the first ungated bucket (on GPUs: stream waits; in a synchronous backward they
+        may be None)."""
+        for _, b, e in self._gated(wait_gate, wait_all):
             dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+
+    def run_reduce_scatter(self, flat_g, shard, wait_gate=None, wait_all=None):
+        """Reduce-scatter (sum) every bucket of `flat_g` in plan order: this rank's slice of bucket k arrives at
+        shard[goff_k : goff_k + s_k]."""
+        for k, b, e in self._gated(wait_gate, wait_all):
+            _, sl, _, _, goff = self.layout[k]
+            dist.reduce_scatter_tensor(shard[goff:goff + sl], flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+
+    def run_all_gather(self, flat, rank):
+        """All-gather the slices of every bucket of `flat` in place (slice r of a bucket comes from rank r), buckets in FORWARD
+        order (front bucket, blocks first to last, tail) -- the order in which the next step's forward needs them."""
+        order = sorted(range(len(self.plan)), key=lambda k: self.plan[k][0])
+        for k in order:
+            b, sl = self.layout[k][0], self.layout[k][1]
+            src = flat[b + rank * sl:b + (rank + 1) * sl]
+            if not flat.is_cuda:
+                src = src.clone()  # gloo: no in-place guarantee for an input that aliases the output
+            dist.all_gather_into_tensor(flat[b:b + self.world * sl], src, group=self.group)
 
 
 class FlatParams:
     """Re-homes all parameters of a module into one flat fp32 buffer (parameters become views), so that the
-    optimizer, the EMA and the gradient all-reduce work on contiguous memory."""
+    optimizer, the EMA and the gradient exchange work on contiguous memory.  The buffer is padded with zeros to a multiple
+    of `pad_to` elements (the pad belongs to no parameter: zero gradient, zero moments, stays zero)."""
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, pad_to: int = 1):
         self.module = module
         self.names = [n for n, _ in module.named_parameters()]
         params = [p for _, p in module.named_parameters()]
@@ -119,7 +187,8 @@ class FlatParams:
         for s in self.sizes:
             self.offsets.append(self.offsets[-1] + s)
         dev = params[0].device
-        self.flat = torch.empty(self.offsets[-1], dtype=torch.float32, device=dev)
+        self.n = self.offsets[-1]
+        self.flat = torch.zeros(-(-self.n // pad_to) * pad_to, dtype=torch.float32, device=dev)
         for p, o, s in zip(params, self.offsets, self.sizes):
             self.flat[o:o + s].copy_(p.detach().reshape(-1))
             p.data = self.flat[o:o + s].view_as(p)
@@ -131,15 +200,31 @@ class FlatParams:
         return self.offsets[idx[0]], self.offsets[idx[-1] + 1]
 
 
+def _check_reserve(r):
+    if r < 0 or r % 8 or r > 64:
+        raise ValueError(f"cu_reserve = {r}: must be 0 or a multiple of 8 up to 64 (bsi_set_cu_reserve)")
+    return r
+
+
 class DPTrainer:
     """Native data-parallel train step around a `bsi_amd.BSI` whose model is a `bsi_amd.models.dit.DenoisingDiT` (per-block
     gradient buckets overlapped with the backward) or a `bsi_amd.models.vdm_unet.DenoisingVDMUNet` (28 M parameters: one
-    bucket after the backward)."""
+    bucket after the backward).
+
+    At world > 1 the constructor broadcasts rank 0's parameters, buffers and EMA to every rank, as the constructor of
+    `DistributedDataParallel` does (bsi/tasks/bsi.py:165): ranks that were seeded differently still train ONE model.
+
+    shard_update=True: the step is reduce-scatter -> clip + AdamW + EMA on this rank's 1/world slice of every bucket -> all-gather
+    of the updated parameters (identical parameters to the all-reduce step: same sums, same per-chunk norm, same arithmetic).
+    The EMA is then updated on the owned slices only; `gather_ema()` completes `ema_model` (call it before sampling from /
+    saving the EMA).  rehearse=(world, rank): lay the buckets and slices out as on that rank of that world size WITHOUT any
+    communication -- a timing rehearsal of one rank's compute on a single GPU (bench.py); with shard_update the parameters
+    outside the rank's slices are then simply not updated."""
 
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
                  ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False,
-                 cu_reserve: int | None = None):
+                 cu_reserve: int | None = None, shard_update: bool = False, rehearse=None):
         self.bsi = bsi
         self.model = bsi.model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -147,18 +232,33 @@ class DPTrainer:
         self.lr_schedule = lr_schedule  # callable step -> lr, or None for constant lr
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         # force_exchange runs the gradient exchange (events, side stream, RCCL calls) even in a group of one rank, so that
         # the multi-GPU code path can be exercised on a single device
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
-        # Compute units left to the RCCL kernels for the length of a step.  The GEMM / weight-gradient / attention / convolution
-        # kernels of the backward are persistent: one 160-KB-LDS workgroup per CU with a STATIC share of the tiles.  An all-reduce
-        # kernel of `_exchange` that holds c CUs while a bucket is in flight would leave c of those workgroups unplaced until the
-        # others finish -- the launch takes up to twice as long.  With the reserve the grids are `CUs - reserve` wide and the
-        # communication kernels find their CUs free (DDP's reducer in the reference simply shares the GPU, bsi/tasks/bsi.py:163-166).
-        # Default: BSI_DP_CU_RESERVE or 16 when the exchange is on (bench.py caps RCCL's channels to the same number), else 0.
+        self.shard_update = bool(shard_update)
+        # the world / rank the buckets and slices are laid out for (a rehearsal lays out another world's without communicating)
+        self.lay_world, self.lay_rank = (int(rehearse[0]), int(rehearse[1])) if rehearse else (self.world, self.rank)
+        assert not (rehearse and self.exchange), "a rehearsal does not communicate"
+        assert 0 <= self.lay_rank < self.lay_world
+        self.bucketed = hasattr(self.model, "dit")
+        # Compute units left to the RCCL kernels while buckets are in flight.  The weight-gradient GEMMs and convolutions of the
+        # backward are persistent with a STATIC share of the work per workgroup (one 160-KB-LDS workgroup per CU): a communication
+        # kernel that holds c CUs leaves c of those workgroups unplaced until the others finish -- the launch takes twice as long.
+        # With the reserve their grids are `CUs - reserve` wide.  It is in force only where a bucket can be in flight: from the
+        # start of the backward to the end of the exchange of a BUCKETED model (the forward, and a model whose single bucket
+        # leaves after the backward, overlap with nothing).  Default: BSI_DP_CU_RESERVE or 0 -- no multi-GPU run has confirmed a
+        # gain yet (bench.py --gpus N measures the step under both settings); RCCL's channel count must then be capped to the
+        # same number BEFORE init_process_group (NCCL_MAX_NCHANNELS; bench.py does it), which is checked here.
         if cu_reserve is None:
-            cu_reserve = int(os.environ.get("BSI_DP_CU_RESERVE", "16")) if self.exchange else 0
-        self.cu_reserve = int(cu_reserve)
+            cu_reserve = int(os.environ.get("BSI_DP_CU_RESERVE", "0"))
+        self.cu_reserve = _check_reserve(int(cu_reserve)) if (self.exchange or rehearse) and self.bucketed else 0
+        if self.cu_reserve and self.exchange and bsi.model is not None and next(self.model.parameters()).is_cuda:
+            ch = os.environ.get("NCCL_MAX_NCHANNELS")
+            if ch is None or int(ch) > self.cu_reserve:
+                import warnings
+                warnings.warn(f"DPTrainer: cu_reserve = {self.cu_reserve} but NCCL_MAX_NCHANNELS = {ch}: RCCL may launch more "
+                              "workgroups than CUs are kept free for it; export NCCL_MAX_NCHANNELS before init_process_group")
         # measurement hook (bench.py): with time_stages on, every step appends three HIP events (start, after backward + exchange,
         # after the optimizer) to stage_events; `stage_ms()` turns them into (forward + backward + exchange, optimizer) milliseconds
         self.time_stages = False
@@ -171,28 +271,56 @@ class DPTrainer:
         # gradients -- is set only INSIDE `_backward`: a sticky attribute would silently turn every ordinary `loss.backward()` on
         # this model, and on the deep-copied EMA model, into a no-op for `p.grad`)
         self.model._flat_grad_only = False
-        for attr in ("_plan", "_plan_t"):  # persistent shadow buffers + ctypes tables (rebuilt on demand; not deep-copyable)
+        for attr in ("_plan", "_plan_t", "_grad_buffer"):  # persistent buffers + ctypes tables (rebuilt on demand; not deep-copyable)
             if hasattr(self.model, attr):
                 setattr(self.model, attr, None)
         self.ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
-        self.fp = FlatParams(self.model)
-        self.ema_fp = FlatParams(self.ema_model) if ema else None
+        pad = self.lay_world * SEG_ALIGN
+        self.fp = FlatParams(self.model, pad)
+        self.ema_fp = FlatParams(self.ema_model, pad) if ema else None
+        self.ema_complete = True  # False while the EMA of a sharded step is current on the owned slices only
         dev = self.fp.flat.device
-        self._setup_update_state(dev)
-        self.bucketed = hasattr(self.model, "dit")
+        if self.world > 1:
+            self._broadcast_start_state()
         depth = len(self.model.dit.blocks) if self.bucketed else 0
-        self.xchg = GradExchange.for_params(self.fp, [f"dit.blocks.{i}." for i in range(depth)], process_group)
+        self.xchg = GradExchange.for_params(self.fp, [f"dit.blocks.{i}." for i in range(depth)], process_group, self.lay_world)
         assert self.xchg.covers(self.fp.flat.numel())
         self.last_grad_norm = None
+        self._setup_update_state(dev)
         self._setup_exchange_state(dev, depth)
 
-    # -- stages of a step: each is one method so that the host logic (order of stages, bucket plan, gates, 1/world) is
-    #    testable with world-size-2 gloo processes that substitute the two device stages (tests/test_dp_host.py)
+    def _broadcast_start_state(self):
+        """Rank 0's parameters, buffers and EMA to every rank (DistributedDataParallel.__init__ -> _sync_module_states,
+        bsi/tasks/bsi.py:165; Lightning wraps the module before the first step)."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(self.fp.flat, src=src, group=self.group)
+        if self.ema_fp is not None:
+            dist.broadcast(self.ema_fp.flat, src=src, group=self.group)
+        for m in (self.model, self.ema_model):
+            for b in (m.buffers() if m is not None else ()):
+                dist.broadcast(b, src=src, group=self.group)
+
+    # -- stages of a step: each is one method so that the host logic (order of stages, bucket plan, gates, slices, 1/world) is
+    #    testable with world-size-2 gloo processes that substitute the device stages (tests/test_dp_host.py)
+    def _seg_table(self, rows, dev):
+        arr = (N.Seg * len(rows))(*[N.Seg(*r) for r in rows])
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
     def _setup_update_state(self, dev):
+        n = self.fp.flat.numel()
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.sq_ws = torch.empty(N.lib().bsi_sqnorm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # the flat gradient the HIP backward writes (its pad stays zero) and, for the sharded step, the compact buffer the
+        # reduce-scatter delivers this rank's slices into
+        self.gbuf = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.gshard = torch.zeros(self.xchg.shard_elems, dtype=torch.float32, device=dev) if self.shard_update else None
+        # squared-norm partials: one per chunk of every slice of every rank; `part_own` holds this rank's chunks and zeros
+        self.part = torch.zeros(self.xchg.total_chunks, dtype=torch.float32, device=dev)
+        self.part_own = torch.zeros_like(self.part) if self.shard_update else None
+        ranks = [self.lay_rank] if self.shard_update else range(self.lay_world)
+        self.seg_rows, self.seg_chunks = self.xchg.segments(ranks, compact=self.shard_update)
+        self.seg_tab = self._seg_table(self.seg_rows, dev) if dev.type == "cuda" else None
 
     def _setup_exchange_state(self, dev, depth):
         self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
@@ -205,51 +333,101 @@ class DPTrainer:
 
     def _backward(self, x, generator):
         """BSI.train_loss + the HIP backward on this rank's shard: (mean loss, flat fp32 gradient in FlatParams order).
-        With the exchange on, the backward records event l when block l's gradients are enqueued."""
+        With the exchange on, the backward records event l when block l's gradients are enqueued.  The CU reserve is set between
+        the forward and the backward (grids are sized at launch) and cleared by `train_step` after the exchange."""
         lib = N.lib()
         for p in self.model.parameters():
             p.grad = None
         self.model._last_flat_grad = None
+        self.model._grad_buffer = self.gbuf
         if self.exchange and self.bucketed:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
         self.model._flat_grad_only = True
         try:
             loss = self.bsi.train_loss(x, generator).mean()
+            if self.cu_reserve:
+                N.check(lib.bsi_set_cu_reserve(self.cu_reserve))
             loss.backward()
         finally:
             self.model._flat_grad_only = False
+            self.model._grad_buffer = None
             if self.exchange and self.bucketed:
                 N.check(lib.bsi_dit_backward_set_events(None, 0))
         flat_g = self.model._last_flat_grad
         assert flat_g is not None, "the HIP training engine did not run (model is not a native denoiser?)"
-        return loss, flat_g
+        assert flat_g.data_ptr() == self.gbuf.data_ptr(), "the training engine did not use the trainer's gradient buffer"
+        return loss, self.gbuf
 
     def _gate_wait(self, l):
         self.comm_stream.wait_event(self.events[l])
 
     def _exchange(self, flat_g):
-        """Sum the gradient over the ranks, bucket by bucket (GradExchange.plan).  On GPUs the collectives run on a side
-        stream: blocks finish last-to-first and each bucket starts when its event fires, overlapping the rest of the
-        backward; encoder / decoder gradients (and the UNet's single bucket) wait for the whole backward."""
+        """Sum the gradient over the ranks, bucket by bucket (GradExchange.plan): all-reduce, or reduce-scatter into this rank's
+        shard buffer.  On GPUs the collectives run on a side stream: blocks finish last-to-first and each bucket starts when its
+        event fires, overlapping the rest of the backward; encoder / decoder gradients (and the UNet's single bucket) wait for the
+        whole backward."""
+        run = (lambda **kw: self.xchg.run_reduce_scatter(flat_g, self.gshard, **kw)) if self.shard_update else \
+              (lambda **kw: self.xchg.run(flat_g, **kw))
         if not flat_g.is_cuda:
-            self.xchg.run(flat_g, wait_gate=self._gate_wait, wait_all=None)
+            run(wait_gate=self._gate_wait, wait_all=None)
             return
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.comm_stream):
-            self.xchg.run(flat_g, wait_gate=self._gate_wait, wait_all=lambda: self.comm_stream.wait_stream(cur))
+            run(wait_gate=self._gate_wait, wait_all=lambda: self.comm_stream.wait_stream(cur))
         cur.wait_stream(self.comm_stream)
 
+    # device stages of the update (CPU stand-ins in tests/test_dp_host.py follow the same contracts)
+    def _sq_partials(self, g, out):
+        """out[chunk] = sum of squares of every chunk of this trainer's segments of gradient buffer `g`."""
+        N.check(N.lib().bsi_sqnorm_segments(N.ptr(g), N.ptr(self.seg_tab), len(self.seg_rows), self.seg_chunks, N.ptr(out), N.stream()))
+
+    def _sq_finish(self, part):
+        N.check(N.lib().bsi_sqnorm_finish(N.ptr(part), part.numel(), N.ptr(self.sq), N.stream()))
+
+    def _apply(self, g, lr, ema_w):
+        """clip + AdamW + EMA on this trainer's segments; `g` holds the SUM over ranks, the 1/world of the average is folded into
+        the kernel's gradient scale."""
+        N.check(N.lib().bsi_clip_adamw_ema_segments(
+            N.ptr(self.fp.flat), N.ptr(g), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ema_fp.flat) if self.ema_fp else None,
+            N.ptr(self.seg_tab), len(self.seg_rows), self.seg_chunks, N.ptr(self.sq), float(self.max_grad_norm or 0.0),
+            1.0 / self.lay_world, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, ema_w, N.stream()))
+
     def _update(self, flat_g, lr, ema_w):
-        """Global-norm clip + AdamW + EMA on the flat buffers; `flat_g` holds the SUM over ranks, the 1/world of the
-        average is folded into the kernel's gradient scale."""
-        lib = N.lib()
-        n = flat_g.numel()
-        N.check(lib.bsi_grad_sqnorm(N.ptr(flat_g), n, N.ptr(self.sq), N.ptr(self.sq_ws), N.stream()))
-        N.check(lib.bsi_clip_adamw_ema(N.ptr(self.fp.flat), N.ptr(flat_g), N.ptr(self.m), N.ptr(self.v),
-                                       N.ptr(self.ema_fp.flat) if self.ema_fp else None, n, N.ptr(self.sq),
-                                       float(self.max_grad_norm or 0.0), 1.0 / self.world, lr, self.betas[0],
-                                       self.betas[1], self.eps, self.weight_decay, self.step_count, ema_w, N.stream()))
+        """Global-norm clip + AdamW + EMA.  All-reduce step: on the whole flat buffers.  Sharded step: the norm's partials of the
+        owned slices are summed over the ranks (the other ranks' entries are exact zeros), the update runs on the owned slices
+        and the updated parameter slices are all-gathered."""
+        if not self.shard_update:
+            self._sq_partials(flat_g, self.part)
+            self._sq_finish(self.part)
+            self._apply(flat_g, lr, ema_w)
+        else:
+            self._sq_partials(self.gshard, self.part_own)
+            self.part.copy_(self.part_own)
+            if self.exchange:
+                dist.all_reduce(self.part, op=dist.ReduceOp.SUM, group=self.group)
+            self._sq_finish(self.part)
+            self._apply(self.gshard, lr, ema_w)
+            self.ema_complete = self.ema_fp is None or ema_w < 0
+            if self.exchange:
+                self._gather(self.fp.flat)
         self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
+
+    def _gather(self, flat):
+        if not flat.is_cuda:
+            self.xchg.run_all_gather(flat, self.rank)
+            return
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.xchg.run_all_gather(flat, self.rank)
+        cur.wait_stream(self.comm_stream)
+
+    def gather_ema(self):
+        """Sharded step: all-gather the EMA slices so that `ema_model` is complete on every rank (no-op otherwise)."""
+        if self.shard_update and self.exchange and self.ema_fp is not None and not self.ema_complete:
+            self._gather(self.ema_fp.flat)
+            self._invalidate(self.ema_model)
+        self.ema_complete = True
 
     def stage_ms(self):
         """Mean (forward + backward + exchange, optimizer) milliseconds of the steps recorded since the last call."""
@@ -268,19 +446,16 @@ class DPTrainer:
 
     def train_step(self, x: torch.Tensor, generator=None) -> torch.Tensor:
         """One optimizer step on this rank's shard `x`; returns the (local) mean loss (detached)."""
-        reserve = self.cu_reserve if x.is_cuda else 0
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (self.time_stages and x.is_cuda) else None
         if ev:
             ev[0].record()
-        if reserve:
-            N.check(N.lib().bsi_set_cu_reserve(reserve))  # grids are sized at launch: in effect for the kernels enqueued below
         try:
             loss, flat_g = self._backward(x, generator)
             if self.exchange:
                 self._exchange(flat_g)
         finally:
-            if reserve:
-                N.check(N.lib().bsi_set_cu_reserve(0))    # sampling / evaluation between steps use every CU
+            if self.cu_reserve and x.is_cuda:
+                N.check(N.lib().bsi_set_cu_reserve(0))    # the update, sampling / evaluation between steps use every CU
         lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
         w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
         self.step_count += 1

@@ -110,7 +110,7 @@ class DenoisingDiT(nn.Module):
         return N.DitConfig(Cc, H, W, a["patch"], a["dim"], a["depth"], a["heads"],
                            ff.n_min if ff is not None else 1, ff.n_max if ff is not None else 0)
 
-    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad")
+    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad", "_grad_buffer")
 
     def __deepcopy__(self, memo):
         """`copy.deepcopy(model)` (EMA copies, checkpoint tooling) after the model has run: the native caches hold ctypes tables with raw
@@ -149,9 +149,15 @@ class DenoisingDiT(nn.Module):
         kpad = lib.bsi_dit_kpad(C.byref(cfg))
         keep, descs = [], []
 
+        def dense(q: Tensor) -> Tensor:
+            """The descriptor table and the weight tables hold raw pointers and assume row stride = cols: a strided parameter
+            (a transposed view, a loaded slice) is made contiguous IN PLACE once, before its pointer is taken."""
+            if not q.is_contiguous():
+                q.data = q.data.contiguous()
+            return q.detach()
+
         def shadow(w: Tensor, ld=None, out=None):
-            w = w.detach()
-            assert w.is_contiguous()
+            w = dense(w)
             rows, cols = w.shape
             ld = ld or cols
             if out is None:
@@ -161,8 +167,7 @@ class DenoisingDiT(nn.Module):
             return out.data_ptr()
 
         def f32(p: Tensor):
-            t = p.detach()
-            assert t.is_contiguous()
+            t = dense(p)
             keep.append(t)
             return t.data_ptr()
 

@@ -110,7 +110,11 @@ class _UNetTrainFn(torch.autograd.Function):
         named = dict(model.named_parameters())
         order = [n for n, _ in model.named_parameters()]
         sizes = {n: named[n].numel() for n in order}
-        flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=dev)
+        total = sum(sizes.values())
+        flat = getattr(model, "_grad_buffer", None)  # the data-parallel trainer's persistent (padded) gradient buffer, if any
+        if flat is None:
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+        assert flat.numel() >= total and flat.dtype == torch.float32 and flat.is_contiguous()
         views, off = {}, 0
         for n in order:
             views[n] = flat[off:off + sizes[n]].view_as(named[n])

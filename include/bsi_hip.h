@@ -644,6 +644,25 @@ int bsi_clip_adamw_ema(float* p, const float* g, float* m, float* v, float* ema,
                        float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int step, float ema_weight, bsi_stream_t stream);
 
+/* Segment forms for the data-parallel step (bsi_amd/dp.py; replaces DDP's reducer + optimizer hooks, bsi/tasks/bsi.py:163-198, for
+ * a reduce-scatter / sharded-update / all-gather step as well as the all-reduce step).  A segment is one (bucket, rank) slice of
+ * the flat buffers: parameters / moments / EMA at element offset p_off, its gradient at g_off of the gradient buffer (the flat
+ * gradient, or the rank's compact reduce-scatter output), len elements (a multiple of 4, offsets too), cut into chunks of
+ * BSI_SQNORM_CHUNK elements.  my_chunk = chunks of the table's earlier segments (ascending), out_chunk = index of the segment's
+ * first chunk in the GLOBAL partial array, which is laid out for the segments of ALL ranks: bsi_sqnorm_segments writes one fp32
+ * partial per chunk of the table, bsi_sqnorm_finish sums `nchunks` partials in index order -- the same bits whether a chunk was
+ * computed by every rank (all-reduced gradient) or by its owner only (partials of the other ranks added as exact zeros).
+ * Table in DEVICE memory.  bsi_clip_adamw_ema_segments = bsi_clip_adamw_ema on the table's segments (same arithmetic). */
+#define BSI_SQNORM_CHUNK 16384
+typedef struct bsi_seg {
+    size_t p_off, g_off, len, my_chunk, out_chunk;
+} bsi_seg;
+int bsi_sqnorm_segments(const float* g, const bsi_seg* segs, int nseg, size_t nchunks, float* partials, bsi_stream_t stream);
+int bsi_sqnorm_finish(const float* partials, size_t nchunks, float* out_sq, bsi_stream_t stream);
+int bsi_clip_adamw_ema_segments(float* p, const float* g, float* m, float* v, float* ema, const bsi_seg* segs, int nseg,
+                                size_t nchunks, const float* sqnorm, float max_norm, float grad_scale, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, float ema_weight, bsi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class timing with HIP events on the launch stream.
  * ---------------------------------------------------------------------------------------- */

@@ -41,21 +41,26 @@ def main():
     from tests.util import golden, replay_draws, shard_draws
 
     g = golden("g4_train_dit")
-    bsi = build(dev)
-    tr = DPTrainer(bsi, **TRAINER)
-    assert tr.world == world and tr.exchange and tr.bucketed and tr.comm_stream is not None and tr.events is not None
     B = g["x"].shape[0]
     nb = split_batch(B, world, rank)
     start = sum(split_batch(B, world, r) for r in range(rank))
     x = g["x"][start:start + nb].to(dev)
-    losses = []
-    for s in range(STEPS):
-        off, perm, eps = shard_draws(rank, s, nb, (3, 16, 16))
-        with replay_draws(dev, rand=[off], randperm=[perm], randn=[eps]):
-            losses.append(float(tr.train_step(x)))
-    torch.cuda.synchronize()
-    torch.save({"flat": tr.fp.flat.cpu(), "ema": tr.ema_fp.flat.cpu(), "losses": losses, "buckets": len(tr.xchg.plan)},
-               os.environ["DP_OUT"] + f".rank{rank}.pt")
+    out = {}
+    # the all-reduce step, then -- from the same start state and draws -- the sharded step (reduce-scatter, slice update, all-gather)
+    for mode, kw in (("allreduce", {}), ("sharded", {"shard_update": True})):
+        bsi = build(dev)
+        tr = DPTrainer(bsi, **TRAINER, **kw)
+        assert tr.world == world and tr.exchange and tr.bucketed and tr.comm_stream is not None and tr.events is not None
+        losses = []
+        for s in range(STEPS):
+            off, perm, eps = shard_draws(rank, s, nb, (3, 16, 16))
+            with replay_draws(dev, rand=[off], randperm=[perm], randn=[eps]):
+                losses.append(float(tr.train_step(x)))
+        tr.gather_ema()
+        torch.cuda.synchronize()
+        out[mode] = {"flat": tr.fp.flat.cpu(), "ema": tr.ema_fp.flat.cpu(), "losses": losses, "buckets": len(tr.xchg.plan),
+                     "sq": float(tr.sq[0]), "n_params": tr.fp.n}
+    torch.save(out, os.environ["DP_OUT"] + f".rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 

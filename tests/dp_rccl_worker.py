@@ -65,8 +65,22 @@ def main():
     dist.all_gather(flats, tr.fp.flat)
     dist.all_gather(emas, tr.ema_fp.flat)
     same = all(torch.equal(flats[0], f) for f in flats) and all(torch.equal(emas[0], e) for e in emas)
+    # the sharded step over RCCL (reduce-scatter, slice update, all-gather of the parameters) from the same start state and draws:
+    # at world 2 a sum has one order, so parameters and EMA must equal the all-reduce step's bit for bit
+    model2 = DenoisingDiT((3, 16, 16), 2, 128, 2, 2, dropout=None, fourier_features=FourierFeatures(n_min=6, n_max=8))
+    model2.load_state_dict(weights("dit_ff"))
+    bsi2 = BSI(model2.to(dev).train(), data_shape=(3, 16, 16), lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=16, preconditioning="edm",
+               discretization=Discretization.image_8bit()).to(dev)
+    tr2 = DPTrainer(bsi2, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, shard_update=True)
+    gen = torch.Generator(dev).manual_seed(100 + rank)
+    for _ in range(2):
+        tr2.train_step(x, gen)
+    tr2.gather_ema()
+    sharded_same = bool(torch.equal(tr2.fp.flat, tr.fp.flat) and torch.equal(tr2.ema_fp.flat, tr.ema_fp.flat)) if world == 2 else \
+        bool(torch.allclose(tr2.fp.flat, tr.fp.flat, rtol=1e-5, atol=1e-7))
+    same = same and sharded_same
     if rank == 0:
-        print(json.dumps({"ok": bool(ok and same), "exchange_rel_err": worst, "identical_params": bool(same),
+        print(json.dumps({"ok": bool(ok and same), "exchange_rel_err": worst, "identical_params": bool(same), "sharded_equals_allreduce": sharded_same,
                           "world": world, "per_rank_batch": nb}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

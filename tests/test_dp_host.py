@@ -67,16 +67,15 @@ class _ToyBSI:
 
 
 def _host_trainer(bsi, log, **kw):
-    """The product's DPTrainer with its two DEVICE stages replaced by CPU stand-ins (autograd for the HIP backward, the
-    oracle's clip+AdamW restatement for the fused kernel).  `train_step`, `_exchange`, the bucket plan, the gate order and
-    the 1/world scale are the product's own code."""
+    """The product's DPTrainer with its DEVICE stages replaced by CPU stand-ins (autograd for the HIP backward; the squared-norm
+    partials, their final sum and the oracle's clip+AdamW restatement for the three optimizer kernels, with the kernels' contracts:
+    one partial per chunk of every segment, the update on the trainer's segments).  `train_step`, `_exchange`, `_update`, the bucket
+    plan, the slices, the gate order, the collectives and the 1/world scale are the product's own code."""
+    import math
+
     from bsi_amd import dp
-    from oracle.bsi_oracle import clip_adamw_step
 
     class HostTrainer(dp.DPTrainer):
-        def _setup_update_state(self, dev):
-            self.m, self.v = torch.zeros_like(self.fp.flat), torch.zeros_like(self.fp.flat)
-
         def _setup_exchange_state(self, dev, depth):
             self.comm_stream, self.events = None, None
 
@@ -85,18 +84,40 @@ def _host_trainer(bsi, log, **kw):
                 p.grad = None
             loss = self.bsi.train_loss(x, generator).mean()
             loss.backward()
-            return loss, torch.cat([p.grad.reshape(-1) for p in self.model.parameters()])
+            g = torch.cat([p.grad.reshape(-1) for p in self.model.parameters()])
+            self.gbuf[:g.numel()].copy_(g)
+            return loss, self.gbuf
 
         def _gate_wait(self, l):
             log.append(("gate", l))
 
-        def _update(self, flat_g, lr, ema_w):
-            g = flat_g * (1.0 / self.world)
-            P, G, M, V = [self.fp.flat], [g], [self.m], [self.v]
-            clip_adamw_step(P, G, M, V, self.step_count, lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                            weight_decay=self.weight_decay, max_norm=self.max_grad_norm)
-            if self.ema_fp is not None and ema_w >= 0:
-                self.ema_fp.flat.lerp_(self.fp.flat, ema_w)
+        def _sq_partials(self, g, out):
+            for p_off, g_off, ln, my_chunk, out_chunk in self.seg_rows:
+                for k in range(-(-ln // dp.SQNORM_CHUNK)):
+                    c = g[g_off + k * dp.SQNORM_CHUNK:g_off + min(ln, (k + 1) * dp.SQNORM_CHUNK)]
+                    out[out_chunk + k] = (c.double() ** 2).sum().float()
+
+        def _sq_finish(self, part):
+            self.sq[0] = part.double().sum().float()
+
+        def _apply(self, g, lr, ema_w):
+            # oracle.bsi_oracle.clip_adamw_step with the norm given (it is global, the segments are not)
+            scale = 1.0 / self.lay_world
+            coef = scale
+            if self.max_grad_norm:
+                total = torch.sqrt(self.sq[0]) * scale
+                coef = scale * float(torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0))
+            b1, b2 = self.betas
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            for p_off, g_off, ln, _, _ in self.seg_rows:
+                p, m_, v_ = (t[p_off:p_off + ln] for t in (self.fp.flat, self.m, self.v))
+                gi = g[g_off:g_off + ln] * coef
+                p.mul_(1 - lr * self.weight_decay)
+                m_.mul_(b1).add_(gi, alpha=1 - b1)
+                v_.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+                p.addcdiv_(m_, (v_.sqrt() / math.sqrt(bc2)).add_(self.eps), value=-lr / bc1)
+                if self.ema_fp is not None and ema_w >= 0:
+                    self.ema_fp.flat[p_off:p_off + ln].lerp_(p, ema_w)
 
     return HostTrainer(bsi, **kw)
 
@@ -128,7 +149,7 @@ def _worker(rank, world, port, ret):
     losses = [float(tr.train_step(X[start:start + nb])) for _ in range(2)]
     dist.all_reduce = real_all_reduce
     ret[rank] = {"nb": nb, "flat": tr.fp.flat.clone(), "ema": tr.ema_fp.flat.clone(), "log": log, "losses": losses,
-                 "plan": tr.xchg.plan, "n": tr.fp.flat.numel(), "steps": tr.step_count}
+                 "plan": tr.xchg.plan, "n": tr.fp.flat.numel(), "n_params": tr.fp.n, "steps": tr.step_count}
     dist.destroy_process_group()
 
 
@@ -175,7 +196,8 @@ def test_gloo_world2_dptrainer_step():
             gsum += torch.cat([p.grad.reshape(-1) for p in model.parameters()])
         clip_adamw_step(P, [gsum / world], M, V, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=1e-2,
                         max_norm=0.05)
-    assert torch.allclose(a["flat"], P[0], rtol=1e-5, atol=1e-7)
+    assert a["n"] % (world * dp.SEG_ALIGN) == 0 and not a["flat"][a["n_params"]:].any()   # zero pad, a whole number of slices
+    assert torch.allclose(a["flat"][:a["n_params"]], P[0], rtol=1e-5, atol=1e-7)
     assert torch.equal(a["ema"], a["flat"])   # first 1000 updates copy the online weights (ema_pytorch.py:320-332)
 
 
@@ -200,3 +222,76 @@ def test_gloo_world2_single_bucket_model():
     ret = mgr.dict()
     mp.spawn(_worker_single_bucket, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert torch.equal(ret[0], ret[1])
+
+
+def _worker_modes(rank, world, port, ret):
+    """Three trainers per rank on the same data: (a) all-reduce step from identical seeds, (b) all-reduce step from RANK-DISTINCT
+    seeds (the constructor's broadcast must make them rank 0's model), (c) sharded step (reduce-scatter / slice update / all-gather)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bsi_amd import dp
+    X = _data(129)
+    nb = dp.split_batch(129, world, rank)
+    start = sum(dp.split_batch(129, world, r) for r in range(rank))
+    out = {}
+    for mode, seed, kw in (("allreduce", 0, {}), ("own_seed", 100 * rank, {}), ("sharded", 0, {"shard_update": True})):
+        torch.manual_seed(seed)
+        model = _ToyDiT()
+        log = []
+        calls = {"rs": 0, "ag": 0, "ar": 0}
+        real = (dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce)
+
+        def rs(*a, _f=real[0], **k):
+            calls["rs"] += 1
+            return _f(*a, **k)
+
+        def ag(*a, _f=real[1], **k):
+            calls["ag"] += 1
+            return _f(*a, **k)
+
+        def ar(*a, _f=real[2], **k):
+            calls["ar"] += 1
+            return _f(*a, **k)
+
+        dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce = rs, ag, ar
+        # after 1000 warm-up copies the EMA lerps: make it lerp from the first step so that the EMA slices differ from the parameters
+        tr = _host_trainer(_ToyBSI(model), log, lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=0.05,
+                           ema_update_after_step=0, **kw)
+        for _ in range(3):
+            tr.train_step(X[start:start + nb])
+        ema_before = tr.ema_fp.flat.clone()
+        tr.gather_ema()
+        dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce = real
+        out[mode] = {"flat": tr.fp.flat.clone(), "ema": tr.ema_fp.flat.clone(), "ema_before": ema_before, "calls": dict(calls),
+                     "buckets": len(tr.xchg.plan), "sq": float(tr.sq[0]), "shard": tr.xchg.shard_elems, "n": tr.fp.flat.numel()}
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_start_broadcast_and_sharded_update():
+    """(1) DDP-equivalent start state: ranks constructed from different seeds train rank 0's model (bsi/tasks/bsi.py:165: the
+    DistributedDataParallel constructor broadcasts rank 0's parameters and buffers).  (2) The sharded step -- reduce-scatter, clip +
+    AdamW + EMA on this rank's slice of every bucket, all-gather -- leaves parameters, EMA and the global gradient norm BIT-IDENTICAL
+    to the all-reduce step."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_modes, args=(world, _free_port(), ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    for mode in ("allreduce", "own_seed", "sharded"):
+        assert torch.equal(a[mode]["flat"], b[mode]["flat"]) and torch.equal(a[mode]["ema"], b[mode]["ema"]), mode
+    # (1) rank 1 was seeded 100, rank 0 seeded 0: both follow the trajectory of the identically seeded run
+    assert torch.equal(a["own_seed"]["flat"], a["allreduce"]["flat"]) and torch.equal(a["own_seed"]["ema"], a["allreduce"]["ema"])
+    # (2) sharded == all-reduce, bit for bit (parameters, EMA after gather_ema, squared norm)
+    assert torch.equal(a["sharded"]["flat"], a["allreduce"]["flat"])
+    assert torch.equal(a["sharded"]["ema"], a["allreduce"]["ema"])
+    assert a["sharded"]["sq"] == a["allreduce"]["sq"]
+    # before gather_ema a rank's EMA is current on its own slices only
+    assert not torch.equal(a["sharded"]["ema_before"], a["sharded"]["ema"])
+    nb = a["sharded"]["buckets"]
+    # 3 steps x (one reduce-scatter + one parameter all-gather per bucket + one all-reduce of the norm partials) + the EMA gather;
+    # the broadcasts of the constructor are not counted here
+    assert a["sharded"]["calls"] == {"rs": 3 * nb, "ag": 3 * nb + nb, "ar": 3}
+    assert a["allreduce"]["calls"] == {"rs": 0, "ag": 0, "ar": 3 * nb}
+    assert a["sharded"]["shard"] * world == a["sharded"]["n"]      # the shard buffer holds exactly 1/world of the gradient

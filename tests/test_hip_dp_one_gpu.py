@@ -37,8 +37,13 @@ def test_two_processes_on_one_gpu_run_the_product_train_step(tmp_path):
             if p.poll() is None:
                 p.kill()
     assert [p.returncode for p in procs] == [0, 0], logs
-    r0, r1 = (torch.load(out + f".rank{r}.pt") for r in range(2))
-    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["ema"], r1["ema"])  # replicas stay bit-identical
+    a0, a1 = (torch.load(out + f".rank{r}.pt") for r in range(2))
+    for mode in ("allreduce", "sharded"):
+        assert torch.equal(a0[mode]["flat"], a1[mode]["flat"]) and torch.equal(a0[mode]["ema"], a1[mode]["ema"]), mode  # replicas stay bit-identical
+    # the sharded step (reduce-scatter -> bsi_clip_adamw_ema_segments on the rank's slices -> all-gather) == the all-reduce step, bit for bit
+    assert torch.equal(a0["sharded"]["flat"], a0["allreduce"]["flat"]) and torch.equal(a0["sharded"]["ema"], a0["allreduce"]["ema"])
+    assert a0["sharded"]["sq"] == a0["allreduce"]["sq"] and a0["sharded"]["losses"] == a0["allreduce"]["losses"]
+    r0, r1 = a0["allreduce"], a1["allreduce"]
     assert r0["buckets"] == 2 + 2  # one per block (last first) + patch encoder + decoder
 
     # single-process restatement: both shards' gradients with the same draws, summed, 1/2 in the fused update
@@ -47,9 +52,8 @@ def test_two_processes_on_one_gpu_run_the_product_train_step(tmp_path):
     from tests.util import golden, replay_draws, shard_draws
     dev = torch.device("cuda", 0)
     g = golden("g4_train_dit")
-    tr = DPTrainer(build(dev), **TRAINER)
-    assert tr.world == 1 and not tr.exchange
-    tr.world = 2  # the update divides the SUM of the two shard gradients by 2 (DDP's average)
+    tr = DPTrainer(build(dev), rehearse=(2, 0), **TRAINER)  # buckets / slices / norm chunks laid out as at world 2; the update
+    assert tr.world == 1 and not tr.exchange                # divides the SUM of the two shard gradients by 2 (DDP's average)
     B = g["x"].shape[0]
     from bsi_amd.dp import ema_weight
     losses = [[], []]

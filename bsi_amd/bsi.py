@@ -144,6 +144,25 @@ class _SqErr(torch.autograd.Function):
         return None, gx, None, None, None
 
 
+# The reference's task wraps train_loss / elbo / sample / sample_history in torch.compile by default (config/task/bsi.yaml:14,
+# bsi/tasks/bsi.py:130-134).  Here these entry points are sequences of C-ABI kernel launches on raw device pointers (plus two
+# autograd.Functions whose backward is a kernel launch): there is nothing for a tracing compiler to fuse, and tracing ctypes calls
+# would only graph-break at every launch.  They are therefore OPAQUE to dynamo: `torch.compile(bsi.sample)` returns a wrapper that
+# runs the method eagerly -- same bits, same generator draws, no graphs, no recompiles (tests/test_hip_compile.py).
+def _opaque(fn):
+    """Method decorator: the body runs outside dynamo.  (Not `torch.compiler.disable` applied to the function itself:
+    `torch.compile(bound_method)` unwraps a disabled function to its UNBOUND original and drops `self`.)"""
+    import functools
+
+    inner = torch.compiler.disable(fn, recursive=True)
+
+    @functools.wraps(fn)
+    def method(self, *args, **kwargs):
+        return inner(self, *args, **kwargs)
+
+    return method
+
+
 class BSI(nn.Module):
     """Bayesian Sample Inference (arXiv 2502.07580) — drop-in for `bsi.bsi.BSI` (bsi.py:87-445).
 
@@ -228,6 +247,7 @@ class BSI(nn.Module):
             extra["bpd_var"] = (conversion_factor**2) * (l_recon_var + l_measure_var)
         return elbo, bpd, extra
 
+    @_opaque
     def elbo(self, x: Tensor, n_recon_samples: int, n_measure_samples: int, generator=None, *,
              estimate_var: bool = False):
         """Monte Carlo estimate of the infinite-step ELBO: returns (elbo[B], bpd[B], extra)."""
@@ -235,6 +255,7 @@ class BSI(nn.Module):
         l_measure = self.inf_measurement_loss(x, n_measure_samples, generator)
         return self._assemble(l_recon, l_measure, n_recon_samples, n_measure_samples, estimate_var)
 
+    @_opaque
     def finite_elbo(self, x: Tensor, n_recon_samples: int, n_measure_samples: int, generator=None, *,
                     t: Tensor | None = None, estimate_var: bool = False):
         """Monte Carlo estimate of the finite-step ELBO."""
@@ -290,6 +311,7 @@ class BSI(nn.Module):
         out = _SqErr.apply(x, x_hat, rpdf, 0.5, False)
         return out.reshape(n_samples, B)
 
+    @_opaque
     def train_loss(self, x: Tensor, generator=None) -> Tensor:
         """bsi.py:291-310: Delta*lambda*mean_D (x - x_hat)^2, one lambda per batch element -> [B]."""
         self._require_fp32()
@@ -301,6 +323,7 @@ class BSI(nn.Module):
         return _SqErr.apply(x, x_hat, rpdf, 1.0, True)
 
     # -- sampling (bsi.py:312-373) -------------------------------------------------------------------
+    @_opaque
     def sample(self, n_samples: int, generator=None, *, t: Tensor | None = None, graph: bool = False,
                device_noise: bool = False) -> Tensor:
         """Draw `n_samples` samples (Algorithm 3): k+1 denoiser evaluations.
@@ -372,6 +395,7 @@ class BSI(nn.Module):
         g.replay()
         return out.clone()
 
+    @_opaque
     def sample_history(self, n_samples: int, generator=None, *, t: Tensor | None = None):
         """As `sample`, returning (mus[k+1], x_hats[k+1], ys[k])."""
         return self._run_chain(n_samples, generator, t, history=True)

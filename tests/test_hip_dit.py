@@ -370,6 +370,84 @@ def test_fused_clip_adamw_ema_vs_golden():
     assert rel_linf(ema, ema2 + 0.25 * (flat_p - ema2)) < 1e-6    # lerp_(p, 1 - decay)
 
 
+def test_segment_forms_of_the_optimizer_kernels():
+    """bsi_sqnorm_segments / bsi_sqnorm_finish / bsi_clip_adamw_ema_segments (the data-parallel step's forms, bsi_amd/dp.py):
+    (a) on a table that tiles the buffer they reproduce the golden trajectory G8 like the flat kernels, with parameters, moments and
+    EMA BIT-identical to bsi_clip_adamw_ema given the same squared norm; (b) a table over ONE rank's slices with the gradient in a
+    compact shard buffer updates exactly those slices to the same bits and leaves the rest untouched; (c) the partial array is the
+    same whether all slices are computed at once or each rank's separately and added.  Run on G8 (53 parameters) and on a random
+    200 003-element problem whose slices span several chunks with ragged ends, at world 2 and 8."""
+    from bsi_amd import _native as N
+    from bsi_amd.dp import SQNORM_CHUNK, GradExchange
+    lib = N.lib()
+
+    def table(rows):
+        arr = (N.Seg * len(rows))(*[N.Seg(*r) for r in rows])
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+
+    def run(p0, grad_of, ref_of, norm_of, world):
+        n0 = p0.numel()
+        n = -(-n0 // (world * 4)) * (world * 4)
+        pad = lambda t: torch.cat([t, torch.zeros(n - n0)]).to(DEV)  # noqa: E731
+        a = world * 4
+        cuts = [0, (n // 3) // a * a, (2 * n // 3) // a * a, n]      # three buckets, exchanged last first
+        xc = GradExchange([(cuts[i], cuts[i + 1], None) for i in (2, 1, 0)], None, world)
+        assert xc.covers(n)
+        rows_all, ch_all = xc.segments(range(world), compact=False)
+        tab_all = table(rows_all)
+        P, M, V, E = pad(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        P2, M2, V2, E2 = P.clone(), M.clone(), V.clone(), E.clone()          # flat kernels
+        P3, M3, V3, E3 = P.clone(), M.clone(), V.clone(), E.clone()          # per-rank tables + compact gradient
+        sq = torch.zeros(1, device=DEV)
+        part = torch.zeros(xc.total_chunks, device=DEV)
+        for step in (1, 2, 3):
+            fg = pad(grad_of(step))
+            w = 1.0 if step < 3 else 0.25
+            N.check(lib.bsi_sqnorm_segments(N.ptr(fg), N.ptr(tab_all), len(rows_all), ch_all, N.ptr(part), N.stream()))
+            N.check(lib.bsi_sqnorm_finish(N.ptr(part), part.numel(), N.ptr(sq), N.stream()))
+            assert abs(float(sq.sqrt()) / norm_of(step, fg) - 1) < 1e-6
+            acc = torch.zeros_like(part)                                     # (c)
+            shards = []
+            for r in range(world):
+                rows_r, ch_r = xc.segments([r], compact=True)
+                shard = torch.cat([fg[po:po + ln] for po, _, ln, _, _ in rows_r])
+                shards.append((rows_r, ch_r, table(rows_r), shard))
+                own = torch.zeros_like(part)
+                N.check(lib.bsi_sqnorm_segments(N.ptr(shard), N.ptr(shards[-1][2]), len(rows_r), ch_r, N.ptr(own), N.stream()))
+                acc += own
+            assert torch.equal(acc, part)
+            args = (1.0, 1.0, 5e-4, 0.9, 0.99, 1e-8, 1e-2, step, w, N.stream())
+            N.check(lib.bsi_clip_adamw_ema_segments(N.ptr(P), N.ptr(fg), N.ptr(M), N.ptr(V), N.ptr(E), N.ptr(tab_all), len(rows_all),
+                                                    ch_all, N.ptr(sq), *args))
+            N.check(lib.bsi_clip_adamw_ema(N.ptr(P2), N.ptr(fg), N.ptr(M2), N.ptr(V2), N.ptr(E2), n, N.ptr(sq), *args))
+            for a_, b_ in ((P, P2), (M, M2), (V, V2), (E, E2)):
+                assert torch.equal(a_, b_)                                   # (a) same arithmetic, element for element
+            if ref_of is not None:
+                bound("test_segment_forms_of_the_optimizer_kernels:golden", rel_linf(P[:n0], ref_of(step)), 1e-6)
+            for rows_r, ch_r, tab_r, shard in shards:                        # (b) one rank at a time: only its slices move
+                before = P3.clone()
+                N.check(lib.bsi_clip_adamw_ema_segments(N.ptr(P3), N.ptr(shard), N.ptr(M3), N.ptr(V3), N.ptr(E3), N.ptr(tab_r),
+                                                        len(rows_r), ch_r, N.ptr(sq), *args))
+                own = torch.zeros(n, dtype=torch.bool, device=DEV)
+                for po, _, ln, _, _ in rows_r:
+                    own[po:po + ln] = True
+                assert torch.equal(P3[~own], before[~own]) and torch.equal(P3[own], P[own])
+            assert torch.equal(P3, P) and torch.equal(E3, E) and torch.equal(M3, M) and torch.equal(V3, V)
+        return rows_all
+
+    g = golden("g8_optimizer")
+    names = sorted(k[3:] for k in g if k.startswith("p0."))
+    cat = lambda pre: torch.cat([g[pre + nm].reshape(-1) for nm in names])  # noqa: E731
+    run(cat("p0."), lambda s_: cat(f"g{s_}."), lambda s_: cat(f"p{s_}."), lambda s_, fg: float(g[f"norm{s_}"]), 2)
+    gen = torch.Generator().manual_seed(5)
+    p0 = torch.randn(200003, generator=gen)
+    grads = {s_: torch.randn(200003, generator=gen) * (10.0 ** -s_) for s_ in (1, 2, 3)}
+    for world in (2, 8):
+        rows = run(p0, lambda s_: grads[s_], None, lambda s_, fg: float(fg.double().norm()), world)
+        assert any(ln % SQNORM_CHUNK for _, _, ln, _, _ in rows)
+    assert any(ln > SQNORM_CHUNK for _, _, ln, _, _ in rows) or world == 8
+
+
 def test_dp_trainer_single_gpu_step():
     """DPTrainer.train_step on one GPU: parameters after one step equal clip+AdamW applied to the engine's own
     gradients, EMA copies the weights during warm-up, and the bf16 shadows are refreshed for the next forward."""

@@ -74,9 +74,9 @@ def test_compiled_entry_points_equal_eager_bits():
         assert all(torch.equal(a, b) for a, b in zip(gs, grads[0][1]))
     bsi.model.eval()
     with torch.no_grad():
-        e0 = bsi.elbo(x, 1, 2, gen(12), estimate_var=True)
+        e0 = bsi.elbo(x, 2, 2, gen(12), estimate_var=True)
         for _ in range(2):
-            e1 = c_elbo(x, 1, 2, gen(12), estimate_var=True)
+            e1 = c_elbo(x, 2, 2, gen(12), estimate_var=True)
             assert torch.equal(e0[0], e1[0]) and torch.equal(e0[1], e1[1]) and torch.equal(e0[2]["bpd_var"], e1[2]["bpd_var"])
         s0 = bsi.sample(8, gen(13))
         h0 = bsi.sample_history(8, gen(14))

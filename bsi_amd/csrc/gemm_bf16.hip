@@ -54,6 +54,7 @@ struct GemmParams {
     // uniform byte strides; workgroup tile index = group * tiles_m*tiles_n + tile
     int groups;
     size_t g_a, g_w, g_bias, g_out;
+    unsigned* queue;  // DYN instances of the K = 64 kernel: the stream's tile-queue control block (common.h)
 };
 
 // tile index -> (tm, tn): the tiles are walked in bands of gm m-tiles, m fastest inside a band.  An XCD runs 32 consecutive tiles
@@ -799,7 +800,14 @@ extern int g_gm;
 // A(G+2) at ks = 1; everything needed at P+1 has then been in flight for at least two phases (the cover that a 3-slot
 // K = 32 ring has and that costs nothing).  The issue stream runs ahead of the compute across tile boundaries with its
 // own tile pointer.
-template <int EPI>
+// DYN: the tiles are not a static share but TICKETS (common.h, "tile queue"): XCD x's tiles [lo_x, hi_x) are handed out in order by
+// the counter queue[x]; a workgroup whose own XCD has run dry draws from the next XCD's counter.  The ticket of the NEXT tile is
+// drawn while the current tile computes, by wave 0, in three steps a K stage apart so that nothing ever waits: a returning atomic
+// issued in front of a load phase's DMA group (the in-order vmcnt of the following phases covers it), one stage later its value
+// stored to the workgroup's mailbox line in global memory (all 160 KB of LDS are ring), one stage later every wave loads the
+// mailbox, one stage later the value is in a scalar register -- long before the issue stream, which runs 1.5 stages ahead of the
+// arithmetic, crosses into the next tile (K >= 512).  Same tiles, same K order: bit-identical results.
+template <int EPI, bool DYN>
 __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p) {
     constexpr int TM = 8, NW = 8;
     constexpr int BM = 256, BN = 256, RB = 128;
@@ -815,11 +823,51 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
     const int wpx = (gridDim.x + 7 - xcd) >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
-    int tile = lo + wl;
-    if (tile >= hi) return;
+    auto xcd_lo = [&](int x) { return (x < r8) ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
+    int lo = xcd_lo(xcd);
+    int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     const int nk = p.K / 64;
+    int tile;
+    // DYN state (wave-uniform, identical in all 8 waves: every wave sees the same mailbox values)
+    int qx = xcd;             // the XCD whose counter the next ticket is drawn from
+    int tries = 8;            // counters not yet found empty
+    int ntile = 0;            // the next tile once `found`
+    bool found = false, pending = false;
+    unsigned tv = 0;          // the ticket / mailbox value in flight (lane 0); written only by asm statements, in place
+    unsigned* const mbox = DYN ? p.queue + BSI_TQ_MBOX + 16 * blockIdx.x : nullptr;
+    if constexpr (DYN) {
+        // first ticket: nothing is in flight yet and the ring is empty, so the value travels through the last word of LDS (slot 4,
+        // first written by the fifth half-stage, two barriers from here).  A workgroup that finds its XCD dry -- it started late --
+        // asks the other XCDs in turn.
+        unsigned* word = reinterpret_cast<unsigned*>(lds + 5 * HALF - 4);
+        if (tid == 0) {
+            unsigned t = 0xffffffffu;
+            int x = xcd, left = 8;
+            while (left > 0) {
+                const int l0 = xcd_lo(x), n = q8 + (x < r8 ? 1 : 0);
+                const unsigned got = n > 0 ? __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                if (got < (unsigned)n) { t = (unsigned)(l0 + got); break; }
+                x = (x + 1) & 7;
+                --left;
+            }
+            word[0] = t;
+            word[-1] = (unsigned)(x | (left << 8));
+        }
+        __syncthreads();
+        const unsigned t0 = word[0], st = word[-1];
+        __syncthreads();
+        qx = __builtin_amdgcn_readfirstlane((int)(st & 0xff));
+        tries = __builtin_amdgcn_readfirstlane((int)(st >> 8));
+        tile = __builtin_amdgcn_readfirstlane((int)t0);
+        lo = 0;
+        hi = nwg;  // `tile < hi` below means "a tile"; no tile = hi
+        // every counter dry (a late workgroup): no tile -- it walks through the empty prologue to the end of the kernel, where it is
+        // counted as gone.  (No early return: a second copy of the leaving code made hipcc merge the two and fail to select.)
+        if (tile < 0) tile = hi;
+    } else {
+        tile = lo + wl;
+        if (tile >= hi) return;
+    }
 
     // ---- issue stream: half-stages in the order A(0) W(0) A(1) W(1) ... over this workgroup's tiles
     const int srow = lane >> 3, spos = lane & 7;
@@ -855,7 +903,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             ihalf = 0;
             if (++iv == nk) {
                 iv = 0;
-                itile += wpx;
+                itile = DYN ? (found ? ntile : hi) : itile + wpx;  // DYN: decided by stage nk - 3 (see the K loop)
                 if (itile < hi) set_sources(itile);
             }
         } else {
@@ -907,7 +955,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     };
 
     // prologue: A(0), W(0), A(1) in flight; stage 0 must have landed before the first load phase
-    set_sources(tile);
+    if (tile < hi) set_sources(tile);
     issue_next();
     issue_next();
     bool more = issue_next();
@@ -925,15 +973,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     constexpr int NST = EPI == BSI_EPI_BIAS_GELU_DUAL ? 32 : 16;
     int after_e = 0;          // 3, 2, 1: phases after an epilogue whose stores may still be in flight
     bool pre = false, pre_status = false;  // the next load phase's half-stage was issued in front of the epilogue
-    while (true) {
-        const int next = tile + wpx;
-        const bool has_next = next < hi;
+    while (tile < hi) {
+        if constexpr (DYN) { found = false; pending = false; }
         init_acc(tile);
         for (int v = 0; v < nk; ++v) {
             const char* ba = lds + sa * HALF;
             const char* bw = lds + sw * HALF;
+            // DYN: the ticket pipeline.  `draw` stage (1, 5, 9, ... while no next tile is known, counters remain and the answer can
+            // still arrive before the issue stream leaves this tile at stage nk - 2): lane 0 of wave 0 issues a returning atomic
+            // (+1 on the counter of XCD qx) IN FRONT of the DMA group of the stage's first load phase; half a stage later, behind
+            // the wait that leaves only that phase's own DMA group in flight, the ticket is stored to the workgroup's mailbox.
+            // `fetch` stage (two stages later: the store completed a stage ago and every wave has passed a barrier since): lane 0
+            // of EVERY wave reads the mailbox the same way (an atomic +0: served by the L2 the store went to) and half a stage
+            // later all waves decode the same ticket.  The value in flight is `tv`, ONE register for the whole kernel that only
+            // these asm statements write ("+v": in place) -- a value defined by an asm load in one block and consumed in another was
+            // copied, or its register reused, by the compiler while the load was in flight (tools/check_asm_loads.py found both in
+            // earlier forms of this code).
+            const bool draw = DYN && !found && !pending && tries > 0 && (v & 3) == 1 && v <= nk - 5;
+            const bool fetch = DYN && pending && (v & 3) == 3;
+            const bool act = (draw && wave == 0) || fetch;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (DYN) {
+                    if (act && ks == 0) {
+                        unsigned long long sv;
+                        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                                     : "+v"(tv), "=&s"(sv)
+                                     : "v"(draw ? qx * 4 : 0), "v"(draw ? 1u : 0u), "s"(draw ? p.queue : mbox)
+                                     : "memory");
+                    }
+                }
                 // ---- L(v, ks): DMA issue (unless it went out in front of an epilogue), fragment reads
                 bool issued;
                 if (pre) { issued = pre_status; pre = false; }
@@ -948,7 +1017,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 // ks = 0 issued W(G+1): A(G+1) (issued one phase ago) may also stay in flight -> 8; ks = 1 issued A(G+2): the
                 // whole stage G+1 must have landed -> 4 (only the new one in flight); + the stores of a recent epilogue.
                 if (issued) {
-                    if (BF16_OUT && after_e > 0) {
+                    if (DYN && act && ks == 0) {  // DYN: the ticket atomic in front of this phase's DMA group may stay in flight too (+1)
+                        if (BF16_OUT && after_e > 0) {
+                            if (EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST + 4) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST) : "memory");
+                        } else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    } else if (BF16_OUT && after_e > 0) {
                         if (EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr) {  // + the wave tile's 4 column-sum stores (operand-free waits)
                             if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST + 4) : "memory");
                             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST + 4) : "memory");
@@ -960,6 +1034,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (after_e > 0) --after_e;
+                if constexpr (DYN) {
+                    if (draw && ks == 1) pending = true;
+                    if (act && ks == 1) {  // the wait above left at most this phase's DMA group in flight: the named wait costs nothing
+                        asm volatile("s_waitcnt vmcnt(4) ; data of %0" : "+v"(tv) :: "memory");
+                        const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+                        if (draw) {
+                            unsigned long long sv;
+                            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(sv) : "v"(0), "v"(got), "s"(mbox) : "memory");
+                        } else {
+                            const int n = q8 + (qx < r8 ? 1 : 0);
+                            if (got < (unsigned)n) {
+                                ntile = xcd_lo(qx) + (int)got;
+                                found = true;
+                            } else {
+                                qx = (qx + 1) & 7;
+                                --tries;
+                            }
+                            pending = false;
+                        }
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
                 // ---- C(v, ks)
@@ -995,11 +1091,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             tile_coords(p, tile, tm_, tn_);
             after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 3 : 0;
         }
-        if (!has_next) break;
+        const int next = DYN ? (found ? ntile : hi) : tile + wpx;
+        if (next >= hi) break;
         tile = next;
     }
     if (wm == 0) PHASE_BARRIER();
 #undef PHASE_BARRIER
+    if constexpr (DYN) {  // the last workgroup to leave zeroes the counters for the next launch on this stream
+        asm volatile("" :: "v"(tv));  // `tv` is live from the first draw to here: its register is never lent to anything else
+        if (tid == 0) {
+            const unsigned gone = __hip_atomic_fetch_add(p.queue + BSI_TQ_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i <= BSI_TQ_DONE; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 template <int TM, int WM, int WN, int EPI>
@@ -1028,11 +1135,21 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     p.gm = g_gm < p.tiles_m ? g_gm : p.tiles_m;
     if (p.gm < 1) p.gm = 1;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = nwg < compute_cus() ? nwg : compute_cus();
     const size_t lds = 5 * (size_t)256 * 128;
-    auto kern = gemm_bf16_k64r_kernel<EPI>;
-    set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    // tile queue (bsi_set_tile_queue): worth it when workgroups take more than one tile, possible when the ticket pipeline fits
+    // into a tile (K >= 512); the grid then spans ALL CUs -- the queue, not a reserve, absorbs CUs that are busy elsewhere
+    const int all = device_cus() < BSI_TQ_MAX_WG ? device_cus() : BSI_TQ_MAX_WG;
+    p.queue = (nwg > all && p.K >= 512 && p.K % 128 == 0) ? bsi_tile_queue_block(s) : nullptr;
+    if (p.queue) {
+        auto kern = gemm_bf16_k64r_kernel<EPI, true>;
+        set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        hipLaunchKernelGGL(kern, dim3(all), dim3(512), lds, s, p);
+    } else {
+        const int grid = nwg < compute_cus() ? nwg : compute_cus();
+        auto kern = gemm_bf16_k64r_kernel<EPI, false>;
+        set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    }
     BSI_CHECK_LAUNCH("bsi_gemm_bf16");
     return BSI_OK;
 }

@@ -1,6 +1,7 @@
 // Optional in-library kernel timing with HIP events (used by bench.py to measure the dominant kernel's
 // average launch duration live, on the stream the kernels are launched on).  Disabled by default: when the
 // class mask is 0 the hooks are a single predictable branch.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -39,6 +40,62 @@ extern "C" int bsi_set_cu_reserve(int cus) {
 }
 
 extern "C" int bsi_compute_cus(void) { return compute_cus(); }
+
+// ---- tile queue control blocks (common.h) --------------------------------------------------------------------------------------
+int g_bsi_tile_queue = [] {
+    const char* e = getenv("BSI_TILE_QUEUE");
+    return e ? atoi(e) : 0;
+}();
+
+extern "C" int bsi_set_tile_queue(int on) {
+    BSI_CHECK_ARG(on == 0 || on == 1, "bsi_set_tile_queue: %d is not 0 or 1", on);
+    g_bsi_tile_queue = on;
+    return BSI_OK;
+}
+
+namespace {
+constexpr int TQ_STREAMS = 64, TQ_DEVICES = 16;
+struct TqPool {
+    unsigned* base = nullptr;     // TQ_STREAMS zeroed blocks of BSI_TQ_WORDS words
+    hipStream_t owner[TQ_STREAMS] = {};
+    bool used[TQ_STREAMS] = {};
+    bool failed = false;
+};
+TqPool g_tq[TQ_DEVICES];
+std::mutex g_tq_mu;
+}  // namespace
+
+unsigned* bsi_tile_queue_block(hipStream_t s) {
+    if (!g_bsi_tile_queue) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    TqPool& pl = g_tq[dev];
+    if (!pl.base) {
+        if (pl.failed) return nullptr;
+        // the pool is allocated (and zeroed, synchronously) at the first launch that wants it; that cannot happen inside a stream
+        // capture -- such a launch, and every launch after a failure, takes the static schedule
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+        void* mem = nullptr;
+        const size_t bytes = (size_t)TQ_STREAMS * BSI_TQ_WORDS * sizeof(unsigned);
+        if (hipMalloc(&mem, bytes) != hipSuccess || hipMemset(mem, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            pl.failed = true;
+            return nullptr;
+        }
+        pl.base = reinterpret_cast<unsigned*>(mem);
+    }
+    int free_slot = -1;
+    for (int i = 0; i < TQ_STREAMS; ++i) {
+        if (pl.used[i] && pl.owner[i] == s) return pl.base + (size_t)i * BSI_TQ_WORDS;
+        if (!pl.used[i] && free_slot < 0) free_slot = i;
+    }
+    if (free_slot < 0) return nullptr;  // more streams than blocks: static schedule
+    pl.used[free_slot] = true;
+    pl.owner[free_slot] = s;
+    return pl.base + (size_t)free_slot * BSI_TQ_WORDS;
+}
 
 void bsi_prof_begin(int cls, hipStream_t s) {
     if (!(g_mask & (1u << cls))) return;

@@ -679,6 +679,12 @@ enum {
 #define BSI_MAX_CU_RESERVE 64
 int bsi_set_cu_reserve(int cus);
 int bsi_compute_cus(void);
+/* Tile queue of the persistent bf16 GEMM (K >= 512, more tiles than CUs): 1 = workgroups draw tile tickets from per-XCD counters in
+ * device memory (and from the other XCDs' once their own is empty) instead of taking a static share, and the grid ignores the CU
+ * reserve: a workgroup whose CU is held by a kernel of another stream leaves its share to the others, and no CU idles while RCCL
+ * is quiet.  Same tiles, same arithmetic per tile: results are bit-identical to the static schedule.  Process-wide, takes effect
+ * at the next launch; default 0 (env BSI_TILE_QUEUE overrides).  DPTrainer switches it on for steps that exchange gradients. */
+int bsi_set_tile_queue(int on);
 /* bit i of mask enables class i; 0 disables.  Events are recorded around every launch of an enabled class
  * made through bsi_dit_forward / bsi_dit_adaln. */
 int bsi_prof_enable(unsigned mask);

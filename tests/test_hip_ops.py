@@ -580,6 +580,56 @@ def test_cu_reserve_changes_grids_not_results(N):
     assert rel_linf(held[1], base[1]) < 1e-5
 
 
+@pytest.mark.parametrize("M,Nn,K", [(16384, 4096, 1024), (16384, 1024, 4096), (16384 + 77, 3072, 1024), (32768, 1024, 512), (70000, 1280, 1152)])
+def test_gemm_tile_queue_is_bit_identical_to_the_static_schedule(N, M, Nn, K):
+    """bsi_set_tile_queue(1): workgroups of the persistent K = 64 GEMM draw tile tickets from per-XCD counters (and from the other
+    XCDs' once theirs is dry) instead of a static share.  Same tiles, same arithmetic per tile: the outputs must be the static
+    schedule's bits for every epilogue that kernel takes -- over repeated launches (the last workgroup resets the counters), with a
+    CU reserve in force (the queue's grid ignores it), with ragged M, and on a second stream (its own control block)."""
+    lib = N.lib()
+    gen = torch.Generator().manual_seed(M + Nn + K)
+    A = dev(torch.randn((M, K), generator=gen).to(torch.bfloat16))
+    W = dev((torch.randn((Nn, K), generator=gen) / 32).to(torch.bfloat16))
+    bias = dev(torch.randn(Nn, generator=gen))
+    aux = dev(torch.randn((M, Nn), generator=gen).to(torch.bfloat16))
+
+    def run(epi, stream=None):
+        out = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out2 = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=DEV) if epi == N.EPI_BIAS_GELU_DUAL else None
+        a = N.GemmArgs(A=A.data_ptr(), W=W.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), M=M, N=Nn, K=K, lda=K, ldw=K, ldo=Nn,
+                       epilogue=epi, aux=aux.data_ptr() if epi == N.EPI_MUL_GELUGRAD_BF16 else None,
+                       out2=out2.data_ptr() if out2 is not None else None)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else N.stream()
+        N.check(lib.bsi_gemm_bf16(C.byref(a), st))
+        return out, out2
+
+    epis = [N.EPI_BIAS_BF16, N.EPI_BIAS_GELU_BF16, N.EPI_BIAS_GELU_DUAL, N.EPI_MUL_GELUGRAD_BF16]
+    N.check(lib.bsi_set_tile_queue(0))
+    base = {e: run(e) for e in epis}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    try:
+        N.check(lib.bsi_set_tile_queue(1))
+        assert lib.bsi_set_tile_queue(2) != 0
+        for rep in range(3):
+            if rep == 2:
+                N.check(lib.bsi_set_cu_reserve(32))
+            for e in epis:
+                got = run(e)
+                assert torch.equal(got[0], base[e][0]) and (got[1] is None or torch.equal(got[1], base[e][1])), (rep, e)
+        N.check(lib.bsi_set_cu_reserve(0))
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            a_, _ = run(N.EPI_BIAS_GELU_BF16, side)
+        b_, _ = run(N.EPI_BIAS_BF16)           # concurrently on the current stream: each stream has its own counters
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(a_, base[N.EPI_BIAS_GELU_BF16][0]) and torch.equal(b_, base[N.EPI_BIAS_BF16][0])
+    finally:
+        N.check(lib.bsi_set_cu_reserve(0))
+        N.check(lib.bsi_set_tile_queue(0))
+
+
 @pytest.mark.parametrize("p", [0.05, 0.3])
 def test_attention_dropout_words_equal_the_exported_mask(N, p):
     """The lane-mask words of the 256-token attention kernels (bsi_attention_dropout_words) against bsi_dropout_mask for the same

@@ -53,7 +53,8 @@ def blocks_of(func):
         if not code or code.startswith((";", ".")) or code.endswith(":"):
             continue
         if in_asm:
-            if code.startswith(("global_load", "buffer_load")) and " lds" not in code:
+            if (code.startswith(("global_load", "buffer_load")) and " lds" not in code) or \
+                    (code.startswith("global_atomic") and code.rstrip().endswith("sc0")):  # returning atomics write their first operand like a load
                 cur[1].append((ln, "load", (regs_of(code.split(",")[0]), "vm")))
             elif code.startswith("ds_read"):  # inline-asm LDS reads (transposed reads the compiler must not wait vmcnt(0) for)
                 cur[1].append((ln, "load", (regs_of(code.split(",")[0]), "lgkm")))

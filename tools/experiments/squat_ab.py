@@ -63,16 +63,20 @@ def main():
         tr.train_step(x, g)
     torch.cuda.synchronize()
 
-    def one_step(squat, reserve, est_ms):
+    def one_step(squat, reserve, est_ms, queue=0, duty=1.0):
         tr.cu_reserve = reserve
+        N.check(N.lib().bsi_set_tile_queue(queue))
         n_pieces = 0
+        gap_us = int(piece_us * (1.0 / duty - 1.0)) if squat else 0   # duty < 1: the squatter holds its CUs `duty` of the time
         if squat:
             # enough back-to-back pieces to cover the whole step (they queue on the side stream and run one after the other)
-            n_pieces = int(est_ms * 1.6 * 1000 / piece_us) + 2
+            n_pieces = int(est_ms * 1.6 * 1000 / (piece_us + gap_us)) + 2
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_pieces):
             assert sq.squat_launch(squat, piece_us, lds, C.c_void_p(side.cuda_stream)) == 0
+            if gap_us:  # the gap: a one-workgroup kernel without LDS (an idle communication stream would hold nothing at all)
+                assert sq.squat_launch(1, gap_us, 0, C.c_void_p(side.cuda_stream)) == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         tr.train_step(x, g)
@@ -82,23 +86,31 @@ def main():
         torch.cuda.synchronize()                            # the rest of the squatter pieces drain here, outside the measurement
         return ms, 1e3 * (time.perf_counter() - t0)
 
-    arms = [("free", 0, 0), ("reserve 16", 0, 16), ("reserve 32", 0, 32), ("squat 16", 16, 0), ("squat 16 + reserve 16", 16, 16),
-            ("squat 32", 32, 0), ("squat 32 + reserve 32", 32, 32), ("squat 8 + reserve 16", 8, 16)]
+    # (name, squatter CUs, reserve, tile queue, squatter duty)
+    arms = [("free", 0, 0, 0, 1.0), ("free, queue", 0, 0, 1, 1.0), ("reserve 16", 0, 16, 0, 1.0), ("reserve 16, queue", 0, 16, 1, 1.0),
+            ("squat 16", 16, 0, 0, 1.0), ("squat 16, queue", 16, 0, 1, 1.0), ("squat 16 + reserve 16", 16, 16, 0, 1.0),
+            ("squat 16 + reserve 16, queue", 16, 16, 1, 1.0),
+            ("squat 16 at 30 % duty + reserve 16", 16, 16, 0, 0.3), ("squat 16 at 30 % duty + reserve 16, queue", 16, 16, 1, 0.3),
+            ("squat 16 at 30 % duty, queue", 16, 0, 1, 0.3)]
+    if os.environ.get("ARMS"):
+        keep = os.environ["ARMS"].split(";")
+        arms = [a for a in arms if a[0] in keep or a[0] == "free"]
     res = {a[0]: [] for a in arms}
     base = one_step(0, 0, 0)[0]
     for _ in range(rounds):
-        for name, s_, r_ in arms:
+        for name, s_, r_, q_, d_ in arms:
             for _ in range(steps):
-                res[name].append(one_step(s_, r_, base * 2.2)[0])
+                res[name].append(one_step(s_, r_, base * 2.2, q_, d_)[0])
+    N.check(N.lib().bsi_set_tile_queue(0))
     free = statistics.median(res["free"])
     print(f"# DiT-L/2 DPTrainer.train_step, per-GPU batch {B}, one MI355X ({N.lib().bsi_compute_cus()} CUs), squatter pieces of {piece_us} us "
           f"with {lds // 1024} KB of LDS per workgroup on a high-priority stream; {rounds} interleaved rounds x {steps} steps, ms per step")
-    print(f"{'arm':28s} {'median':>9s} {'min':>9s} {'max':>9s} {'vs free':>9s}   allowed (CUs taken / 256 + 3 %)")
-    for name, s_, r_ in arms:
+    print(f"{'arm':44s} {'median':>9s} {'min':>9s} {'max':>9s} {'vs free':>9s}   allowed (CUs taken / 256 + 3 %)")
+    for name, s_, r_, q_, d_ in arms:
         v = res[name]
         med = statistics.median(v)
         allowed = f"{100 * (max(s_, r_) / 256 + 0.03):5.1f} %" if (s_ or r_) else ""
-        print(f"{name:28s} {med:9.2f} {min(v):9.2f} {max(v):9.2f} {100 * (med / free - 1):+8.1f} %   {allowed}")
+        print(f"{name:44s} {med:9.2f} {min(v):9.2f} {max(v):9.2f} {100 * (med / free - 1):+8.1f} %   {allowed}")
 
 
 if __name__ == "__main__":

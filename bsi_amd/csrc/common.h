@@ -92,12 +92,17 @@ inline int compute_cus() {
 // tickets from per-XCD counters in device memory, so a workgroup that starts late -- its CU held by a communication kernel of
 // another stream (the RCCL all-reduce of the data-parallel step) -- leaves its share to the others instead of running it alone
 // at the end.  Layout of a control block (unsigned words, zero between launches: the last workgroup to leave resets it):
-// [0..7] next ticket of XCD x, [8] workgroups that have left, [16 + 16 * blockIdx.x] this workgroup's mailbox (one 64-byte line:
-// wave 0 draws the ticket, the other waves read it there).  One block per stream (kernels of a stream are serialised).
-constexpr int BSI_TQ_DONE = 8, BSI_TQ_MBOX = 16, BSI_TQ_MAX_WG = 512;
+// [0..7] next ticket of XCD x, [8..15] workgroups of XCD x that have left, [16] XCDs whose workgroups have all left (leaving is
+// counted in two levels: 256 returning atomics on ONE word serialise into a 10-20 us tail of the kernel), [32 + 16 * blockIdx.x]
+// this workgroup's mailbox (one 64-byte line: wave 0 draws the ticket, the other waves read it there).  One block per stream
+// (kernels of a stream are serialised).
+constexpr int BSI_TQ_GONE = 8, BSI_TQ_XCDS = 16, BSI_TQ_MBOX = 32, BSI_TQ_MAX_WG = 512;
 constexpr size_t BSI_TQ_WORDS = BSI_TQ_MBOX + 16 * (size_t)BSI_TQ_MAX_WG;
 extern int g_bsi_tile_queue;                    // prof.hip: 0 = static shares, 1 = tickets where a kernel supports them
 unsigned* bsi_tile_queue_block(hipStream_t s);  // prof.hip: the stream's control block, or nullptr (queue off / none available)
+#ifdef BSI_LAB
+extern unsigned* g_lab_static_block;            // prof.hip (laboratory build): where the static schedule leaves its stamps
+#endif
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);

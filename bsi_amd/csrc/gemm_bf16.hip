@@ -831,39 +831,85 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     // DYN state (wave-uniform, identical in all 8 waves: every wave sees the same mailbox values)
     int qx = xcd;             // the XCD whose counter the next ticket is drawn from
     int tries = 8;            // counters not yet found empty
-    int ntile = 0;            // the next tile once `found`
-    bool found = false, pending = false;
-    unsigned tv = 0;          // the ticket / mailbox value in flight (lane 0); written only by asm statements, in place
+    int ntile = 0;            // the tile after the current one, once `found`
+    bool found = false;
+    int ev = -1, ek = 0;      // ticket pipeline: the K stage of its next step, and the step (0 draw, 1 store, 2 fetch, 3 decode)
     unsigned* const mbox = DYN ? p.queue + BSI_TQ_MBOX + 16 * blockIdx.x : nullptr;
+    // The ticket / mailbox value in flight lives in the FIXED register v255, named in the asm text and listed as a clobber: hipcc
+    // then counts it as used but, allocating from v0 upwards and needing fewer than 255 registers here, never names it itself --
+    // tools/check_asm_loads.py (tests/test_asm_waits.py) verifies that for every build.  A compiler-allocated destination was
+    // copied, split or lent to another value while the load was in flight in every earlier form of this code ("+v" operands do not
+    // pin a value to ONE register across blocks); accumulator registers are no way out either: an asm statement that names one makes
+    // hipcc halve the kernel's VGPR budget (128 + 128: 400-580 bytes of scratch per lane).
+    // lane 0 of this wave only: returning atomic +1 on (base + off) -> v255
+#define TQ_DRAW(off, base)                                                                                                      \
+    do {                                                                                                                        \
+        unsigned long long sv_;                                                                                                 \
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"   \
+                     : "=&s"(sv_) : "v"(off), "v"(1u), "s"(base) : "memory", "v255");                                           \
+    } while (0)
+    // waits until at most four younger vector-memory operations (a DMA group) are in flight, then reads v255 (lane 0's value, as a scalar)
+#define TQ_VALUE(dst)                                                                                                           \
+    do {                                                                                                                        \
+        unsigned v_;                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(4)\n\tv_mov_b32 %0, v255" : "=v"(v_) :: "memory", "v255");                                \
+        dst = (unsigned)__builtin_amdgcn_readfirstlane((int)v_);                                                                \
+    } while (0)
+#ifdef BSI_LAB
+    unsigned long long lab_t0 = __builtin_amdgcn_s_memrealtime(), lab_t1 = 0;
+    unsigned lab_tiles = 0;
+#endif
     if constexpr (DYN) {
-        // first ticket: nothing is in flight yet and the ring is empty, so the value travels through the last word of LDS (slot 4,
-        // first written by the fifth half-stage, two barriers from here).  A workgroup that finds its XCD dry -- it started late --
-        // asks the other XCDs in turn.
+        // The first TWO tickets (this workgroup's first tile and the one after it) are drawn together by thread 0 before anything is
+        // in flight; the ring is still empty, so the values travel through the last words of LDS (slot 4, first written by the fifth
+        // half-stage, two barriers from here).  A workgroup that finds its XCD dry -- it started late -- asks the other XCDs in turn.
         unsigned* word = reinterpret_cast<unsigned*>(lds + 5 * HALF - 4);
         if (tid == 0) {
-            unsigned t = 0xffffffffu;
+            unsigned t0 = 0xffffffffu, t1 = 0xffffffffu;
             int x = xcd, left = 8;
-            while (left > 0) {
-                const int l0 = xcd_lo(x), n = q8 + (x < r8 ? 1 : 0);
+            {
+                const int n = q8 + (x < r8 ? 1 : 0);
+                unsigned g0 = 0xffffffffu, g1 = 0xffffffffu;
+                if (n > 0) {  // two atomics in flight, one wait
+                    g0 = __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (g1 < g0) { const unsigned t = g0; g0 = g1; g1 = t; }
+                if (g0 < (unsigned)n) t0 = (unsigned)xcd_lo(x) + g0;
+                if (g1 < (unsigned)n) t1 = (unsigned)xcd_lo(x) + g1;
+                if (g1 + (unsigned)wpx >= (unsigned)n) { x = (x + 1) & 7; --left; }  // the next draw would find this counter dry
+            }
+            while (t0 == 0xffffffffu && left > 0) {  // a late workgroup
+                const int n = q8 + (x < r8 ? 1 : 0);
                 const unsigned got = n > 0 ? __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                if (got < (unsigned)n) { t = (unsigned)(l0 + got); break; }
+                if (got < (unsigned)n) { t0 = (unsigned)xcd_lo(x) + got; break; }
                 x = (x + 1) & 7;
                 --left;
             }
-            word[0] = t;
-            word[-1] = (unsigned)(x | (left << 8));
+            word[0] = t0;
+            word[-1] = t1;
+            word[-2] = (unsigned)(x | (left << 8));
         }
         __syncthreads();
-        const unsigned t0 = word[0], st = word[-1];
+        const unsigned t0 = word[0], t1 = word[-1], st = word[-2];
         __syncthreads();
         qx = __builtin_amdgcn_readfirstlane((int)(st & 0xff));
         tries = __builtin_amdgcn_readfirstlane((int)(st >> 8));
         tile = __builtin_amdgcn_readfirstlane((int)t0);
+        ntile = __builtin_amdgcn_readfirstlane((int)t1);
         lo = 0;
         hi = nwg;  // `tile < hi` below means "a tile"; no tile = hi
         // every counter dry (a late workgroup): no tile -- it walks through the empty prologue to the end of the kernel, where it is
         // counted as gone.  (No early return: a second copy of the leaving code made hipcc merge the two and fail to select.)
         if (tile < 0) tile = hi;
+        found = ntile >= 0;
+        if (!found && tries > 0 && tile < hi && nk >= 10) { ev = 5; ek = 0; }  // no second ticket yet: draw again inside the first tile
+#ifdef BSI_LAB
+        lab_t1 = __builtin_amdgcn_s_memrealtime();
+        if (p.splits > 1000) {  // laboratory: align the start of all workgroups to (entry + splits - 1000 ticks of 10 ns)
+            while (__builtin_amdgcn_s_memrealtime() - lab_t0 < (unsigned long long)(p.splits - 1000)) __builtin_amdgcn_s_sleep(1);
+        }
+#endif
     } else {
         tile = lo + wl;
         if (tile >= hi) return;
@@ -903,7 +949,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             ihalf = 0;
             if (++iv == nk) {
                 iv = 0;
-                itile = DYN ? (found ? ntile : hi) : itile + wpx;  // DYN: decided by stage nk - 3 (see the K loop)
+                itile = DYN ? (found ? ntile : hi) : itile + wpx;  // DYN: decided by stage nk - 2 (see the K loop)
                 if (itile < hi) set_sources(itile);
             }
         } else {
@@ -974,35 +1020,54 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     int after_e = 0;          // 3, 2, 1: phases after an epilogue whose stores may still be in flight
     bool pre = false, pre_status = false;  // the next load phase's half-stage was issued in front of the epilogue
     while (tile < hi) {
-        if constexpr (DYN) { found = false; pending = false; }
         init_acc(tile);
         for (int v = 0; v < nk; ++v) {
             const char* ba = lds + sa * HALF;
             const char* bw = lds + sw * HALF;
-            // DYN: the ticket pipeline.  `draw` stage (1, 5, 9, ... while no next tile is known, counters remain and the answer can
-            // still arrive before the issue stream leaves this tile at stage nk - 2): lane 0 of wave 0 issues a returning atomic
-            // (+1 on the counter of XCD qx) IN FRONT of the DMA group of the stage's first load phase; half a stage later, behind
-            // the wait that leaves only that phase's own DMA group in flight, the ticket is stored to the workgroup's mailbox.
-            // `fetch` stage (two stages later: the store completed a stage ago and every wave has passed a barrier since): lane 0
-            // of EVERY wave reads the mailbox the same way (an atomic +0: served by the L2 the store went to) and half a stage
-            // later all waves decode the same ticket.  The value in flight is `tv`, ONE register for the whole kernel that only
-            // these asm statements write ("+v": in place) -- a value defined by an asm load in one block and consumed in another was
-            // copied, or its register reused, by the compiler while the load was in flight (tools/check_asm_loads.py found both in
-            // earlier forms of this code).
-            const bool draw = DYN && !found && !pending && tries > 0 && (v & 3) == 1 && v <= nk - 5;
-            const bool fetch = DYN && pending && (v & 3) == 3;
-            const bool act = (draw && wave == 0) || fetch;
+            if constexpr (DYN) {
+                // ---- the ticket pipeline: one step at the TOP of a K stage (in front of its first DMA group), a stage apart; the phases
+                // below are the static schedule's, untouched.  The ticket of the tile after this one was drawn by wave 0 at the tile
+                // boundary, in front of the epilogue's stores (a returning atomic takes ~1.5 us; the stores' allowance of the next three
+                // phases covers it) -> stage 2: wave 0 stores it to the workgroup's mailbox -> stage 3 (the store completed a stage
+                // ago, every wave has passed a barrier since): lane 0 of every wave loads the mailbox -> stage 4: all waves decode the
+                // same ticket -- long before the issue stream leaves this tile at stage nk - 2.  A dry counter: draw again from the
+                // next XCD's, from inside the tile (stages 5 / 9: that atomic is waited for half a stage later, ~1 us, end of the
+                // kernel only).  The value in flight sits in the reserved register v255 (see TQ_DRAW above).
+                if (v == ev) {
+                    if (ek == 0) {
+                        if (wave == 0) TQ_DRAW(qx * 4, p.queue);
+                    } else if (ek == 1) {
+                        if (wave == 0) {  // at most the previous phase's DMA group is younger than the atomic: landed
+                            unsigned tk;
+                            TQ_VALUE(tk);
+                            unsigned long long sv_;
+                            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %2, %3 sc1\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(sv_) : "v"(0), "v"(tk), "s"(mbox) : "memory");
+                        }
+                    } else if (ek == 2) {
+                        unsigned long long sv_;
+                        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_load_dword v255, %1, %2 sc1\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(sv_) : "v"(0), "s"(mbox) : "memory", "v255");
+                    } else {
+                        unsigned got;
+                        TQ_VALUE(got);
+                        const int n = q8 + (qx < r8 ? 1 : 0);
+                        if (got < (unsigned)n) {
+                            ntile = xcd_lo(qx) + (int)got;
+                            found = true;
+                            if (got + (unsigned)wpx >= (unsigned)n) { qx = (qx + 1) & 7; --tries; }  // the next draw would find it dry
+                        } else {
+                            qx = (qx + 1) & 7;
+                            --tries;
+                        }
+                    }
+                    if (ek < 3) { ++ek; ev = v + 1; }
+                    else if (!found && tries > 0 && v + 4 <= nk - 2) { ek = 0; ev = v + 1; }
+                    else ev = -1;
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (DYN) {
-                    if (act && ks == 0) {
-                        unsigned long long sv;
-                        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
-                                     : "+v"(tv), "=&s"(sv)
-                                     : "v"(draw ? qx * 4 : 0), "v"(draw ? 1u : 0u), "s"(draw ? p.queue : mbox)
-                                     : "memory");
-                    }
-                }
                 // ---- L(v, ks): DMA issue (unless it went out in front of an epilogue), fragment reads
                 bool issued;
                 if (pre) { issued = pre_status; pre = false; }
@@ -1017,12 +1082,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 // ks = 0 issued W(G+1): A(G+1) (issued one phase ago) may also stay in flight -> 8; ks = 1 issued A(G+2): the
                 // whole stage G+1 must have landed -> 4 (only the new one in flight); + the stores of a recent epilogue.
                 if (issued) {
-                    if (DYN && act && ks == 0) {  // DYN: the ticket atomic in front of this phase's DMA group may stay in flight too (+1)
-                        if (BF16_OUT && after_e > 0) {
-                            if (EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST + 4) : "memory");
-                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST) : "memory");
-                        } else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    } else if (BF16_OUT && after_e > 0) {
+                    if (BF16_OUT && after_e > 0) {
                         if (EPI == BSI_EPI_MUL_GELUGRAD_BF16 && p.colsum != nullptr) {  // + the wave tile's 4 column-sum stores (operand-free waits)
                             if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST + 4) : "memory");
                             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST + 4) : "memory");
@@ -1034,28 +1094,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (after_e > 0) --after_e;
-                if constexpr (DYN) {
-                    if (draw && ks == 1) pending = true;
-                    if (act && ks == 1) {  // the wait above left at most this phase's DMA group in flight: the named wait costs nothing
-                        asm volatile("s_waitcnt vmcnt(4) ; data of %0" : "+v"(tv) :: "memory");
-                        const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
-                        if (draw) {
-                            unsigned long long sv;
-                            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
-                                         : "=&s"(sv) : "v"(0), "v"(got), "s"(mbox) : "memory");
-                        } else {
-                            const int n = q8 + (qx < r8 ? 1 : 0);
-                            if (got < (unsigned)n) {
-                                ntile = xcd_lo(qx) + (int)got;
-                                found = true;
-                            } else {
-                                qx = (qx + 1) & 7;
-                                --tries;
-                            }
-                            pending = false;
-                        }
-                    }
-                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
                 // ---- C(v, ks)
@@ -1081,9 +1119,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             sa = sa >= 3 ? sa - 3 : sa + 2;
             sw = sw >= 3 ? sw - 3 : sw + 2;
         }
+        // DYN: the ticket of the tile after the NEXT one is drawn here, at the boundary, if there is a next tile and counters remain
+        const bool want = DYN && found && tries > 0 && nk >= 8;
         if (wm == 0) {  // group A: after that barrier, i.e. at the start of its next load phase
             pre_status = issue_next();
             pre = true;
+            if constexpr (DYN) {
+                if (want && wave == 0) TQ_DRAW(qx * 4, p.queue);  // in front of the epilogue's stores: their allowance covers it
+            }
             epilogue(tile);
         }
         {   // the store allowance of the next phases is valid only if every store of the epilogue is issued (no M / N tail)
@@ -1091,19 +1134,48 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             tile_coords(p, tile, tm_, tn_);
             after_e = (tm_ * 256 + 256 <= p.M && tn_ * 256 + 256 <= p.N) ? 3 : 0;
         }
+#ifdef BSI_LAB
+        if (tid == 0 && p.queue && lab_tiles < 8 && blockIdx.x < 256) {  // end of tile `lab_tiles`: (low word of the time, tile index)
+            unsigned* e = p.queue + BSI_TQ_MBOX + 16 * (256 + blockIdx.x) + 2 * lab_tiles;
+            e[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
+            e[1] = (unsigned)tile;
+        }
+        ++lab_tiles;
+#endif
         const int next = DYN ? (found ? ntile : hi) : tile + wpx;
         if (next >= hi) break;
         tile = next;
+        if constexpr (DYN) {  // the tile after `next` is unknown again; its ticket, if drawn, is stored at stage 2
+            found = false;
+            if (want) { ev = 2; ek = 1; }
+            else if (tries > 0 && nk >= 10) { ev = 5; ek = 0; }
+            else ev = -1;
+        }
     }
     if (wm == 0) PHASE_BARRIER();
 #undef PHASE_BARRIER
+#undef TQ_DRAW
+#undef TQ_VALUE
+#ifdef BSI_LAB
+    if (tid == 0 && p.queue) {  // laboratory build: per-workgroup stamps in the mailbox line (100 MHz ticks): entry, first ticket known, leaving
+        unsigned* mb_ = p.queue + BSI_TQ_MBOX + 16 * blockIdx.x;
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(mb_ + 2);
+        const unsigned long long prev_leave = st[2];
+        st[0] = lab_t0; st[1] = lab_t1; st[2] = __builtin_amdgcn_s_memrealtime();
+        reinterpret_cast<unsigned long long*>(mb_ + 10)[0] = prev_leave;
+        mb_[1] = lab_tiles;
+    }
+#endif
     if constexpr (DYN) {  // the last workgroup to leave zeroes the counters for the next launch on this stream
-        asm volatile("" :: "v"(tv));  // `tv` is live from the first draw to here: its register is never lent to anything else
         if (tid == 0) {
-            const unsigned gone = __hip_atomic_fetch_add(p.queue + BSI_TQ_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gone == gridDim.x - 1) {
+            const unsigned gone = __hip_atomic_fetch_add(p.queue + BSI_TQ_GONE + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == (unsigned)wpx - 1) {  // last of this XCD's workgroups
+                const unsigned xg = __hip_atomic_fetch_add(p.queue + BSI_TQ_XCDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned nx = gridDim.x < 8 ? gridDim.x : 8;
+                if (xg == nx - 1) {
 #pragma unroll
-                for (int i = 0; i <= BSI_TQ_DONE; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i <= BSI_TQ_XCDS; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -1139,8 +1211,25 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     // tile queue (bsi_set_tile_queue): worth it when workgroups take more than one tile, possible when the ticket pipeline fits
     // into a tile (K >= 512); the grid then spans ALL CUs -- the queue, not a reserve, absorbs CUs that are busy elsewhere
     const int all = device_cus() < BSI_TQ_MAX_WG ? device_cus() : BSI_TQ_MAX_WG;
-    p.queue = (nwg > all && p.K >= 512 && p.K % 128 == 0) ? bsi_tile_queue_block(s) : nullptr;
+    p.queue = (nwg > all && p.K >= 512) ? bsi_tile_queue_block(s) : nullptr;
+#ifdef BSI_LAB
+    unsigned*& lab_block = g_lab_static_block;  // laboratory build: the static schedule stamps into a block of its own
+    if (!p.queue && getenv("BSI_LAB_STAMPS")) {
+        if (!lab_block && hipMalloc(reinterpret_cast<void**>(&lab_block), BSI_TQ_WORDS * 4) == hipSuccess) (void)hipMemset(lab_block, 0, BSI_TQ_WORDS * 4);
+        GemmParams ps = p;
+        ps.queue = lab_block;
+        const int grid = nwg < compute_cus() ? nwg : compute_cus();
+        auto kern = gemm_bf16_k64r_kernel<EPI, false>;
+        set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, ps);
+        BSI_CHECK_LAUNCH("bsi_gemm_bf16");
+        return BSI_OK;
+    }
+#endif
     if (p.queue) {
+#ifdef BSI_LAB
+        if (getenv("BSI_LAB_ALIGN")) p.splits = 1000 + atoi(getenv("BSI_LAB_ALIGN"));
+#endif
         auto kern = gemm_bf16_k64r_kernel<EPI, true>;
         set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, dim3(all), dim3(512), lds, s, p);

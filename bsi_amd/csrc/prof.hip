@@ -65,6 +65,13 @@ TqPool g_tq[TQ_DEVICES];
 std::mutex g_tq_mu;
 }  // namespace
 
+#ifdef BSI_LAB
+unsigned* g_lab_static_block = nullptr;  // gemm_bf16.hip (laboratory build): the stamp block of the static schedule
+extern "C" void* bsi_lab_tile_queue_block(void* stream) {
+    return g_bsi_tile_queue ? bsi_tile_queue_block(reinterpret_cast<hipStream_t>(stream)) : g_lab_static_block;
+}
+#endif
+
 unsigned* bsi_tile_queue_block(hipStream_t s) {
     if (!g_bsi_tile_queue) return nullptr;
     int dev = 0;

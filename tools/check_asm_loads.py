@@ -88,10 +88,33 @@ def blocks_of(func):
     return blocks
 
 
+RESERVED = re.compile(r"\bv255\b|\bv\[(\d+):255\]")
+
+
+def check_reserved_register(name, func):
+    """Kernels whose inline asm lands vector-memory results in the FIXED register v255 (gemm_bf16.hip, the tile queue's ticket) rely on
+    the compiler never naming that register itself (it is a clobber of those statements, not an operand): report every instruction
+    outside the asm blocks that does."""
+    lines = func.split("\n")
+    in_asm, uses_fixed, out = False, False, []
+    for ln, line in enumerate(lines):
+        code = line.strip()
+        if code.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif code.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm:
+            uses_fixed |= bool(re.match(r"(global_atomic\w*|global_load_dword\w*)\s+v255\b", code))
+        elif code and not code.startswith((";", ".")) and RESERVED.search(code.split(";")[0]):
+            out.append(f"{name}: line {ln}: `{code}` names v255 outside the asm statements that reserve it")
+    return out if uses_fixed else []
+
+
 def check(asm_text):
     problems, n_loads, n_waits = [], 0, 0
     for func in re.split(r"\n(?=_Z\w+:)", asm_text):
         name = func.split(":")[0]
+        problems += check_reserved_register(name, func)
         blocks = blocks_of(func)
         index = {b[0]: i for i, b in enumerate(blocks) if b[0]}
         succ = [set() for _ in blocks]

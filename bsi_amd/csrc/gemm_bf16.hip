@@ -832,6 +832,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     int qx = xcd;             // the XCD whose counter the next ticket is drawn from
     int tries = 8;            // counters not yet found empty
     int ntile = 0;            // the tile after the current one, once `found`
+    int extra = -1;           // the tile after THAT, when a ticket stood for two tiles (see the first draw)
     bool found = false;
     int ev = -1, ek = 0;      // ticket pipeline: the K stage of its next step, and the step (0 draw, 1 store, 2 fetch, 3 decode)
     unsigned* const mbox = DYN ? p.queue + BSI_TQ_MBOX + 16 * blockIdx.x : nullptr;
@@ -860,31 +861,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
     unsigned lab_tiles = 0;
 #endif
     if constexpr (DYN) {
-        // The first TWO tickets (this workgroup's first tile and the one after it) are drawn together by thread 0 before anything is
-        // in flight; the ring is still empty, so the values travel through the last words of LDS (slot 4, first written by the fifth
-        // half-stage, two barriers from here).  A workgroup that finds its XCD dry -- it started late -- asks the other XCDs in turn.
+        // Ticket T of XCD x's counter stands for TWO tiles while T < W (W = the XCD's workgroups in this grid): tiles T and T + W of
+        // the XCD's range -- the first two rounds are dealt as the static schedule deals them (32 neighbouring tiles of an XCD in flight
+        // together: drawing two tickets per workgroup instead put every other tile of a 64-tile window in flight, twice the operand
+        // panels per round in the XCD's L2: +6 us on the first tile) -- and for ONE tile, T + W, from then on.  The first ticket is
+        // drawn by thread 0 before anything is in flight; the ring is still empty, so the values travel through the last words of LDS
+        // (slot 4, first written by the fifth half-stage, two barriers from here).  A workgroup that finds its XCD dry -- it started
+        // late -- asks the other XCDs in turn.
         unsigned* word = reinterpret_cast<unsigned*>(lds + 5 * HALF - 4);
         if (tid == 0) {
             unsigned t0 = 0xffffffffu, t1 = 0xffffffffu;
             int x = xcd, left = 8;
-            {
-                const int n = q8 + (x < r8 ? 1 : 0);
-                unsigned g0 = 0xffffffffu, g1 = 0xffffffffu;
-                if (n > 0) {  // two atomics in flight, one wait
-                    g0 = __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g1 = __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (g1 < g0) { const unsigned t = g0; g0 = g1; g1 = t; }
-                if (g0 < (unsigned)n) t0 = (unsigned)xcd_lo(x) + g0;
-                if (g1 < (unsigned)n) t1 = (unsigned)xcd_lo(x) + g1;
-                if (g1 + (unsigned)wpx >= (unsigned)n) { x = (x + 1) & 7; --left; }  // the next draw would find this counter dry
-            }
-            while (t0 == 0xffffffffu && left > 0) {  // a late workgroup
-                const int n = q8 + (x < r8 ? 1 : 0);
+            while (left > 0) {
+                const int n = q8 + (x < r8 ? 1 : 0), w = (int)((gridDim.x + 7 - x) >> 3);
                 const unsigned got = n > 0 ? __hip_atomic_fetch_add(p.queue + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                if (got < (unsigned)n) { t0 = (unsigned)xcd_lo(x) + got; break; }
-                x = (x + 1) & 7;
-                --left;
+                if (got < (unsigned)w) {
+                    if (got < (unsigned)n) t0 = (unsigned)xcd_lo(x) + got;
+                    if (got + (unsigned)w < (unsigned)n) t1 = (unsigned)xcd_lo(x) + got + (unsigned)w;
+                } else if (got != 0xffffffffu && got + (unsigned)w < (unsigned)n) {
+                    t0 = (unsigned)xcd_lo(x) + got + (unsigned)w;
+                }
+                if (got == 0xffffffffu || got + 2u * (unsigned)w >= (unsigned)n) {  // this counter is dry now or will be at the next draw
+                    x = (x + 1) & 7;
+                    --left;
+                }
+                if (t0 != 0xffffffffu) break;
             }
             word[0] = t0;
             word[-1] = t1;
@@ -903,7 +904,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
         // counted as gone.  (No early return: a second copy of the leaving code made hipcc merge the two and fail to select.)
         if (tile < 0) tile = hi;
         found = ntile >= 0;
-        if (!found && tries > 0 && tile < hi && nk >= 10) { ev = 5; ek = 0; }  // no second ticket yet: draw again inside the first tile
 #ifdef BSI_LAB
         lab_t1 = __builtin_amdgcn_s_memrealtime();
         if (p.splits > 1000) {  // laboratory: align the start of all workgroups to (entry + splits - 1000 ticks of 10 ns)
@@ -1030,13 +1030,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                 // boundary, in front of the epilogue's stores (a returning atomic takes ~1.5 us; the stores' allowance of the next three
                 // phases covers it) -> stage 2: wave 0 stores it to the workgroup's mailbox -> stage 3 (the store completed a stage
                 // ago, every wave has passed a barrier since): lane 0 of every wave loads the mailbox -> stage 4: all waves decode the
-                // same ticket -- long before the issue stream leaves this tile at stage nk - 2.  A dry counter: draw again from the
-                // next XCD's, from inside the tile (stages 5 / 9: that atomic is waited for half a stage later, ~1 us, end of the
-                // kernel only).  The value in flight sits in the reserved register v255 (see TQ_DRAW above).
+                // same ticket -- long before the issue stream leaves this tile at stage nk - 2.  A counter that is dry, or will be at the
+                // next draw (ticket + 2 W >= its tiles), sends the NEXT boundary's draw to the next XCD's counter; a draw that fails
+                // ends the workgroup after its current tile (a draw from inside a tile would be waited for half a stage later: ~1 us).
+                // The value in flight sits in the reserved register v255 (see TQ_DRAW above).
                 if (v == ev) {
-                    if (ek == 0) {
-                        if (wave == 0) TQ_DRAW(qx * 4, p.queue);
-                    } else if (ek == 1) {
+                    if (ek == 1) {
                         if (wave == 0) {  // at most the previous phase's DMA group is younger than the atomic: landed
                             unsigned tk;
                             TQ_VALUE(tk);
@@ -1051,18 +1050,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
                     } else {
                         unsigned got;
                         TQ_VALUE(got);
-                        const int n = q8 + (qx < r8 ? 1 : 0);
-                        if (got < (unsigned)n) {
+                        const int n = q8 + (qx < r8 ? 1 : 0), w = (int)((gridDim.x + 7 - qx) >> 3);
+#ifdef BSI_LAB
+                        if (p.gate_rows & 8) {
+                            ntile = tile + wpx;
+                            found = ntile < xcd_lo(xcd) + q8 + (xcd < r8 ? 1 : 0);
+                        } else
+#endif
+                        if (got < (unsigned)w && got < (unsigned)n) {  // an early ticket of that counter (its own workgroups are late): two tiles
                             ntile = xcd_lo(qx) + (int)got;
                             found = true;
-                            if (got + (unsigned)wpx >= (unsigned)n) { qx = (qx + 1) & 7; --tries; }  // the next draw would find it dry
-                        } else {
+                            if (got + (unsigned)w < (unsigned)n) extra = ntile + w;
+                        } else if (got + (unsigned)w < (unsigned)n) {
+                            ntile = xcd_lo(qx) + (int)got + w;
+                            found = true;
+                        }
+                        if (got + 2u * (unsigned)w >= (unsigned)n && !(BSI_ABL(p.gate_rows, 8))) {  // dry now, or at the next draw: ask the next XCD then
                             qx = (qx + 1) & 7;
                             --tries;
                         }
                     }
                     if (ek < 3) { ++ek; ev = v + 1; }
-                    else if (!found && tries > 0 && v + 4 <= nk - 2) { ek = 0; ev = v + 1; }
                     else ev = -1;
                 }
             }
@@ -1120,11 +1128,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
             sw = sw >= 3 ? sw - 3 : sw + 2;
         }
         // DYN: the ticket of the tile after the NEXT one is drawn here, at the boundary, if there is a next tile and counters remain
-        const bool want = DYN && found && tries > 0 && nk >= 8;
+        const bool want = DYN && found && extra < 0 && tries > 0 && nk >= 8;
         if (wm == 0) {  // group A: after that barrier, i.e. at the start of its next load phase
             pre_status = issue_next();
             pre = true;
             if constexpr (DYN) {
+#ifdef BSI_LAB
+                if (p.gate_rows & 8) {}  // laboratory: no atomic (the decode below then walks the static order: timing only)
+                else
+#endif
                 if (want && wave == 0) TQ_DRAW(qx * 4, p.queue);  // in front of the epilogue's stores: their allowance covers it
             }
             epilogue(tile);
@@ -1145,11 +1157,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k64r_kernel(const GemmParams p)
         const int next = DYN ? (found ? ntile : hi) : tile + wpx;
         if (next >= hi) break;
         tile = next;
-        if constexpr (DYN) {  // the tile after `next` is unknown again; its ticket, if drawn, is stored at stage 2
-            found = false;
-            if (want) { ev = 2; ek = 1; }
-            else if (tries > 0 && nk >= 10) { ev = 5; ek = 0; }
-            else ev = -1;
+        if constexpr (DYN) {  // the tile after `next`: the second tile of a two-tile ticket, or the ticket just drawn (stored at stage 2)
+            found = extra >= 0;
+            ntile = extra;
+            extra = -1;
+            ev = want ? 2 : -1;
+            ek = 1;
         }
     }
     if (wm == 0) PHASE_BARRIER();
@@ -1229,6 +1242,7 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     if (p.queue) {
 #ifdef BSI_LAB
         if (getenv("BSI_LAB_ALIGN")) p.splits = 1000 + atoi(getenv("BSI_LAB_ALIGN"));
+        if (getenv("BSI_LAB_TQ")) p.gate_rows = atoi(getenv("BSI_LAB_TQ"));  // laboratory: mailbox scope variants (see the K loop)
 #endif
         auto kern = gemm_bf16_k64r_kernel<EPI, true>;
         set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);

@@ -224,7 +224,7 @@ class DPTrainer:
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
                  ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False,
-                 cu_reserve: int | None = None, shard_update: bool = False, rehearse=None):
+                 cu_reserve: int | None = None, tile_queue: bool | None = None, shard_update: bool = False, rehearse=None):
         self.bsi = bsi
         self.model = bsi.model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -259,6 +259,14 @@ class DPTrainer:
                 import warnings
                 warnings.warn(f"DPTrainer: cu_reserve = {self.cu_reserve} but NCCL_MAX_NCHANNELS = {ch}: RCCL may launch more "
                               "workgroups than CUs are kept free for it; export NCCL_MAX_NCHANNELS before init_process_group")
+        # Tile queue (bsi_set_tile_queue): the persistent GEMMs of the backward that have more tiles than CUs draw their tiles from
+        # counters instead of taking a static share, on ALL CUs whatever the reserve says -- a workgroup whose CU an RCCL kernel holds
+        # leaves its share to the others, and no CU idles while RCCL is quiet (the reserve then only sizes the kernels that keep a
+        # static partition: weight-gradient GEMMs, attention).  Bit-identical results.  On where buckets can be in flight, like the
+        # reserve: from the start of the backward to the end of the exchange of a bucketed model.  BSI_DP_TILE_QUEUE=0 switches it off.
+        if tile_queue is None:
+            tile_queue = os.environ.get("BSI_DP_TILE_QUEUE", "1") != "0"
+        self.tile_queue = bool(tile_queue) and (self.exchange or bool(rehearse)) and self.bucketed
         # measurement hook (bench.py): with time_stages on, every step appends three HIP events (start, after backward + exchange,
         # after the optimizer) to stage_events; `stage_ms()` turns them into (forward + backward + exchange, optimizer) milliseconds
         self.time_stages = False
@@ -347,6 +355,8 @@ class DPTrainer:
             loss = self.bsi.train_loss(x, generator).mean()
             if self.cu_reserve:
                 N.check(lib.bsi_set_cu_reserve(self.cu_reserve))
+            if self.tile_queue:
+                N.check(lib.bsi_set_tile_queue(1))
             loss.backward()
         finally:
             self.model._flat_grad_only = False
@@ -456,6 +466,8 @@ class DPTrainer:
         finally:
             if self.cu_reserve and x.is_cuda:
                 N.check(N.lib().bsi_set_cu_reserve(0))    # the update, sampling / evaluation between steps use every CU
+            if self.tile_queue and x.is_cuda:
+                N.check(N.lib().bsi_set_tile_queue(0))
         lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
         w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
         self.step_count += 1

@@ -55,7 +55,7 @@ def main():
     bsi = BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=128, preconditioning="edm",
               discretization=Discretization.image_8bit()).to(dev)
     model.train()
-    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, cu_reserve=0)
+    tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, cu_reserve=0, tile_queue=False)
     g = torch.Generator(dev).manual_seed(0)
     x = (torch.round(255 * torch.rand((B, *shape), device=dev, generator=g)) / 255) * 2 - 1
     side = torch.cuda.Stream(device=dev, priority=-1)      # high priority, like a communication stream
@@ -65,7 +65,7 @@ def main():
 
     def one_step(squat, reserve, est_ms, queue=0, duty=1.0):
         tr.cu_reserve = reserve
-        N.check(N.lib().bsi_set_tile_queue(queue))
+        tr.tile_queue = bool(queue)
         n_pieces = 0
         gap_us = int(piece_us * (1.0 / duty - 1.0)) if squat else 0   # duty < 1: the squatter holds its CUs `duty` of the time
         if squat:
@@ -101,7 +101,7 @@ def main():
         for name, s_, r_, q_, d_ in arms:
             for _ in range(steps):
                 res[name].append(one_step(s_, r_, base * 2.2, q_, d_)[0])
-    N.check(N.lib().bsi_set_tile_queue(0))
+    tr.tile_queue = False
     free = statistics.median(res["free"])
     print(f"# DiT-L/2 DPTrainer.train_step, per-GPU batch {B}, one MI355X ({N.lib().bsi_compute_cus()} CUs), squatter pieces of {piece_us} us "
           f"with {lds // 1024} KB of LDS per workgroup on a high-priority stream; {rounds} interleaved rounds x {steps} steps, ms per step")

@@ -1248,7 +1248,11 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
         set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, dim3(all), dim3(512), lds, s, p);
     } else {
-        const int grid = nwg < compute_cus() ? nwg : compute_cus();
+        // With the queue on, launches that keep the static schedule also span ALL CUs: with at most one tile per workgroup a
+        // reserve only turns one round into two for good, while a late workgroup (its CU held by a communication kernel) costs that
+        // second round only while the communication kernel is actually there.  (Short K, or no control block: the reserve applies.)
+        const int cus = (g_bsi_tile_queue && nwg <= all) ? all : compute_cus();
+        const int grid = nwg < cus ? nwg : cus;
         auto kern = gemm_bf16_k64r_kernel<EPI, false>;
         set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);

@@ -754,6 +754,331 @@ __global__ __launch_bounds__(512) void conv_slab_kernel(const ConvParams p) {
 #undef PHASE_BARRIER
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The slab kernel WITH a second source: conv2 of the up blocks = 3 x 3 over h (Cin channels) + the folded 1 x 1 skip convolution
+// over the raw concatenation cat(x, skip) (Cin2 = 2 Cin channels), which the ring kernel ran at 138 us against 101 us for the same
+// 3 x 3 on the slab kernel.  A skip K step has ONE tap: its 32 KB of pixels are consumed a phase after they arrive, so it cannot
+// join the two-slab rotation of the 3 x 3 chunks.  It gets ONE buffer of its own (Q, the tile's 512 pixels, no halo) and the two
+// skip steps of a chunk are placed where Q can be refilled in between -- eleven phases per 32-channel chunk c of h:
+//     position   0    1    2    3    4          5    6    7    8    9    10
+//     K step     t0   t1   t2   t3   skip 2c    t4   t5   t6   t7   t8   skip 2c+1
+//     issues     m s s  m s  m s  m   -          m k  k    k    k    -    -          (+ one weight stage each)
+// m = a piece of the NEXT chunk's main slab (the other slab buffer, as in conv_slab_kernel), s = a piece of THIS chunk's first skip
+// step (Q is free: the previous chunk's second skip step was read at position 10, by the lagging wave group half a phase before
+// position 0's issue), k = a piece of this chunk's second skip step (Q was read at position 4).  The last s goes out at position 2
+// and is read at 4, the last k at 8 and is read at 10: one and a half phases of lead, what the ring kernel gives its stages.  The
+// weight stream runs five 8-KB stages ahead on a ring of six (a slot is rewritten the phase after both wave groups read it).
+// LDS: 2 x 38 KB + 32 KB + 48 KB + the zero row = 156.25 KB.  The issue sequence is the same in every chunk of every tile (past
+// the end of a stream the instructions are harmless dummies), so the vmcnt allowance of a phase -- the instructions issued after
+// the youngest one it needs -- is a constant of its position: the weight stage of the next phase went out four phases ago
+// (8 9 11 12 9 9 8 8 9 7 6 instructions since); position 3 also needs Q whole (3), position 9 Q again (2), position 10 the next
+// main slab (10): the minimum of the two.
+constexpr int S2_SKIP = C_BM * C_RB;                                   // 32 KB: the tile's 512 pixels, no halo
+constexpr int S2_Q = 2 * S_SLAB, S2_WRING = S2_Q + S2_SKIP;
+constexpr int S2_WSLOTS = 6, S2_WD = 5;
+constexpr int S2_ZERO = S2_WRING + S2_WSLOTS * S_WSTAGE, S2_LDS = S2_ZERO + 256;
+static_assert(S2_ZERO % 256 == 0 && S2_LDS <= 160 * 1024, "LDS image of the two-source slab kernel");
+
+template <int EPI, int WD>
+__global__ __launch_bounds__(512) void conv_slab2_kernel(const ConvParams p) {
+    constexpr int TM = 8, NW = 8;
+    constexpr unsigned XL = WD == 32 ? 0x55u : 0xffu, XR = WD == 32 ? 0xaau : 0xffu;
+    constexpr bool BF16_OUT = (EPI < CEPI_BIAS_RESID_F32 || EPI == CEPI_FILM_ROWS_SILU_BF16);
+    constexpr int NSTORE = BF16_OUT ? 2 * TM : 4 * TM + (EPI == CEPI_BIAS_RESID_F32_GN ? 4 : 0);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wmm = (wave >> 1) & 1, wn = wave & 1;
+    const int wrow0 = (wm * 2 + wmm) * 128;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wpx = (gridDim.x + 7 - xcd) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lo = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + wl;
+    if (tile >= hi) return;
+    const int nc = p.Cin / 32;  // chunks of the 3 x 3 source; the skip source has 2 nc (launcher)
+    const int HW = p.H * WD;
+
+    if (tid < 64) reinterpret_cast<float*>(lds + S2_ZERO)[tid] = 0.f;
+
+    const int srow = lane >> 2, spos = lane & 3;
+    const int achunk = (spos ^ ((srow >> 1) & 3)) * 16;
+    const int rowb = p.Cin * 2, rowb2 = p.Cin2 * 2;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* A2b = reinterpret_cast<const char*>(p.A2);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    asm volatile("" : "+s"(Ab), "+s"(A2b), "+s"(Wb));
+    // ---- main slab stream, one slab ahead of the compute (conv_slab_kernel's)
+    unsigned soff[5];
+    unsigned before = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int ins = q * NW + wave;
+        ins = ins < S_INSTR ? ins : S_INSTR - 1;
+        const int r = ins * 16 + srow;
+        soff[q] = (unsigned)r * (unsigned)rowb + achunk;
+        before |= (r < S_HALO ? 1u : 0u) << q;
+    }
+    int st_tile = tile, st_c = 0, sg = 0;
+    int st_m0 = (tile / p.tiles_n) * C_BM - S_HALO;
+    __amdgpu_buffer_rsrc_t srs;
+    auto slab_resource = [&]() {
+        const long rec = ((long)p.M - st_m0) * rowb - st_c * 64;
+        srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab + (long)st_m0 * rowb + st_c * 64), 0,
+                                                (unsigned)(rec < (long)BUF_RECORDS ? rec : (long)BUF_RECORDS), 0x00020000);
+    };
+    slab_resource();
+    auto issue_slab_piece = [&](int q) {
+        int ins = q * NW + wave;
+        ins = ins < S_INSTR ? ins : S_INSTR - 1;
+        unsigned vo = soff[q];
+        if (st_m0 < 0) vo = ((before >> q) & 1) ? OOB_OFFSET : vo;
+        if (st_tile >= hi) vo = OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, LDS_PTR(lds + (sg & 1) * S_SLAB + ins * 1024), 16, vo, 0, 0, 0);
+    };
+    auto advance_slab = [&]() {
+        ++sg;
+        if (++st_c == nc) {
+            st_c = 0;
+            st_tile += wpx;
+            st_m0 = (st_tile / p.tiles_n) * C_BM - S_HALO;
+        }
+        if (st_tile < hi) slab_resource();
+    };
+    // ---- skip steps of the chunk being computed: piece q of skip chunk sc -> rows 128 q + 16 wave .. + 15 of Q
+    unsigned koff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) koff[q] = (unsigned)((q * NW + wave) * 16 + srow) * (unsigned)rowb2 + achunk;
+    __amdgpu_buffer_rsrc_t krs;
+    auto skip_resource = [&](int sc) {  // the tile's pixels from its first row, channels 32 sc ..: rows past the tensor read zeros
+        const int m0 = (tile / p.tiles_n) * C_BM;
+        const long rec = ((long)p.M - m0) * rowb2 - sc * 64;
+        krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A2b + (long)m0 * rowb2 + sc * 64), 0,
+                                                (unsigned)(rec < (long)BUF_RECORDS ? rec : (long)BUF_RECORDS), 0x00020000);
+    };
+    auto issue_skip_piece = [&](int q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, LDS_PTR(lds + S2_Q + (q * NW + wave) * 1024), 16, koff[q], 0, 0, 0);
+    };
+    // ---- weight stream: the stage of the phase five ahead; (tile, chunk) of that phase, its position is a constant of this one's
+    const unsigned woffs = (unsigned)(wave * 16 + srow) * (unsigned)(p.K * 2) + (spos ^ ((-wave) & 3)) * 16;
+    int wt_tile = tile, wt_c = 0;
+    int cslot = 0;  // ring slot of the stage this phase reads; the stage issued in it goes to slot cslot - 1 (mod 6)
+    auto issue_w = [&](int pos) {  // pos: position of the issued stage in its chunk's eleven phases
+        const int tap = pos < 4 ? pos : pos - 1;  // positions 0-3 -> taps 0-3, 5-9 -> taps 4-8 (4 and 10 are the skip steps)
+        const char* base = wt_tile < hi ? Wb + (size_t)(wt_tile % p.tiles_n) * C_BN * p.K * 2 : Wb;
+        const int off = wt_tile >= hi ? 0 : (pos == 4 || pos == 10) ? 9 * rowb + (2 * wt_c + (pos == 10 ? 1 : 0)) * 64 : tap * rowb + wt_c * 64;
+        const int islot = cslot == 0 ? S2_WSLOTS - 1 : cslot - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off + woffs), LDS_PTR(lds + S2_WRING + islot * S_WSTAGE + wave * 1024), 16, 0, 0);
+        if (pos == 10 && wt_tile < hi) {
+            if (++wt_c == nc) {
+                wt_c = 0;
+                wt_tile += wpx;
+            }
+        }
+    };
+
+    const int rho = lane & 15, qd = lane >> 4;
+    const int wcc = ((qd ^ ((-(rho >> 2)) & 3)) << 4);
+    const int woff = S2_WRING + (wn * 64 + 16 * (rho >> 2) + (rho & 3)) * C_RB + wcc;
+    const int xrow0 = S_HALO + wrow0 + rho;
+    const bool edge_lane[2] = {rho == 0, rho == 15};
+    const int krow = wrow0 + rho;  // Q holds the tile's rows from 0
+    const int kaddr = S2_Q + krow * C_RB + ((qd ^ ((krow >> 1) & 3)) << 4);
+
+    f32x4 acc[4][TM];
+    bf16x8 wf[4], xf[TM];
+#define PHASE_BARRIER()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
+    auto init_acc = [&](int t) {
+        f32x4 bv[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int nb = (t % p.tiles_n) * C_BN + wn * 64 + 16 * qd;
+        if (p.bias && nb < p.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = bv[i];
+    };
+    auto epilogue = [&](int t) {
+        asm volatile("" : "+s"(t));
+        const int mw0 = (t / p.tiles_n) * C_BM + wrow0, nb0 = (t % p.tiles_n) * C_BN + wn * 64, nb = nb0 + 16 * qd;
+        if (nb0 >= p.N || (BSI_ABL(p.abl, 4))) return;
+        if constexpr (BF16_OUT) {
+            if (nb >= p.N) return;
+            if constexpr (EPI == CEPI_FILM_SILU_BF16) film_silu_inplace(p, acc, mw0, nb, HW);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                f32x4 v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+                u32x4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    w0[e] = pack_bf16x2(v[0][2 * e], v[0][2 * e + 1]);
+                    w0[2 + e] = pack_bf16x2(v[1][2 * e], v[1][2 * e + 1]);
+                    w1[e] = pack_bf16x2(v[2][2 * e], v[2][2 * e + 1]);
+                    w1[2 + e] = pack_bf16x2(v[3][2 * e], v[3][2 * e + 1]);
+                }
+                store_rows_dpp(reinterpret_cast<__bf16*>(p.out), p.ldo, p.M, mw0 + 16 * j, nb, rho, w0, w1);
+            }
+        } else {
+            store_f32_rows<EPI == CEPI_BIAS_RESID_F32_GN>(p, acc, mw0, nb0, rho, qd);
+        }
+    };
+    auto full_tile = [&](int t) {
+        return (t / p.tiles_n) * C_BM + C_BM <= p.M && (t % p.tiles_n) * C_BN + C_BN <= p.N && !(BSI_ABL(p.abl, 4));
+    };
+
+    // prologue: the first main slab and weight stages 0 .. 4 (positions 0 .. 4 of chunk 0); the slab and stage 0 must have landed
+#pragma unroll
+    for (int q = 0; q < 5; ++q) issue_slab_piece(q);
+    advance_slab();
+#pragma unroll
+    for (int d = 0; d < S2_WD; ++d) {
+        cslot = d + 1;  // issue_w writes slot cslot - 1 = d
+        issue_w(d);
+    }
+    cslot = 0;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S2_WD - 1) : "memory");
+    PHASE_BARRIER();
+    if (wm == 1) PHASE_BARRIER();
+
+    bool cold = true;  // the kernel's first phase: stages 1 .. 4 went out back to back in the prologue (7 instructions since stage 1, not 8)
+    int cg = 0;
+    int after_e = 0;
+    while (true) {
+        const int next = tile + wpx;
+        const bool has_next = next < hi;
+        init_acc(tile);
+        unsigned ytop, ybot;
+        {
+            const int R = (tile / p.tiles_n) * C_BM + wrow0 + 16 * (lane & 7);
+            const int rem = R % HW, y = rem / WD;
+            ytop = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == 0) & 0xff));
+            ybot = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(y == p.H - 1) & 0xff));
+        }
+        for (int c = 0; c < nc; ++c) {
+            const int slab_off = (cg & 1) * S_SLAB;
+            auto phase = [&](auto I_) {
+                constexpr int I = decltype(I_)::value;  // position in the chunk: 4 and 10 are the skip steps
+                constexpr bool SKIP = I == 4 || I == 10;
+                // ---- L phase: fragments
+                {
+                    const char* wb = lds + cslot * S_WSTAGE;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + woff + i * 4 * C_RB);
+                }
+                if constexpr (!SKIP) {
+                    constexpr int t = I < 4 ? I : I - 1;
+                    constexpr int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                    constexpr unsigned ZL = dx < 0 ? XL : dx > 0 ? XR : 0u;
+                    int row = xrow0 + dy * WD + dx;
+                    asm volatile("" : "+v"(row));
+                    const int xaddr = slab_off + row * C_RB + ((qd ^ ((row >> 1) & 3)) << 4);
+                    asm volatile("" : "+s"(ytop), "+s"(ybot));
+                    const unsigned zall = dy < 0 ? ytop : dy > 0 ? ybot : 0u;
+                    if (zall == 0) {
+                        if constexpr (ZL == 0) {
+#pragma unroll
+                            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(lds + xaddr + j * 16 * C_RB);
+                        } else {
+                            const int za = edge_lane[dx < 0 ? 0 : 1] ? S2_ZERO + (xaddr & 255) : -1;
+#pragma unroll
+                            for (int j = 0; j < TM; ++j) {
+                                if ((ZL >> j) & 1) {
+                                    const int a = za >= 0 ? za : xaddr + j * 16 * C_RB;
+                                    xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
+                                } else {
+                                    xf[j] = *reinterpret_cast<const bf16x8*>(lds + xaddr + j * 16 * C_RB);
+                                }
+                            }
+                        }
+                    } else {
+                        const bool el = dx == 0 ? false : edge_lane[dx < 0 ? 0 : 1];
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) {
+                            const bool z = ((zall >> j) & 1) || (((ZL >> j) & 1) && el);
+                            const int a0 = xaddr + j * 16 * C_RB;
+                            const int a = z ? S2_ZERO + (a0 & 255) : a0;
+                            xf[j] = *reinterpret_cast<const bf16x8*>(lds + a);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(lds + kaddr + j * 16 * C_RB);
+                }
+                // ---- issue: [main slab piece] [skip pieces] [weight stage of the phase five ahead]
+                if constexpr (I < 4) issue_slab_piece(I);
+                if constexpr (I == 5) { issue_slab_piece(4); advance_slab(); }
+                if constexpr (I == 0) { skip_resource(2 * c); issue_skip_piece(0); issue_skip_piece(1); }
+                if constexpr (I == 1) issue_skip_piece(2);
+                if constexpr (I == 2) issue_skip_piece(3);
+                if constexpr (I == 5) { skip_resource(2 * c + 1); issue_skip_piece(0); }
+                if constexpr (I == 6) issue_skip_piece(1);
+                if constexpr (I == 7) issue_skip_piece(2);
+                if constexpr (I == 8) issue_skip_piece(3);
+                issue_w((I + S2_WD) % 11);
+                {
+                    constexpr int allow_[11] = {8, 9, 11, 3, 9, 9, 8, 8, 9, 2, 6};
+                    constexpr int allow = allow_[I];
+                    if (I == 0 && cold) {
+                        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                        cold = false;
+                    } else if (I < 3 && after_e > 0) {  // positions 0 .. 2 after an epilogue: its stores are younger than what the phase needs
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow + NSTORE) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
+                    }
+                    if (I == 2) after_e = 0;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                // ---- C phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i0 = 0; i0 < 4; ++i0) {
+                        const int i = (j & 1) ? 3 - i0 : i0;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                if (I == 10 && c == nc - 1 && wm == 1) { epilogue(tile); after_e = full_tile(tile) ? 1 : 0; }  // group B: before its last barrier
+                PHASE_BARRIER();
+                cslot = cslot == S2_WSLOTS - 1 ? 0 : cslot + 1;
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{});
+            phase(std::integral_constant<int, 5>{});
+            phase(std::integral_constant<int, 6>{});
+            phase(std::integral_constant<int, 7>{});
+            phase(std::integral_constant<int, 8>{});
+            phase(std::integral_constant<int, 9>{});
+            phase(std::integral_constant<int, 10>{});
+            ++cg;
+        }
+        if (wm == 0) { epilogue(tile); after_e = full_tile(tile) ? 1 : 0; }  // group A: merged with its next load phase (position 0)
+        if (!has_next) break;
+        tile = next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wm == 0) PHASE_BARRIER();
+#undef PHASE_BARRIER
+}
+
 int g_conv_abl = 0;
 int g_conv_grid_limit = 0;  // > 0: at most this many workgroups (tests: several tiles per workgroup on small inputs)
 
@@ -800,6 +1125,21 @@ int launch_conv(ConvParams p, hipStream_t s) {
         // can runs the slab kernel now.
         // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
         // 2048 / 4096 = ring kernel for the FiLM / fp32 epilogues.
+        // 3 x 3 + folded 1 x 1 skip (conv2 of the up blocks): the two-source slab kernel when the skip source has exactly two chunks per
+        // chunk of the 3 x 3 source (the UNet: 128 + 256 channels); ablation bit 256 keeps the ring kernel (the A/B partner)
+        if (p.taps == 9 && p.Cin2 == 2 * p.Cin && p.Cin2 > 0 && (p.Wd == 16 || p.Wd == 32) && p.N % C_BN == 0 && !(g_conv_abl & 256)) {
+            if (p.Wd == 32) {
+                auto kern = conv_slab2_kernel<EPI, 32>;
+                set_max_lds(reinterpret_cast<const void*>(kern), (int)S2_LDS);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S2_LDS, s, p);
+            } else {
+                auto kern = conv_slab2_kernel<EPI, 16>;
+                set_max_lds(reinterpret_cast<const void*>(kern), (int)S2_LDS);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S2_LDS, s, p);
+            }
+            BSI_CHECK_LAUNCH("bsi_conv_nhwc_bf16");
+            return BSI_OK;
+        }
         const bool can = p.taps == 9 && p.Cin2 == 0 && (p.Wd == 16 || p.Wd == 32) && p.N % C_BN == 0;
         constexpr bool F32 = (EPI == CEPI_BIAS_RESID_F32 || EPI == CEPI_BIAS_RESID_F32_GN);
         const bool want = (g_conv_abl & 512) ? true

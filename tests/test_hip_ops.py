@@ -1027,7 +1027,11 @@ def _nhwc(x):
     (9, 8, 256, 0, 64, 1, "bias"), (3, 16, 384, 0, 128, 9, "bias"), (5, 16, 256, 128, 128, 9, "resid_skip"),
     (12, 32, 128, 0, 128, 9, "bias_persistent"), (12, 32, 64, 0, 128, 9, "resid_persistent"), (3, 8, 128, 0, 384, 1, "resid"), (3, 32, 256, 0, 384, 9, "bias_ring"), (2, 32, 128, 0, 128, 9, "resid_ring"), (3, 32, 128, 0, 128, 9, "bias_slab"), (2, 32, 256, 0, 384, 9, "bias"), (5, 16, 128, 0, 256, 9, "resid"), (48, 16, 64, 0, 128, 9, "bias_persistent_slab"),
     (48, 16, 128, 0, 128, 9, "bias_persistent_ring"), (5, 8, 128, 0, 128, 9, "film"), (3, 32, 128, 0, 128, 9, "film_ring"),
-    (6, 16, 256, 0, 128, 9, "film")])
+    (6, 16, 256, 0, 128, 9, "film"),
+    # 3 x 3 + folded 1 x 1 skip with two skip chunks per chunk (the up blocks' conv2): the two-source slab kernel -- several tiles per
+    # workgroup, image width 16, two chunks, a ragged last tile, and the ring kernel on the same shape
+    (12, 32, 128, 256, 128, 9, "resid_skip_persistent"), (5, 16, 128, 256, 128, 9, "resid_skip"), (3, 32, 64, 128, 128, 9, "resid_skip"),
+    (3, 16, 128, 256, 256, 9, "resid_skip"), (2, 32, 128, 256, 128, 9, "resid_skip_ring"), (7, 16, 128, 256, 128, 9, "bias_skip_persistent")])
 def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
     if epi.endswith("_slab"):  # the pixel-slab kernel on a shape the dispatcher gives to the ring kernel
         N.check(N.lib().bsi_conv_set_ablation(512))
@@ -1065,7 +1069,7 @@ def test_conv_implicit_gemm(N, B, H, Cin, Cin2, Cout, taps, epi):
         N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w2)), Cout, Cin2, 1, Cin2, K, taps * Cin, N.ptr(wp), N.stream()))
         a.x2 = dev(_nhwc(x2).to(torch.bfloat16)).data_ptr()
         ref = ref + torch.nn.functional.conv2d(x2.double(), w2.double())
-    if epi == "bias":
+    if epi in ("bias", "bias_skip"):
         out = empty(B * H * H, Cout, dtype=torch.bfloat16)
         a.out, a.epilogue = out.data_ptr(), N.CONV_BIAS_BF16
         N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
@@ -1134,6 +1138,52 @@ def test_conv_full_size_slab_against_ring(N, epi_name):
     if f32:
         ref = ref + res[img * H * H:(img + 1) * H * H].cpu().double()
     assert rel_linf(a0[img * H * H:(img + 1) * H * H].cpu(), ref) < (3e-5 if f32 else 5e-3)
+
+
+def test_conv_full_size_two_source_slab_against_ring(N):
+    """conv2 of the up blocks at full size (256 images of 32 x 32: 512 tiles on 256 CUs; 3 x 3 over 128 channels + the folded 1 x 1
+    skip convolution over the 256-channel concatenation, fp32 output with GroupNorm partials): the two-source slab kernel against the
+    ring kernel on the whole output and the partials, each run twice (reproducible), and against fp64 on one image."""
+    B, H, Cin, Cin2, Cout = 256, 32, 128, 256, 128
+    gen = torch.Generator().manual_seed(6)
+    M, K = B * H * H, 9 * Cin + Cin2
+    x = torch.randn((M, Cin), generator=gen).to(torch.bfloat16)
+    x2 = torch.randn((M, Cin2), generator=gen).to(torch.bfloat16)
+    w = bf16r(torch.randn((Cout, Cin, 3, 3), generator=gen) / math.sqrt(9 * Cin))
+    w2 = bf16r(torch.randn((Cout, Cin2, 1, 1), generator=gen) / math.sqrt(Cin2))
+    bias = torch.randn(Cout, generator=gen)
+    xd, x2d, bd = dev(x), dev(x2), dev(bias)
+    wp = empty(Cout, K, dtype=torch.bfloat16)
+    N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w)), Cout, Cin, 9, Cin, K, 0, N.ptr(wp), N.stream()))
+    N.check(N.lib().bsi_conv_weight_pack(N.ptr(dev(w2)), Cout, Cin2, 1, Cin2, K, 9 * Cin, N.ptr(wp), N.stream()))
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    outs, parts = {}, {}
+    try:
+        for abl in (0, 256):  # 0 = the dispatcher's choice (two-source slab kernel), 256 = ring kernel
+            N.check(N.lib().bsi_conv_set_ablation(abl))
+            for rep in range(2):
+                out = torch.full((M, Cout), float("nan"), dtype=torch.float32, device=DEV)
+                gp = torch.full((M // 128, Cout // 4, 2), float("nan"), dtype=torch.float32, device=DEV)
+                a = N.ConvArgs(x=xd.data_ptr(), x2=x2d.data_ptr(), w=wp.data_ptr(), bias=bd.data_ptr(), zeros=zeros.data_ptr(), B=B, H=H, W=H,
+                               Cin=Cin, Cin2=Cin2, Cout=Cout, taps=9, ldo=Cout, out=out.data_ptr(), epilogue=N.CONV_BIAS_RESID_F32,
+                               gn_partial=gp.data_ptr())
+                N.check(N.lib().bsi_conv_nhwc_bf16(C.byref(a), N.stream()))
+                torch.cuda.synchronize()
+                if rep:
+                    assert torch.equal(out, outs[abl]) and torch.equal(gp, parts[abl]), f"kernel choice {abl} is not reproducible"
+                outs[abl], parts[abl] = out, gp
+    finally:
+        N.check(N.lib().bsi_conv_set_ablation(0))
+    a0, a1 = outs[0], outs[256]
+    assert bool(torch.isfinite(a0).all()) and bool(torch.isfinite(parts[0]).all())
+    assert float(((a0 - a1).abs() / (a1.abs() + 0.05)).max()) < 1e-3      # different fp32 summation orders of the same products
+    assert float(((parts[0][..., 0] - parts[256][..., 0]).abs()).max()) < 1e-4
+    for img in (0, 171, 255):  # first tile, second tile of a workgroup, last tile: against fp64
+        sl = slice(img * H * H, (img + 1) * H * H)
+        xi = x[sl].double().reshape(1, H, H, Cin).permute(0, 3, 1, 2)
+        x2i = x2[sl].double().reshape(1, H, H, Cin2).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xi, w.double(), bias.double(), padding=1) + torch.nn.functional.conv2d(x2i, w2.double())
+        assert rel_linf(a0[sl].cpu(), _nhwc(ref).reshape(-1, Cout)) < 3e-5
 
 
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(3, 64, 64, 0, 1), (2, 1024, 128, 0, 1), (2, 1024, 128, 128, 1), (2, 1024, 128, 0, 0)])

@@ -851,9 +851,7 @@ __global__ __launch_bounds__(512) void conv_slab2_kernel(const ConvParams p) {
         if (st_tile < hi) slab_resource();
     };
     // ---- skip steps of the chunk being computed: piece q of skip chunk sc -> rows 128 q + 16 wave .. + 15 of Q
-    unsigned koff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) koff[q] = (unsigned)((q * NW + wave) * 16 + srow) * (unsigned)rowb2 + achunk;
+    const unsigned koff = (unsigned)(wave * 16 + srow) * (unsigned)rowb2 + achunk;  // piece q lies 128 q rows further: the scalar offset
     __amdgpu_buffer_rsrc_t krs;
     auto skip_resource = [&](int sc) {  // the tile's pixels from its first row, channels 32 sc ..: rows past the tensor read zeros
         const int m0 = (tile / p.tiles_n) * C_BM;
@@ -862,7 +860,7 @@ __global__ __launch_bounds__(512) void conv_slab2_kernel(const ConvParams p) {
                                                 (unsigned)(rec < (long)BUF_RECORDS ? rec : (long)BUF_RECORDS), 0x00020000);
     };
     auto issue_skip_piece = [&](int q) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, LDS_PTR(lds + S2_Q + (q * NW + wave) * 1024), 16, koff[q], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, LDS_PTR(lds + S2_Q + (q * NW + wave) * 1024), 16, koff, q * 128 * rowb2, 0, 0);
     };
     // ---- weight stream: the stage of the phase five ahead; (tile, chunk) of that phase, its position is a constant of this one's
     const unsigned woffs = (unsigned)(wave * 16 + srow) * (unsigned)(p.K * 2) + (spos ^ ((-wave) & 3)) * 16;
@@ -1126,8 +1124,9 @@ int launch_conv(ConvParams p, hipStream_t s) {
         // Ablation flags (bsi_conv_set_ablation): 256 = never the slab kernel, 512 = the slab kernel wherever the shape allows,
         // 2048 / 4096 = ring kernel for the FiLM / fp32 epilogues.
         // 3 x 3 + folded 1 x 1 skip (conv2 of the up blocks): the two-source slab kernel when the skip source has exactly two chunks per
-        // chunk of the 3 x 3 source (the UNet: 128 + 256 channels); ablation bit 256 keeps the ring kernel (the A/B partner)
-        if (p.taps == 9 && p.Cin2 == 2 * p.Cin && p.Cin2 > 0 && (p.Wd == 16 || p.Wd == 32) && p.N % C_BN == 0 && !(g_conv_abl & 256)) {
+        // chunk of the 3 x 3 source (the UNet: 128 + 256 channels); ablation bits 256 / 8192 keep the ring kernel (8192: for these shapes only,
+        // the A/B partner of tools/unet_bench.py)
+        if (p.taps == 9 && p.Cin2 == 2 * p.Cin && p.Cin2 > 0 && (p.Wd == 16 || p.Wd == 32) && p.N % C_BN == 0 && !(g_conv_abl & (256 | 8192))) {
             if (p.Wd == 32) {
                 auto kern = conv_slab2_kernel<EPI, 32>;
                 set_max_lds(reinterpret_cast<const void*>(kern), (int)S2_LDS);
@@ -1159,7 +1158,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int bsi_conv_set_ablation(int flags) {  // bits 256 / 512 / 2048 / 4096: kernel choice; bits 1..64: laboratory build only
+extern "C" int bsi_conv_set_ablation(int flags) {  // bits 256 / 512 / 2048 / 4096 / 8192: kernel choice; bits 1..64: laboratory build only
 #ifndef BSI_LAB
     BSI_CHECK_ARG(!(flags & 127), "bsi_conv_set_ablation: bits 1..64 switch kernel parts off (wrong results) and exist only in a laboratory "
                                   "build (make -C bsi_amd/csrc LAB=1 OUTDIR=<dir>, BSI_HIP_LIB=<dir>/libbsi_hip.so); got %d", flags);

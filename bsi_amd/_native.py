@@ -179,6 +179,7 @@ _PROTOS = {
     "bsi_conv_set_ablation": (_i, [_i]),
     "bsi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "bsi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "bsi_gemm_tn_pair_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "bsi_gemm_tn_bias_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "bsi_colsum_workspace_bytes": (_sz, [_i]),
     "bsi_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),

@@ -377,9 +377,14 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
                                  bt.d1, ml + 2 * dim, mod_stride, dml + 2 * dim, dstride, ws.dd, M, dim, d.tokens,
                                  make_drop(dropout_p, seed, 2 * l + 1), stream, plane, rel_dd ? ws.rows_out : nullptr));
         TRY(gemm(ws.dd, dim, bT.out_wT, dim, nullptr, ws.dsmall, dim, M, dim, dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dao
-        if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
-        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         const bool rel_qkv = rel_qkv_of(l);
+        // The out-projection's weight gradient (16 output tiles) waits for the qkv projection's (48) when neither carries a bias rider:
+        // one launch of 64 tiles x 4 token ranges instead of 16 x 15 and 48 x 5 (ws.dd and the tape's ao live until LayerNorm 1 below)
+        static const bool no_pair = [] { const char* e = getenv("BSI_TRAIN_NO_TN_PAIR"); return e && *e == '1'; }();
+        const bool pair = rel_dd && rel_qkv && !no_pair && dim % 256 == 0;
+        if (pair) {}
+        else if (rel_dd) TRY(bsi_gemm_tn_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, 0, ws.tn, stream));
+        else TRY(bsi_gemm_tn_bias_bf16(ws.dd, dim, bt.ao, dim, M, dim, dim, bg.out_w, dim, bg.out_b, 0, ws.tn, stream));
         TRY(bsi_attention_bwd_drop(bt.qkv, 3 * dim, bt.ao, ws.dsmall, dim, bt.lse, B, d.tokens, d.heads, 64, ws.dbig, 3 * dim,
                                    make_drop(dropout_p, seed, 2 * l), stream, bt.maskw, rel_qkv ? ws.rows_qkv : nullptr));
         if (rel_dd || rel_fc1 || rel_qkv) {  // the slab tables of this block are complete (rows_fc2 is rewritten by the LayerNorm-1 launch below)
@@ -394,7 +399,8 @@ extern "C" int bsi_dit_backward(const bsi_dit_config* cfg, const bsi_dit_weights
             TRY(bsi_colsum_rows_f32(jobs, nj, ws.rows_scratch, stream));
         }
         TRY(gemm(ws.dbig, 3 * dim, bT.qkv_wT, 3 * dim, nullptr, ws.dsmall, dim, M, dim, 3 * dim, BSI_EPI_BIAS_BF16, nullptr, nullptr, nullptr, 0, stream));  // dxn1
-        if (rel_qkv) TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
+        if (pair) TRY(bsi_gemm_tn_pair_bf16(ws.dbig, 3 * dim, bt.xn1, 3 * dim, bg.qkv_w, ws.dd, dim, bt.ao, dim, bg.out_w, dim, M, dim, ws.tn, stream));
+        else if (rel_qkv) TRY(bsi_gemm_tn_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, 0, ws.tn, stream));
         else TRY(bsi_gemm_tn_bias_bf16(ws.dbig, 3 * dim, bt.xn1, dim, M, 3 * dim, dim, bg.qkv_w, dim, bg.qkv_b, 0, ws.tn, stream));
         // LayerNorm 1 backward (dX becomes dL/dxa) + the MLP branch of the block below: xa = xb' + g_m' * d2'
         if (l > 0) {

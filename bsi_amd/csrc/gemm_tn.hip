@@ -25,6 +25,14 @@ struct TnParams {
     size_t slab_stride;  // floats between slabs
     float* colsum;       // optional: [splits][colsum_stride] column sums of P (bias gradient), written by the k-tile-0 workgroups
     size_t colsum_stride;
+    // paired launch (bsi_gemm_tn_pair_bf16): n tiles >= pair_tiles belong to a SECOND problem of the same M, K, ldq, ldc -- its P
+    // operand, Q operand, N, output slabs -- so that two weight gradients with few output tiles each fill the chip together
+    int pair_tiles;      // 0 = one problem
+    const __bf16* P2;
+    const __bf16* Q2;
+    float* out2;
+    int N2, ldp2;
+    size_t slab_stride2;
     int xcd_map;         // XCD-aware workgroup order (off: BSI_TN_ABL & 1)
     int abl;             // laboratory (BSI_TN_ABL): 2 = no operand DMA after the prologue, 4 = fragment reads only in the first stage, 8 = no MFMAs
 };
@@ -309,6 +317,14 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
         tile_n = tile / p.tiles_k;
         tile_k = tile % p.tiles_k;
     }
+    // the problem this n tile belongs to (paired launch: see TnParams)
+    const bool second = p.pair_tiles > 0 && tile_n >= p.pair_tiles;
+    const __bf16* const Pp = second ? p.P2 : p.P;
+    const __bf16* const Qp = second ? p.Q2 : p.Q;
+    const int Np = second ? p.N2 : p.N, ldpp = second ? p.ldp2 : p.ldp;
+    float* const outp = second ? p.out2 : p.out;
+    const size_t slabp = second ? p.slab_stride2 : p.slab_stride;
+    if (second) tile_n -= p.pair_tiles;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
@@ -321,9 +337,9 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
     unsigned ldb;       // row pitch in bytes of its operand
     {
         int col = (pside ? n0 : k0) + c16 * 8;
-        col = col < (pside ? p.N : p.K) ? col : 0;  // columns beyond the matrix are never stored
-        gbase = reinterpret_cast<const char*>((pside ? p.P : p.Q) + col);
-        ldb = (unsigned)(pside ? p.ldp : p.ldq) * 2u;
+        col = col < (pside ? Np : p.K) ? col : 0;  // columns beyond the matrix are never stored
+        gbase = reinterpret_cast<const char*>((pside ? Pp : Qp) + col);
+        ldb = (unsigned)(pside ? ldpp : p.ldq) * 2u;
     }
     int mrow[4];  // contraction row (within the stage) of instruction q: position t holds row (t with bits 2 and 3 swapped)
 #pragma unroll
@@ -500,11 +516,11 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const TnParams p) {
             if (n < p.N) p.colsum[(size_t)split * p.colsum_stride + n] = accb[u][0];
         }
     }
-    float* out = p.out + (size_t)split * p.slab_stride;
+    float* out = outp + (size_t)split * slabp;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int n = n0 + 128 * wg + 16 * j + (lane & 15);
-        if (n >= p.N) continue;
+        if (n >= Np) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + 64 * wk + 16 * i + 4 * q;
@@ -781,6 +797,45 @@ static int gemm_tn_impl(const void* P, int ldp, const void* Q, int ldq, int M, i
                                        accumulate, out, s);
     }
     return BSI_OK;
+}
+
+extern "C" int bsi_gemm_tn_pair_bf16(const void* P1, int ldp1, const void* Q1, int N1, float* out1, const void* P2, int ldp2, const void* Q2,
+                                     int N2, float* out2, int ldq, int M, int K, void* workspace, bsi_stream_t stream) {
+    BSI_CHECK_ARG(P1 && Q1 && out1 && P2 && Q2 && out2 && workspace && M > 0 && N1 > 0 && N2 > 0 && K > 0, "bsi_gemm_tn_pair_bf16: bad args");
+    BSI_CHECK_ARG(N1 % 256 == 0 && N2 % 8 == 0 && K % 8 == 0 && ldp1 % 8 == 0 && ldp2 % 8 == 0 && ldq % 8 == 0 && ldp1 >= N1 && ldp2 >= N2 && ldq >= K,
+                  "bsi_gemm_tn_pair_bf16: N1=%d must be a multiple of 256 (whole tiles), N2=%d K=%d and the leading dimensions multiples of 8", N1, N2, K);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int cus = compute_cus();
+    TnParams p{};
+    p.P = reinterpret_cast<const __bf16*>(P1);
+    p.Q = reinterpret_cast<const __bf16*>(Q1);
+    p.P2 = reinterpret_cast<const __bf16*>(P2);
+    p.Q2 = reinterpret_cast<const __bf16*>(Q2);
+    p.M = M; p.N = N1; p.N2 = N2; p.K = K; p.ldp = ldp1; p.ldp2 = ldp2; p.ldq = ldq; p.ldc = K;
+    p.pair_tiles = N1 / 256;
+    p.tiles_n = p.pair_tiles + (N2 + 255) / 256;
+    p.tiles_k = (K + 255) / 256;
+    p.splits = tn_splits(M, p.tiles_n * 256, K, cus);
+    const int per = (M + p.splits - 1) / p.splits;
+    p.m_per_split = (per + 31) / 32 * 32;
+    p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+    // slabs: problem 1's first, problem 2's behind them (bsi_gemm_tn_workspace_bytes(M, N1 + N2, K) covers both)
+    p.out = reinterpret_cast<float*>(workspace);
+    p.slab_stride = (size_t)N1 * K;
+    p.out2 = p.out + (size_t)p.splits * p.slab_stride;
+    p.slab_stride2 = (size_t)N2 * K;
+    static const int abl = [] { const char* e = getenv("BSI_TN_ABL"); return e ? atoi(e) : 0; }();
+    p.xcd_map = !(abl & 1);
+    p.abl = abl;
+    auto kern = gemm_tn2_kernel<0x1012>;
+    set_max_lds(reinterpret_cast<const void*>(kern), T2_R * T2_SLOT);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(512), T2_R * T2_SLOT, s, p);
+    BSI_CHECK_LAUNCH("bsi_gemm_tn_pair_bf16");
+    if (p.splits == 1) {  // (never at the engine's sizes) one slab each: plain copies through the reduction
+        const int rc = bsi_reduce_slabs_launch(p.out, p.slab_stride, 1, (size_t)N1 * K, 0, out1, s);
+        return rc ? rc : bsi_reduce_slabs_launch(p.out2, p.slab_stride2, 1, (size_t)N2 * K, 0, out2, s);
+    }
+    return bsi_reduce_slabs2_launch(p.out, p.slab_stride, (size_t)N1 * K, out1, p.out2, p.slab_stride2, (size_t)N2 * K, out2, p.splits, 0, s);
 }
 
 extern "C" int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,

@@ -245,6 +245,13 @@ int bsi_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int 
                      int accumulate, void* workspace, bsi_stream_t stream);
 /* Same, plus colsum_out[N] (+)= sum_m P[m, :] from the same launch (the bias gradient of the Linear: one extra MFMA with an
  * all-ones operand per stage in the workgroups of the first k tile, instead of a second pass over dY). */
+/* TWO weight gradients of one token count in ONE launch: out1[N1,K] = P1^T Q1 and out2[N2,K] = P2^T Q2 (M rows each, the Q operands
+ * share ldq, the outputs are dense: ldc = K; N1 a multiple of 256).  The qkv and out-projection gradients of a DiT block have 48 and
+ * 16 output tiles: together they are the fc1 gradient's 64, split over M four ways = one workgroup per CU, instead of 5- and 15-way
+ * splits of their own.  workspace: bsi_gemm_tn_workspace_bytes(M, N1 + N2, K).  Replaces two torch.mm(dY.t(), X) of autograd over
+ * nn.Linear (bsi/models/dit.py:33-34). */
+int bsi_gemm_tn_pair_bf16(const void* P1, int ldp1, const void* Q1, int N1, float* out1, const void* P2, int ldp2, const void* Q2, int N2,
+                          float* out2, int ldq, int M, int K, void* workspace, bsi_stream_t stream);
 int bsi_gemm_tn_bias_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int N, int K, float* out, int ldc,
                           float* colsum_out, int accumulate, void* workspace, bsi_stream_t stream);
 /* out[c] = sum over r < rows of src[r * ld + c] (fp32, c < cols, cols % 4 == 0), rows added in index order (deterministic): the second

@@ -798,6 +798,34 @@ def test_gemm_tn_and_colsum(N, M, Nn, K):
         assert rel_linf(cs2, mult * dY.double().sum(0)) < 1e-5, rel_linf(cs2, mult * dY.double().sum(0))
 
 
+@pytest.mark.parametrize("M,N1,N2,K,ld1", [(16384, 3072, 1024, 1024, 3072), (4096 + 40, 768, 200, 256, 1024), (700, 256, 256, 320, 256)])
+def test_gemm_tn_pair_matches_two_launches(N, M, N1, N2, K, ld1):
+    """bsi_gemm_tn_pair_bf16: two weight gradients of one token count in one launch (the DiT block's qkv + out-projection gradients:
+    64 output tiles together) against fp64 on the same bf16 operands and against the two single launches (another split of the token
+    range: equal to fp32 summation order); ragged token counts / second N / padded leading dimension; run twice (reproducible)."""
+    gen = torch.Generator().manual_seed(M + N1 + N2)
+    dY1 = bf16r(torch.randn((M, ld1), generator=gen))
+    dY2 = bf16r(torch.randn((M, N2), generator=gen))
+    X1, X2 = bf16r(torch.randn((M, K), generator=gen)), bf16r(torch.randn((M, K), generator=gen))
+    r1, r2 = dY1[:, :N1].double().t() @ X1.double(), dY2.double().t() @ X2.double()
+    d1, d2, q1, q2 = (dev(t.to(torch.bfloat16)) for t in (dY1, dY2, X1, X2))
+    ws = torch.empty(N.lib().bsi_gemm_tn_workspace_bytes(M, N1 + (N2 + 255) // 256 * 256, K), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        o1 = torch.full((N1, K), float("nan"), device=DEV)
+        o2 = torch.full((N2, K), float("nan"), device=DEV)
+        N.check(N.lib().bsi_gemm_tn_pair_bf16(N.ptr(d1), ld1, N.ptr(q1), N1, N.ptr(o1), N.ptr(d2), N2, N.ptr(q2), N2, N.ptr(o2), K, M, K,
+                                              N.ptr(ws), N.stream()))
+        torch.cuda.synchronize()
+        outs.append((o1, o2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_linf(outs[0][0], r1) < 3e-5 and rel_linf(outs[0][1], r2) < 3e-5
+    s1, s2 = empty(N1, K), empty(N2, K)
+    N.check(N.lib().bsi_gemm_tn_bf16(N.ptr(d1), ld1, N.ptr(q1), K, M, N1, K, N.ptr(s1), K, 0, N.ptr(ws), N.stream()))
+    N.check(N.lib().bsi_gemm_tn_bf16(N.ptr(d2), N2, N.ptr(q2), K, M, N2, K, N.ptr(s2), K, 0, N.ptr(ws), N.stream()))
+    assert rel_linf(outs[0][0], s1.cpu().double()) < 2e-5 and rel_linf(outs[0][1], s2.cpu().double()) < 2e-5
+
+
 # ----------------------------------------------------------------------------------------------
 # backward kernels (checked against torch autograd of the oracle expressions in fp64)
 # ----------------------------------------------------------------------------------------------

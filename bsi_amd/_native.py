@@ -266,7 +266,7 @@ PROF_CLASSES = {"gemm_qkv": 0, "gemm_out": 1, "gemm_fc1": 2, "gemm_fc2": 3, "att
 
 def fc1_kernel_name():
     """Name (as rocprofv3 prints it) of the kernel the DiT engine launches for fc1 = the benchmark's dominant kernel."""
-    return "gemm_bf16_k64r_kernel<BSI_EPI_BIAS_GELU_BF16=2> (fc1)"
+    return "gemm_bf16_k64r_kernel<BSI_EPI_BIAS_GELU_BF16=2, DYN=false> (fc1)"
 
 
 def prof_enable(names=()):

@@ -65,6 +65,7 @@ for B in 64 512; do B=$B S=16 timeout 600 python tools/experiments/tile_queue_ab
 bash tools/experiments/r5_queue_sampling_ab.sh > $O/tile_queue_sampling_ab.txt 2>&1
 # paired qkv + out-projection weight gradient, two-source slab convolution
 ROUNDS=2 bash tools/experiments/ab.sh "BSI_TRAIN_NO_TN_PAIR=0 STEPS=5" "BSI_TRAIN_NO_TN_PAIR=1 STEPS=5" "BSI_TRAIN_NO_TN_PAIR=0 B=64 STEPS=10" "BSI_TRAIN_NO_TN_PAIR=1 B=64 STEPS=10" -- python tools/train_profile.py > $O/tn_pair_ab.txt 2>&1
+for B in 512 64; do NOBIAS=1 B=$B timeout 300 python tools/tn_bench.py 2>&1 | grep -v amdgpu.ids; done > $O/tn_pair_vs_two_launches.txt
 ROUNDS=3 bash tools/experiments/ab.sh "BSI_CONV_ABL=0 B=512" "BSI_CONV_ABL=8192 B=512" -- python tools/unet_bench.py > $O/unet_two_source_slab_e2e_ab.txt 2>&1
 B=256 ABL=0,8192,0,8192 timeout 300 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids > $O/unet_two_source_slab_conv_ab.txt
 # the GPU suite on the final tree: tail with every BOUND / PARITY line

@@ -344,6 +344,36 @@ def test_train_loss_gradients_vs_golden():
         assert abs(sq ** 0.5 / float(g["grad_norm"]) - 1) < 1e-2, (sq ** 0.5, float(g["grad_norm"]), worst)
 
 
+def test_grouped_adaln_path_on_flat_parameters_matches_the_per_block_path_and_the_reference():
+    """The training forward runs the per-sample adaLN MLPs of all blocks as TWO grouped launches when the blocks' matrices and biases
+    lie at uniform positive strides -- which only the flat parameter buffer of DPTrainer gives (bsi_amd/csrc/dit_train.hip) -- and as
+    one split-K GEMM per block and matrix otherwise (other summation order).  Same weights, same draws: the flat-parameter model's
+    loss and gradient must agree with the per-block path and with the reference's golden gradients (G4, depth 2)."""
+    from bsi_amd.dp import DPTrainer
+    g = golden("g4_train_dit")
+    plain = make_model("dit_ff", True).train()
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss_p = make_bsi(plain).train_loss(g["x"].to(DEV))
+    loss_p.mean().backward()
+    flat_model = make_model("dit_ff", True).train()
+    tr = DPTrainer(make_bsi(flat_model), lr=5e-4, max_grad_norm=1.0)      # re-homes the parameters into one flat buffer
+    biases = [blk.adaLN_modulation[2].bias.data_ptr() for blk in flat_model.dit.blocks]
+    assert biases[1] > biases[0]                                            # uniform positive strides: the grouped launch is taken
+    with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
+        loss_f, flat_g = tr._backward(g["x"].to(DEV), None)
+    bound("test_grouped_adaln:loss_vs_per_block_path", abs(float(loss_f) / float(loss_p.mean()) - 1), 1e-5)
+    bound("test_grouped_adaln:loss_vs_reference", abs(float(loss_f) / float(g["loss_mean"]) - 1), 2e-3)
+    worst_p, worst_r = 0.0, 0.0
+    for name, o, n in zip(tr.fp.names, tr.fp.offsets, tr.fp.sizes):
+        got = flat_g[o:o + n].cpu().double()
+        per_block = dict(plain.named_parameters())[name].grad.reshape(-1).cpu().double()
+        ref = g["G." + name].reshape(-1).double()
+        worst_p = max(worst_p, float((got - per_block).norm() / per_block.norm().clamp_min(1e-30)))
+        worst_r = max(worst_r, float((got - ref).norm() / ref.norm().clamp_min(1e-30)))
+    bound("test_grouped_adaln:grad_vs_per_block_path", worst_p, 1e-3)
+    bound("test_grouped_adaln:grad_vs_reference", worst_r, 1e-2)
+
+
 def test_fused_clip_adamw_ema_vs_golden():
     """bsi_grad_sqnorm + bsi_clip_adamw_ema against torch.optim.AdamW + clip_grad_norm_ recorded from torch (G8)."""
     import ctypes as C

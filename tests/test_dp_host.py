@@ -295,3 +295,48 @@ def test_gloo_world2_start_broadcast_and_sharded_update():
     assert a["sharded"]["calls"] == {"rs": 3 * nb, "ag": 3 * nb + nb, "ar": 3}
     assert a["allreduce"]["calls"] == {"rs": 0, "ag": 0, "ar": 3 * nb}
     assert a["sharded"]["shard"] * world == a["sharded"]["n"]      # the shard buffer holds exactly 1/world of the gradient
+
+
+def test_rehearsal_lays_out_another_world_without_communicating():
+    """`rehearse=(world, rank)` (bench.py's one-GPU timing of a rank's share): no process group, buckets / slices / norm chunks as on
+    that rank of that world.  With the all-reduce layout the whole buffer is updated with 1 / world; with the sharded update only the
+    rank's slices move -- to the values the all-reduce layout gives them -- and everything else stays."""
+    from bsi_amd import dp
+    assert not dist.is_initialized()
+    X = _data(16)
+    outs = {}
+    for mode, kw in (("all", {}), ("shard0", {"shard_update": True}), ("shard1", {"shard_update": True})):
+        torch.manual_seed(0)
+        model = _ToyDiT()
+        rank = 1 if mode == "shard1" else 0
+        tr = _host_trainer(_ToyBSI(model), [], lr=1e-2, max_grad_norm=0.05, ema_update_after_step=0, rehearse=(2, rank), **kw)
+        assert tr.world == 1 and not tr.exchange and tr.lay_world == 2 and tr.lay_rank == rank
+        assert tr.fp.flat.numel() % (2 * dp.SEG_ALIGN) == 0 and tr.xchg.covers(tr.fp.flat.numel())
+        before = tr.fp.flat.clone()
+        if kw:   # a rehearsal has no reduce-scatter: the shard buffer holds the rank's slices of the local gradient
+            orig = tr._update
+
+            def upd(flat_g, lr, w, tr=tr, orig=orig):
+                for p_off, g_off, ln, _, _ in tr.seg_rows:
+                    tr.gshard[g_off:g_off + ln].copy_(flat_g[p_off:p_off + ln])
+                return orig(flat_g, lr, w)
+
+            tr._update = upd
+        tr.train_step(X)
+        own = torch.zeros(tr.fp.flat.numel(), dtype=torch.bool)
+        for p_off, _, ln, _, _ in tr.seg_rows:
+            own[p_off:p_off + ln] = True
+        outs[mode] = (tr.fp.flat.clone(), before, own, float(tr.sq[0]))
+    full = outs["all"]
+    assert bool(full[2].all())
+    for mode in ("shard0", "shard1"):
+        flat, before, own, _ = outs[mode]
+        assert 0 < int(own.sum()) < own.numel() and torch.equal(flat[~own], before[~own])
+    # the two ranks' slices tile the buffer, and a rank's slices get the all-reduce layout's values when the norm is the same: here
+    # each rank only sees its own partials (no exchange in a rehearsal), so compare the update direction on the owned slices instead
+    assert bool((outs["shard0"][2] ^ outs["shard1"][2]).all())
+    for mode in ("shard0", "shard1"):
+        flat, before, own, _ = outs[mode]
+        moved = (flat - before)[own]
+        ref = (full[0] - full[1])[own]
+        assert torch.equal(torch.sign(moved), torch.sign(ref))

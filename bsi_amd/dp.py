@@ -341,8 +341,8 @@ class DPTrainer:
 
     def _backward(self, x, generator):
         """BSI.train_loss + the HIP backward on this rank's shard: (mean loss, flat fp32 gradient in FlatParams order).
-        With the exchange on, the backward records event l when block l's gradients are enqueued.  The CU reserve is set between
-        the forward and the backward (grids are sized at launch) and cleared by `train_step` after the exchange."""
+        With the exchange on, the backward records event l when block l's gradients are enqueued.  The CU reserve and the tile queue
+        are in force for the launches of the backward only."""
         lib = N.lib()
         for p in self.model.parameters():
             p.grad = None
@@ -353,6 +353,8 @@ class DPTrainer:
         self.model._flat_grad_only = True
         try:
             loss = self.bsi.train_loss(x, generator).mean()
+            # grids are sized when a kernel is LAUNCHED: the switches are on while the backward's kernels are enqueued (the forward
+            # above overlaps with nothing) and off again before this returns -- the exchange only launches RCCL's own kernels
             if self.cu_reserve:
                 N.check(lib.bsi_set_cu_reserve(self.cu_reserve))
             if self.tile_queue:
@@ -361,6 +363,10 @@ class DPTrainer:
         finally:
             self.model._flat_grad_only = False
             self.model._grad_buffer = None
+            if self.cu_reserve:
+                N.check(lib.bsi_set_cu_reserve(0))
+            if self.tile_queue:
+                N.check(lib.bsi_set_tile_queue(0))
             if self.exchange and self.bucketed:
                 N.check(lib.bsi_dit_backward_set_events(None, 0))
         flat_g = self.model._last_flat_grad
@@ -459,15 +465,9 @@ class DPTrainer:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (self.time_stages and x.is_cuda) else None
         if ev:
             ev[0].record()
-        try:
-            loss, flat_g = self._backward(x, generator)
-            if self.exchange:
-                self._exchange(flat_g)
-        finally:
-            if self.cu_reserve and x.is_cuda:
-                N.check(N.lib().bsi_set_cu_reserve(0))    # the update, sampling / evaluation between steps use every CU
-            if self.tile_queue and x.is_cuda:
-                N.check(N.lib().bsi_set_tile_queue(0))
+        loss, flat_g = self._backward(x, generator)
+        if self.exchange:
+            self._exchange(flat_g)
         lr = self.lr_schedule(self.step_count) if self.lr_schedule is not None else self.lr
         w = ema_weight(self.step_count, beta=self.ema_beta, update_after_step=self.ema_after) if self.ema_fp else -1.0
         self.step_count += 1

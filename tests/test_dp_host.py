@@ -340,3 +340,21 @@ def test_rehearsal_lays_out_another_world_without_communicating():
         moved = (flat - before)[own]
         ref = (full[0] - full[1])[own]
         assert torch.equal(torch.sign(moved), torch.sign(ref))
+
+
+def test_gloo_world3_sharded_update_matches_allreduce():
+    """A world size that is not a power of two: slices of world x 16 bytes, three slices per bucket, replicas identical, and the sharded
+    step equal to the all-reduce step to fp32 rounding (gloo's reduce-scatter and all-reduce may add three terms in different orders:
+    bit equality is a world-2 property)."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_modes, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for mode in ("allreduce", "own_seed", "sharded"):
+        for r in (1, 2):
+            assert torch.equal(ret[0][mode]["flat"], ret[r][mode]["flat"]) and torch.equal(ret[0][mode]["ema"], ret[r][mode]["ema"]), (mode, r)
+    a = ret[0]
+    assert torch.equal(a["own_seed"]["flat"], a["allreduce"]["flat"])
+    assert torch.allclose(a["sharded"]["flat"], a["allreduce"]["flat"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(a["sharded"]["ema"], a["allreduce"]["ema"], rtol=1e-5, atol=1e-7)
+    assert a["sharded"]["n"] % (world * 4) == 0 and a["sharded"]["shard"] * world == a["sharded"]["n"]

@@ -783,19 +783,23 @@ def test_dp_trainer_exchange_path_on_one_rank():
                                    (lambda: make_unet(), "g4_train_unet", (3, 8, 8))):
             g = golden(gname)
             outs = []
-            for force in (False, True):
+            # exchange off / all-reduce over RCCL / sharded step over RCCL (reduce_scatter_tensor into the shard buffer, the segment
+            # optimizer kernels, all_gather_into_tensor in place: with one rank a slice is a whole bucket)
+            for force, shard in ((False, False), (True, False), (True, True)):
                 torch.manual_seed(5)
                 model = make()
                 model._drop_calls = 0
                 tr = DPTrainer(make_bsi(model, shape), lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0,
-                               force_exchange=force)
+                               force_exchange=force, shard_update=shard)
                 assert tr.exchange == force
                 for _ in range(2):
                     with replay_noise(rand=[g["offset"]], randperm=[g["perm"]], randn=[g["eps"]]):
                         loss = tr.train_step(g["x"].to(DEV))
+                tr.gather_ema()
                 torch.cuda.synchronize()
                 outs.append((float(loss), tr.fp.flat.clone(), tr.ema_fp.flat.clone()))
             assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]), (gname, outs[0][0], outs[1][0])
+            assert outs[2][0] == outs[1][0] and torch.equal(outs[2][1], outs[1][1]) and torch.equal(outs[2][2], outs[1][2]), gname
             # atomics in the backward make the low bits run-dependent; the two paths must agree to fp32 noise
             bound("test_dp_trainer_exchange_path_on_one_rank:651a", rel_linf(outs[1][1], outs[0][1]), 1e-5)
             bound("test_dp_trainer_exchange_path_on_one_rank:651b", rel_linf(outs[1][2], outs[0][2]), 1e-5)

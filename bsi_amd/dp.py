@@ -245,9 +245,9 @@ class DPTrainer:
         # Compute units left to the RCCL kernels while buckets are in flight.  The weight-gradient GEMMs and convolutions of the
         # backward are persistent with a STATIC share of the work per workgroup (one 160-KB-LDS workgroup per CU): a communication
         # kernel that holds c CUs leaves c of those workgroups unplaced until the others finish -- the launch takes twice as long.
-        # With the reserve their grids are `CUs - reserve` wide.  It is in force only where a bucket can be in flight: from the
-        # start of the backward to the end of the exchange of a BUCKETED model (the forward, and a model whose single bucket
-        # leaves after the backward, overlap with nothing).  Default: BSI_DP_CU_RESERVE or 0 -- no multi-GPU run has confirmed a
+        # With the reserve their grids are `CUs - reserve` wide.  It is in force only for the kernels that can run beside a bucket:
+        # while the backward of a BUCKETED model is enqueued (grids are sized at launch; the forward, and a model whose single
+        # bucket leaves after the backward, overlap with nothing).  Default: BSI_DP_CU_RESERVE or 0 -- no multi-GPU run has confirmed a
         # gain yet (bench.py --gpus N measures the step under both settings); RCCL's channel count must then be capped to the
         # same number BEFORE init_process_group (NCCL_MAX_NCHANNELS; bench.py does it), which is checked here.
         if cu_reserve is None:
@@ -255,15 +255,15 @@ class DPTrainer:
         self.cu_reserve = _check_reserve(int(cu_reserve)) if (self.exchange or rehearse) and self.bucketed else 0
         if self.cu_reserve and self.exchange and bsi.model is not None and next(self.model.parameters()).is_cuda:
             ch = os.environ.get("NCCL_MAX_NCHANNELS")
-            if ch is None or int(ch) > self.cu_reserve:
+            if ch is None or not ch.isdigit() or int(ch) > self.cu_reserve:
                 import warnings
                 warnings.warn(f"DPTrainer: cu_reserve = {self.cu_reserve} but NCCL_MAX_NCHANNELS = {ch}: RCCL may launch more "
                               "workgroups than CUs are kept free for it; export NCCL_MAX_NCHANNELS before init_process_group")
         # Tile queue (bsi_set_tile_queue): the persistent GEMMs of the backward that have more tiles than CUs draw their tiles from
         # counters instead of taking a static share, on ALL CUs whatever the reserve says -- a workgroup whose CU an RCCL kernel holds
         # leaves its share to the others, and no CU idles while RCCL is quiet (the reserve then only sizes the kernels that keep a
-        # static partition: weight-gradient GEMMs, attention).  Bit-identical results.  On where buckets can be in flight, like the
-        # reserve: from the start of the backward to the end of the exchange of a bucketed model.  BSI_DP_TILE_QUEUE=0 switches it off.
+        # static partition: weight-gradient GEMMs, attention).  Bit-identical results.  On for the launches of the backward of a
+        # bucketed model, like the reserve.  BSI_DP_TILE_QUEUE=0 switches it off.
         if tile_queue is None:
             tile_queue = os.environ.get("BSI_DP_TILE_QUEUE", "1") != "0"
         self.tile_queue = bool(tile_queue) and (self.exchange or bool(rehearse)) and self.bucketed

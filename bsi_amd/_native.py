@@ -255,6 +255,7 @@ _PROTOS = {
     "bsi_set_cu_reserve": (_i, [_i]),
     "bsi_compute_cus": (_i, []),
     "bsi_set_tile_queue": (_i, [_i]),
+    "bsi_set_attention_bwd_skew": (_i, [_i]),
     "bsi_prof_enable": (_i, [C.c_uint]),
     "bsi_prof_read": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

@@ -61,7 +61,16 @@ __device__ __forceinline__ s16x4 tr_rd(unsigned addr) {
 // DROP: 0 = no dropout, 2 = the mask arrives as the 64-bit words of attention_persist.hip (word (16-query block qb, 16-key block
 // kt, r), bit 16 g + c = keep(query 16 qb + c, key 16 kt + 4 g + r)); a lane = one key, four queries reads the 16-bit group of its
 // key and tests four bits.  (The hash form, DROP = 1, stays with the two-pass kernel.)
-template <int DROP>
+// SKEW (round 5): the two wave groups (waves 0-3 = A, 4-7 = B; a SIMD hosts one wave of each) run HALF A TRIP apart -- the persistent
+// GEMM's ping-pong.  A trip is two slots with a barrier behind each: H1 = S / dP MFMAs, softmax, dS block to X[t & 1]; H2 = dV / dK
+// MFMAs, a dQ^T tile, the fetches.  B executes one barrier more in front of its first H1 of every pair (and A one behind its pair
+// epilogue), so B's H1(t) runs next to A's H2(t) and B's H2(t) next to A's H1(t + 1): vector and matrix phases of a SIMD's two waves
+// alternate instead of coinciding.  X[t & 1] is whole when B's H1(t) ends, i.e. when A's H2(t) ends too: A forms the dQ^T tile of trip
+// t - 1 in H2(t) (that of trip 7 in front of its pair epilogue), B that of trip t -- X stays two deep (A writes X[t + 1] in the slot
+// after its read of X[t - 1], next to B's read of X[t]).  Rows and words of a trip are dead one slot later than without the skew, so
+// H2(t) refills the slot of trip t - 1 (trip 0: slot 7, for THIS pair's trip 7).  The per-wave issue order is the unskewed one, the
+// counted waits carry over (A's extra dQ store in the epilogue only makes two of them stricter).
+template <int DROP, bool SKEW>
 __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __restrict__ qkv, int ld_qkv, const __bf16* __restrict__ o,
                                                               const __bf16* __restrict__ dout, int ld_o, const float* __restrict__ lse,
                                                               int pairs, int heads, __bf16* __restrict__ dqkv, int ld_dqkv, float scale,
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     //      each, instead of the ~50 registers of hoisted 64-bit addresses (or ~100 integer instructions per trip to redo them) that
     //      per-lane pointer arithmetic cost.
     const int second = wave >> 2, w4 = wave & 3;
+    const int grp = second;  // SKEW: wave group (B = 1 runs half a trip late)
     const int drow8 = lane >> 3;
     const unsigned dchunk = (unsigned)(((lane & 7) ^ sw(drow8)) << 4);  // sw(8 k + drow8) = sw(drow8)
     const unsigned ldb1 = (unsigned)((second ? ld_o : ld_qkv) * 2), ldbq = (unsigned)(ld_qkv * 2), ldbo = (unsigned)(ld_o * 2);
@@ -99,19 +109,23 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     auto issue_qd = [&](int pr, int t) {  // rows 32 t .. 32 t + 31 of Q (waves 0-3) and dO (waves 4-7): 8 rows per wave
         const int row0 = 32 * t + 8 * w4;
         const char* src = (second ? reinterpret_cast<const char*>(dout) + o_off(pr) : q_base(pr)) + (size_t)row0 * ldb1;
+        if constexpr (SKEW) asm volatile("" : "+s"(src));  // (pair, slot) vary per trip there: without the fence the sum becomes a per-lane 64-bit induction variable
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + qd_off), LDS_PTR(lds + (second ? DL : QL) + row0 * RB), 16, 0, 0);
     };
     auto issue_k = [&](int pr) {  // K tile: rows 32 wave .. + 31 (4 instructions)
         const char* src = q_base(pr) + (size_t)heads * DH * 2 + (size_t)(32 * wave) * ldbq;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)(8 * t4) * ldbq + k_off), LDS_PTR(lds + KL + (32 * wave + 8 * t4) * RB), 16, 0, 0);
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const char* s4 = src + (size_t)(8 * t4) * ldbq;
+            if constexpr (SKEW) asm volatile("" : "+s"(s4));  // (without the fence: four per-lane 64-bit addresses per pair, spilled in the skewed instances)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(s4 + k_off), LDS_PTR(lds + KL + (32 * wave + 8 * t4) * RB), 16, 0, 0);
+        }
     };
     auto issue_mask = [&](int pr, int t) {  // DROP == 2: the trip's 1 KB of words, 128 B per wave (8 lanes)
         if constexpr (DROP == 2) {
-            if (lane < 8)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(maskw + (size_t)pr * MK_BYTES + t * 1024 + wave * 128 + lane * 16),
-                                                 LDS_PTR(lds + MK + t * 1024 + wave * 128), 16, 0, 0);
+            const char* mb = maskw + (size_t)pr * MK_BYTES + t * 1024 + wave * 128;  // wave-uniform base + a 32-bit lane offset, as everywhere
+            if constexpr (SKEW) asm volatile("" : "+s"(mb));
+            if (lane < 8) __builtin_amdgcn_global_load_lds(GLB_PTR(mb + (unsigned)lane * 16u), LDS_PTR(lds + MK + t * 1024 + wave * 128), 16, 0, 0);
         }
     };
     // ---- this wave's own V rows, as MFMA fragments straight from memory (inline asm: the compiler must not wait for them).  They are
@@ -199,6 +213,26 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
     const char* Dl = lds + DL;
     const char* Kl = lds + KL;
 
+    // the eight waves' bias partials of pair (b_, h_) in wave order -> bias_rows; a dQ column has two contributors (the waves of its head-dim
+    // block).  192 threads: waves 0-2 behind the pair's last barrier; SKEW: waves 4-6 behind B's first barrier of the next pair.
+    auto bias_reduce = [&](int to, int b_, int h_) {
+        asm volatile("" : "+v"(to));  // LDS addresses formed here, not hoisted out of the pair loop (two were spilled)
+        const int part = to >> 6, d = to & 63;
+        float a;
+        const char* bq = lds + XL + (to >> 3) * XP + 64 + (to & 7) * 4;  // float `to` of wave 0's partials
+        if (part == 0) {
+            a = *reinterpret_cast<const float*>(bq + (d >> 4) * BPW) + *reinterpret_cast<const float*>(bq + (d >> 4) * BPW + 4 * BPW);
+        } else {
+            a = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) a += *reinterpret_cast<const float*>(bq + w8 * BPW);
+        }
+        float* br = bias_rows;
+        asm volatile("" : "+s"(br));  // a scalar base at the point of use (hoisted as a vector pair it was spilled: a scratch reload here drains vmcnt)
+        br[(size_t)b_ * (3 * heads * DH) + part * heads * DH + h_ * DH + d] = a;  // (one more store on three waves: the counted waits only over-wait)
+    };
+    int pprev = -1;  // SKEW: the pair whose bias partials group B still has to reduce
+
     while (true) {
         const int nxt = pr + gridDim.x < pairs ? pr + gridDim.x : pr;  // past the end: re-fetch this pair (never read)
         const int b = pr / heads, h = pr % heads;
@@ -213,6 +247,41 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 kf[jk][ks] = *reinterpret_cast<const bf16x8*>(row_chunk(Kl, k, 4 * ks + g));
             }
         }
+        // ---- S = Q . K^T, dP = dO . V^T for 32 queries x this wave's 32 keys (key on the lane, four queries per register quad)
+        f32x4 s[2][2], dp[2][2];
+        auto m1 = [&](const int t) {
+            const int qc = 32 * t;
+            if (t == 0) WAIT_V(20 + NM);  // fetched in trip 7 of the previous pair, in front of its 3 + 1 + NM fetches and the 16 stores
+            bf16x8 vf[2][2];
+#pragma unroll
+            for (int jk = 0; jk < 2; ++jk)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    Frag f;
+                    f.u = vn[jk][ks];
+                    vf[jk][ks] = f.v;
+                }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                s[qt][0] = s[qt][1] = dp[qt][0] = dp[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int row = qc + 16 * qt + c16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(row_chunk(Ql, row, 4 * ks + g));
+                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(row_chunk(Dl, row, 4 * ks + g));
+#pragma unroll
+                    for (int jk = 0; jk < 2; ++jk) {
+                        if constexpr (ABL & 16) {
+                            s[qt][jk][0] += __builtin_bit_cast(f32x4, qa)[0] + __builtin_bit_cast(f32x4, kf[jk][ks])[0];
+                            dp[qt][jk][0] += __builtin_bit_cast(f32x4, da)[0] + __builtin_bit_cast(f32x4, vf[jk][ks])[0];
+                            continue;
+                        }
+                        s[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[jk][ks], s[qt][jk], 0, 0, 0);
+                        dp[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[jk][ks], dp[qt][jk], 0, 0, 0);
+                    }
+                }
+            }
+        };
         int lp = lane;
         asm volatile("" : "+v"(lp));  // the K^T address is used here only: formed per pair instead of living in a register through the loops
         const int gp = lp >> 4, qpp = (lp & 15) >> 2, ppp = lp & 3;
@@ -230,7 +299,6 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
         f32x4 dk[4][2], dv[4][2];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt][0] = dk[dt][1] = dv[dt][0] = dv[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         // ---- dQ^T tile (head-dim block dtw, queries 32 tt + 16 jqw ..) of trip tt = K^T . dS^T over all 256 keys, from X[tt & 1]: all 16
         //      transposed reads are issued at once, the first four MFMAs start when half of them are back (LDS returns in order).
         //      (Running the tile one trip late, under the next trip's softmax, measured the same time at 15 registers more: not kept.)
@@ -268,40 +336,16 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 qsum[2] += __uint_as_float(w[1] << 16); qsum[3] += __uint_as_float(w[1] & 0xffff0000u);
             }
         };
+        if constexpr (SKEW) {
+            if (grp) {  // B: half a trip behind A from here on.  All eight waves' bias partials of the previous pair are written now
+                PBARRIER();
+                if (BIAS_ON && pprev >= 0 && tid < 448) bias_reduce(tid - 256, pprev / heads, pprev % heads);
+            }
+        }
+
         auto trip = [&](const int t, StatSet& S) {
             const int qc = 32 * t;
-            // ---- S = Q . K^T, dP = dO . V^T for 32 queries x this wave's 32 keys (key on the lane, four queries per register quad)
-            f32x4 s[2][2], dp[2][2];
-            if (t == 0) WAIT_V(20 + NM);  // fetched in trip 7 of the previous pair, in front of its 3 + 1 + NM fetches and the 16 stores
-            bf16x8 vf[2][2];
-#pragma unroll
-            for (int jk = 0; jk < 2; ++jk)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    Frag f;
-                    f.u = vn[jk][ks];
-                    vf[jk][ks] = f.v;
-                }
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                s[qt][0] = s[qt][1] = dp[qt][0] = dp[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int row = qc + 16 * qt + c16;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(row_chunk(Ql, row, 4 * ks + g));
-                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(row_chunk(Dl, row, 4 * ks + g));
-#pragma unroll
-                    for (int jk = 0; jk < 2; ++jk) {
-                        if constexpr (ABL & 16) {
-                            s[qt][jk][0] += __builtin_bit_cast(f32x4, qa)[0] + __builtin_bit_cast(f32x4, kf[jk][ks])[0];
-                            dp[qt][jk][0] += __builtin_bit_cast(f32x4, da)[0] + __builtin_bit_cast(f32x4, vf[jk][ks])[0];
-                            continue;
-                        }
-                        s[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[jk][ks], s[qt][jk], 0, 0, 0);
-                        dp[qt][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[jk][ks], dp[qt][jk], 0, 0, 0);
-                    }
-                }
-            }
+            m1(t);
             // ---- the transposed Q / dO fragments (for dK / dV): all 16 reads go out together behind the softmax and each group of eight MFMAs
             //      waits only for its own eight.  (The first eight in FRONT of the softmax -- they do not depend on it -- measured 1 % faster
             //      at 16 registers more, which the instances with the bias sums do not have.)
@@ -372,6 +416,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     *reinterpret_cast<u32x2*>(xw + jk * 16 * XP + 32) = u32x2{dsf[jk].u[2], dsf[jk].u[3]};
                 }
             }
+            if constexpr (SKEW && !(ABL & 8)) PBARRIER();  // end of H1: this group's dS block is in X[t & 1]
             // ---- dV^T += dO^T . P, dK^T += Q^T . dS
             if constexpr (ABL & 2) {
                 dv[0][0][0] += __builtin_bit_cast(f32x4, pf[0].v)[0] + __builtin_bit_cast(f32x4, pf[1].v)[0];
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                     }
             }
 #undef QD_RD
-            if constexpr (!(ABL & 8)) PBARRIER();  // every wave's dS block is in X[t & 1]; the trip's Q / dO rows and dropout words are dead
+            if constexpr (!SKEW && !(ABL & 8)) PBARRIER();  // every wave's dS block is in X[t & 1]; the trip's Q / dO rows and dropout words are dead
 
             // ---- the next pair's share of this trip: statistics of four queries, the Q / dO rows and dropout words of this trip's slot
             //      (trip 0: also the K tile; trip 7: this wave's V rows; both IN FRONT of the statistics loads, so that one count serves
@@ -408,7 +453,14 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             //      ONE wait statement carries the loaded registers: with a second one in the other arm of an if / else, hipcc merged the
             //      arms by COPYING the loaded registers in front of one arm's wait -- stale statistics in a few pairs per thousand
             //      (tools/check_asm_loads.py scans for that pattern).
-            if constexpr (!(ABL & 4)) dq_tile(t);
+            if constexpr (!(ABL & 4)) {
+                if constexpr (SKEW) {
+                    const int tt = t - 1 + grp;  // A: the tile of the trip before (X[t & 1] still lacks B's block)
+                    if (tt >= 0) dq_tile(tt);
+                } else {
+                    dq_tile(t);
+                }
+            }
             if constexpr (!(ABL & 32)) {
             if (!(ABL & 128) && t >= 2) {  // 128: no wait for / use of the statistics loads
                 // this set's loads went out in trip t - 2; younger: that trip's rows + words, trip t - 1 whole (store, 3 loads, rows,
@@ -420,10 +472,16 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             if (!(ABL & 256) && t == 0) issue_k(nxt);  // 256: no LDS-DMA
             if constexpr (!(ABL & 512)) issue_stats(S, nxt, t);  // 512: no statistics loads
             if constexpr (!(ABL & 256)) {
-                issue_qd(nxt, t);
-                issue_mask(nxt, t);
+                if constexpr (SKEW) {  // the slot of trip t - 1 (dead since the other group's H2(t - 1)); trip 0: slot 7, for this pair's trip 7
+                    issue_qd(t ? nxt : pr, (t + 7) & 7);
+                    issue_mask(t ? nxt : pr, (t + 7) & 7);
+                } else {
+                    issue_qd(nxt, t);
+                    issue_mask(nxt, t);
+                }
             }
             }
+            if constexpr (SKEW && !(ABL & 8)) PBARRIER();  // end of H2
         };
 #pragma unroll 1
         for (int t2 = 0; t2 < 8; t2 += 2) {
@@ -431,6 +489,9 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
             trip(t2 + 1, S1);
         }
         // ---- end of the pair: the statistics of trip 7, then dK and dV of this wave's keys
+        if constexpr (SKEW && !(ABL & 4)) {
+            if (!grp) dq_tile(7);  // A: X[1] is whole since the barrier that ended its H2(7)
+        }
 #undef X_RD
         if constexpr (!(ABL & (32 | 128))) {
             WAIT_S(S0, 10 + 2 * NM);  // trip 6's set: behind it its rows + words and trip 7's store, 4 V loads, 3 loads, rows, words
@@ -460,17 +521,22 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 }
             }
         }
-        if (BIAS_ON) {  // column sums over this wave's 32 keys (dK, dV) / its 128 queries (dQ): lane c16 = 0 of row group g holds d = 4 g + r
+        // column sums over this wave's 32 keys (dK, dV) / its 128 queries (dQ): lane c16 = 0 of row group g holds d = 4 g + r
+        auto partial_base = [&](bool& first) {
             int lb = lane;
             asm volatile("" : "+v"(lb));  // one per-lane base formed here + immediates (hoisted addresses cost registers through both loops)
             const int gb = lb >> 4;
-            char* bpl = lds + XL + wave * BPW + (gb >> 1) * XP + 64 + (gb & 1) * 16;  // float 4 g of this wave's partials; + 16 dt floats = + 2 dt rows
-            const bool first = (lb & 15) == 0;
+            first = (lb & 15) == 0;
+            return lds + XL + wave * BPW + (gb >> 1) * XP + 64 + (gb & 1) * 16;  // float 4 g of this wave's partials; + 16 dt floats = + 2 dt rows
+        };
+        auto q_partials = [&](char* bpl, bool first) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sq = row16_sum(qsum[r]);
                 if (first) *reinterpret_cast<float*>(bpl + 2 * dtw * XP + 4 * r) = sq;
             }
+        };
+        auto kv_partials = [&](char* bpl, bool first) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -481,28 +547,29 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                         *reinterpret_cast<float*>(bpl + (16 + 2 * dt) * XP + 4 * r) = sv;  // floats 128 ..
                     }
                 }
+        };
+        if (BIAS_ON) {
+            bool first;
+            char* bpl = partial_base(first);
+            q_partials(bpl, first);
+            kv_partials(bpl, first);
         }
-        PBARRIER();  // the next pair's statistics are written, its K tile is whole (this wave's share was complete at the wait of trip 2)
-        if (BIAS_ON && tid < 192) {  // the eight waves' partials in wave order; a dQ column has two contributors (the waves of its head-dim block)
-            int to = tid;
-            asm volatile("" : "+v"(to));  // LDS addresses formed here, not hoisted out of the pair loop (two were spilled)
-            const int part = to >> 6, d = to & 63;
-            float a;
-            const char* bq = lds + XL + (to >> 3) * XP + 64 + (to & 7) * 4;  // float `to` of wave 0's partials
-            if (part == 0) {
-                a = *reinterpret_cast<const float*>(bq + (d >> 4) * BPW) + *reinterpret_cast<const float*>(bq + (d >> 4) * BPW + 4 * BPW);
-            } else {
-                a = 0.f;
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) a += *reinterpret_cast<const float*>(bq + w8 * BPW);
-            }
-            float* br = bias_rows;
-            asm volatile("" : "+s"(br));  // a scalar base at the point of use (hoisted as a vector pair it was spilled: a scratch reload here drains vmcnt)
-            br[(size_t)b * (3 * heads * DH) + part * heads * DH + h * DH + d] = a;  // (one more store on waves 0-2: the counted waits only over-wait)
+        if constexpr (SKEW) {
+            if (!grp) PBARRIER();  // A: its pair epilogue ran next to B's H2(7); the next pair's first statistics (wave 0's) are written
+            pprev = pr;
+        } else {
+            PBARRIER();  // the next pair's statistics are written, its K tile is whole (this wave's share was complete at the wait of trip 2)
+            if (BIAS_ON && tid < 192) bias_reduce(tid, b, h);
         }
         if (pr + (int)gridDim.x >= pairs) break;
         pr += gridDim.x;
         pb ^= 1;
+    }
+    if constexpr (SKEW) {
+        if (grp) {  // B's partials of the last pair are written behind this barrier (group A has left: not counted)
+            PBARRIER();
+            if (BIAS_ON && tid < 448) bias_reduce(tid - 256, pprev / heads, pprev % heads);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus fetches of the last pair land before the LDS is released
 #undef WAIT_S
@@ -511,6 +578,16 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
 }
 
 }  // namespace
+
+static int g_attn_bwd_skew = -1;  // -1: not decided (BSI_ATTN_BWD_SKEW, default on)
+
+// 1 (default): the single-sweep backward runs its wave groups half a trip apart; 0: in lock step (the A/B partner; bit-identical results).
+// Returns the previous setting.
+extern "C" int bsi_set_attention_bwd_skew(int on) {
+    const int prev = g_attn_bwd_skew < 0 ? (getenv("BSI_ATTN_BWD_SKEW") ? atoi(getenv("BSI_ATTN_BWD_SKEW")) != 0 : 1) : g_attn_bwd_skew;
+    g_attn_bwd_skew = on != 0;
+    return prev;
+}
 
 // (the dispatcher in attention_bwd.hip decides when this kernel runs)
 int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
@@ -524,8 +601,15 @@ int bsi_attention_bwd_exchange(const void* qkv, int ld_qkv, const void* out, con
                            reinterpret_cast<const __bf16*>(out), reinterpret_cast<const __bf16*>(dout), ld_o, lse, pairs, heads,
                            reinterpret_cast<__bf16*>(dqkv), ld_dqkv, sc, dc, reinterpret_cast<const char*>(maskw), bias_rows);
     };
-    if (dc.thr) go(attention_bwd_x_kernel<2>);
-    else go(attention_bwd_x_kernel<0>);
+    if (g_attn_bwd_skew < 0) g_attn_bwd_skew = getenv("BSI_ATTN_BWD_SKEW") ? atoi(getenv("BSI_ATTN_BWD_SKEW")) != 0 : 1;
+    if (g_attn_bwd_skew) {
+        if (dc.thr) go(attention_bwd_x_kernel<2, true>);
+        else go(attention_bwd_x_kernel<0, true>);
+    } else if (dc.thr) {
+        go(attention_bwd_x_kernel<2, false>);
+    } else {
+        go(attention_bwd_x_kernel<0, false>);
+    }
     BSI_CHECK_LAUNCH("bsi_attention_bwd(exchange)");
     return BSI_OK;
 }

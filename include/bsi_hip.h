@@ -692,6 +692,11 @@ int bsi_compute_cus(void);
  * is quiet.  Same tiles, same arithmetic per tile: results are bit-identical to the static schedule.  Process-wide, takes effect
  * at the next launch; default 0 (env BSI_TILE_QUEUE overrides).  DPTrainer switches it on for steps that exchange gradients. */
 int bsi_set_tile_queue(int on);
+/* Schedule of the single-sweep attention backward (256 tokens, head dim 64: autograd of dit.py:43-44).  1 (default; env
+ * BSI_ATTN_BWD_SKEW=0 overrides): the workgroup's two wave groups run half a trip apart, so that the softmax of one shares a SIMD with
+ * the matrix products of the other; 0: both in lock step (the A/B partner).  Same arithmetic in the same order: bit-identical
+ * results.  Process-wide, takes effect at the next launch; returns the previous setting. */
+int bsi_set_attention_bwd_skew(int on);
 /* bit i of mask enables class i; 0 disables.  Events are recorded around every launch of an enabled class
  * made through bsi_dit_forward / bsi_dit_adaln. */
 int bsi_prof_enable(unsigned mask);

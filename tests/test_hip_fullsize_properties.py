@@ -193,3 +193,32 @@ def test_train_step_is_bit_identical_with_the_tile_queue_and_a_cu_reserve():
     rel = float((c[1] - a[1]).abs().max() / a[1].abs().max())
     assert rel < 2e-3, rel  # measured 2.8e-4: Adam's first steps move a weight by ~lr whatever the size of its gradient, so last-bit differences of tiny gradients show
     report("train_step_tile_queue", model="dit", batch=32, steps=3, queue_bit_identical=True, reserve_rel_linf=rel)
+
+
+def test_train_step_is_bit_identical_under_both_attention_backward_schedules():
+    """Three optimizer steps of the full-size DiT-L/2 at 32 images (512 (image, head) pairs: two per compute unit, dropout on, the qkv
+    bias sums riding on the attention backward) end in the same parameters and EMA with the backward's wave groups half a trip apart
+    (the default) as in lock step: the skew moves work between barriers, not a bit of the result."""
+    from bsi_amd import _native as N
+    from bsi_amd.dp import DPTrainer
+    shape = (3, 32, 32)
+    finals = {}
+    prev = N.lib().bsi_set_attention_bwd_skew(1)
+    try:
+        for on in (1, 0):
+            N.lib().bsi_set_attention_bwd_skew(on)
+            torch.manual_seed(0)
+            model = _dit().train()
+            trainer = DPTrainer(_bsi(model, shape), lr=2e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0)
+            gen = torch.Generator(DEV).manual_seed(5)
+            x = (torch.randint(0, 256, (32, *shape), device=DEV, generator=torch.Generator(DEV).manual_seed(1)).float() / 255) * 2 - 1
+            losses = [float(trainer.train_step(x, gen)) for _ in range(3)]
+            torch.cuda.synchronize()
+            finals[on] = (losses, trainer.fp.flat.clone(), trainer.ema_fp.flat.clone())
+            del trainer, model
+            torch.cuda.empty_cache()
+    finally:
+        N.lib().bsi_set_attention_bwd_skew(prev)
+    a, b = finals[1], finals[0]
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    report("train_step_attention_bwd_schedules", model="dit", batch=32, steps=3, bit_identical=True)

@@ -905,6 +905,42 @@ def test_attention_dropout_forward_backward(N, B, heads, p, words):
     assert torch.equal(first_o.view(torch.int16), out.view(torch.int16)) and torch.equal(first_g.view(torch.int16), dqkv.view(torch.int16))
 
 
+@pytest.mark.parametrize("B,p", [(70, 0.1), (70, 0.0), (512, 0.1)])
+def test_attention_backward_schedules_agree_bit_for_bit(N, B, p):
+    """The single-sweep attention backward with its two wave groups half a trip apart (bsi_set_attention_bwd_skew(1), the default) and
+    in lock step (0) runs the same arithmetic in the same order: dQ, dK and dV agree bit for bit -- at 1120 pairs (4-5 per compute
+    unit) and at the training batch (8192 pairs, 32 per compute unit), so a hand-over between slots that read a tile, an exchange
+    buffer, a statistic or a mask word too early or too late in either schedule shows as a difference."""
+    tokens, heads, dh = 256, 16, 64
+    d = heads * dh
+    seed, site = 77, 3
+    gen = torch.Generator(device=DEV).manual_seed(B)
+    qkv = (torch.randn((B, tokens, 3 * d), device=DEV, generator=gen) * 1.1).to(torch.bfloat16)
+    dout = torch.randn((B, tokens, d), device=DEV, generator=gen).to(torch.bfloat16)
+    out = empty(B, tokens, d, dtype=torch.bfloat16)
+    lse = empty(B, heads, tokens)
+    mw = torch.zeros(B * heads * 8192, dtype=torch.uint8, device=DEV) if p else None
+    N.check(N.lib().bsi_attention_fwd_dropout(N.ptr(qkv), 3 * d, B, tokens, heads, dh, N.ptr(out), d, N.ptr(lse), p, seed, site,
+                                              N.ptr(mw) if p else None, N.stream()))
+    got = {}
+    prev = N.lib().bsi_set_attention_bwd_skew(1)
+    try:
+        for on in (1, 0, 1):
+            N.lib().bsi_set_attention_bwd_skew(on)
+            dqkv = torch.full((B, tokens, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+            N.check(N.lib().bsi_attention_bwd_dropout(N.ptr(qkv), 3 * d, N.ptr(out), N.ptr(dout), d, N.ptr(lse), B, tokens, heads, dh, N.ptr(dqkv),
+                                                      3 * d, p, seed, site, N.ptr(mw) if p else None, N.stream()))
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(dqkv.float()).all())
+            if on in got:
+                assert torch.equal(got[on].view(torch.int16), dqkv.view(torch.int16))
+            got[on] = dqkv
+    finally:
+        N.lib().bsi_set_attention_bwd_skew(prev)
+    diff = (got[0].view(torch.int16) != got[1].view(torch.int16))
+    assert not bool(diff.any()), (int(diff.sum()), torch.nonzero(diff)[:4].tolist())
+
+
 @pytest.mark.parametrize("Bs,tokens,d", [(3, 64, 128), (2, 256, 1024)])
 def test_gate_and_ln_backward(N, Bs, tokens, d):
     gen = torch.Generator().manual_seed(Bs + tokens + d)

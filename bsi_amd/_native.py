@@ -32,6 +32,10 @@ class CastDesc(C.Structure):
                 ("ld_t", C.c_int), ("tile0", C.c_int), ("reserved", C.c_int)]
 
 
+class CopyDesc(C.Structure):  # bsi_copy_desc (include/bsi_hip.h)
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("len", C.c_size_t), ("tile0", C.c_uint), ("reserved", C.c_uint)]
+
+
 class Seg(C.Structure):  # bsi_seg (include/bsi_hip.h)
     _fields_ = [("p_off", C.c_size_t), ("g_off", C.c_size_t), ("len", C.c_size_t), ("my_chunk", C.c_size_t), ("out_chunk", C.c_size_t)]
 
@@ -250,6 +254,8 @@ _PROTOS = {
                              _vp, _vp, _vp, _vp]),
     "bsi_sqnorm_segments": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),
     "bsi_sqnorm_finish": (_i, [_vp, _sz, _vp, _vp]),
+    "bsi_copy_batch_tiles": (_i, [_sz]),
+    "bsi_copy_batch_f32": (_i, [_vp, _i, _i, _vp]),
     "bsi_clip_adamw_ema_segments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "bsi_clock_probe": (_i, [_vp, _i, _vp]),
     "bsi_set_cu_reserve": (_i, [_i]),

@@ -22,7 +22,7 @@ void bsi_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bsi_last_error(void) { return g_err; }
-extern "C" int bsi_version(void) { return 105; }  // 100 + the round that last added entry points (round 5: 120 of them)
+extern "C" int bsi_version(void) { return 105; }  // 100 + the round that last added entry points (round 5: 122 of them)
 
 namespace {
 

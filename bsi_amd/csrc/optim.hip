@@ -225,3 +225,42 @@ extern "C" int bsi_clip_adamw_ema_segments(float* p, const float* g, float* m, f
     BSI_CHECK_LAUNCH("bsi_clip_adamw_ema_segments");
     return BSI_OK;
 }
+
+
+// ---- batched fp32 copy (round 5): n jobs (src, dst, len) in one launch.  The VDM-UNet backward hands the stacked FiLM gradients and the
+// shared conv2 / skip bias gradients to their parameters' places in the flat gradient buffer with it: torch._foreach_copy_ issues one
+// hipMemcpyAsync per pair on ROCm (167 per step, 3 % of the UNet train step's GPU time and ~1 ms of host time).
+namespace {
+constexpr int CPY_TILE = 2048;  // elements per workgroup
+__global__ __launch_bounds__(256) void copy_batch_kernel(const bsi_copy_desc* __restrict__ descs, int n) {
+    int lo = 0, hi = n - 1;  // the job of this tile: the last descriptor whose tile0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const bsi_copy_desc d = descs[lo];
+    const size_t e0 = (size_t)(blockIdx.x - d.tile0) * CPY_TILE;
+    const size_t left = d.len - e0;
+    const int cnt = left < (size_t)CPY_TILE ? (int)left : CPY_TILE;
+    const float* s = d.src + e0;
+    float* t = d.dst + e0;
+    if ((((uintptr_t)s | (uintptr_t)t) & 15) == 0) {
+        const int c4 = cnt >> 2;
+        for (int i = threadIdx.x; i < c4; i += 256) reinterpret_cast<float4*>(t)[i] = reinterpret_cast<const float4*>(s)[i];
+        for (int i = (c4 << 2) + threadIdx.x; i < cnt; i += 256) t[i] = s[i];
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += 256) t[i] = s[i];
+    }
+}
+}  // namespace
+
+extern "C" int bsi_copy_batch_tiles(size_t len) { return (int)((len + CPY_TILE - 1) / CPY_TILE); }
+
+extern "C" int bsi_copy_batch_f32(const bsi_copy_desc* descs, int n, int tiles, bsi_stream_t stream) {
+    if (n <= 0 || tiles <= 0) return BSI_OK;
+    if (descs == nullptr) return BSI_EINVAL;
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs, n);
+    BSI_CHECK_LAUNCH("bsi_copy_batch_f32");
+    return BSI_OK;
+}

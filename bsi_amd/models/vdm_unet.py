@@ -122,7 +122,7 @@ class DenoisingVDMUNet(nn.Module):
         return N.UNetConfig(Cc, H, W, a["dim"], a["levels"], a["heads"], ff.n_min if ff is not None else 1,
                             ff.n_max if ff is not None else 0, self.pos_emb.size, a["c_dim"])
 
-    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad", "_grad_buffer")
+    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_plan_g", "_ws", "_last_flat_grad", "_grad_buffer")
 
     def __deepcopy__(self, memo):
         """`copy.deepcopy(model)` (EMA copies, checkpoint tooling) after the model has run: the native caches hold ctypes tables with raw

@@ -664,6 +664,13 @@ int bsi_clip_adamw_ema(float* p, const float* g, float* m, float* v, float* ema,
 typedef struct bsi_seg {
     size_t p_off, g_off, len, my_chunk, out_chunk;
 } bsi_seg;
+/* n fp32 copies (src -> dst, len elements, non-overlapping) in ONE launch: descriptor table in DEVICE memory, tile0 = the sum of
+ * bsi_copy_batch_tiles(len) over the descriptors in front (ascending), tiles = the total.  The UNet backward uses it to put the stacked
+ * FiLM gradients and the shared conv2 / skip bias gradients at their parameters' places in the flat gradient buffer (what autograd's
+ * per-parameter accumulation does for residual_block.py:39,41,63). */
+typedef struct bsi_copy_desc { const float* src; float* dst; size_t len; unsigned tile0, reserved; } bsi_copy_desc;
+int bsi_copy_batch_tiles(size_t len);
+int bsi_copy_batch_f32(const bsi_copy_desc* descs /*device*/, int n, int tiles, bsi_stream_t stream);
 int bsi_sqnorm_segments(const float* g, const bsi_seg* segs, int nseg, size_t nchunks, float* partials, bsi_stream_t stream);
 int bsi_sqnorm_finish(const float* partials, size_t nchunks, float* out_sq, bsi_stream_t stream);
 int bsi_clip_adamw_ema_segments(float* p, const float* g, float* m, float* v, float* ema, const bsi_seg* segs, int nseg,

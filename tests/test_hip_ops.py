@@ -941,6 +941,33 @@ def test_attention_backward_schedules_agree_bit_for_bit(N, B, p):
     assert not bool(diff.any()), (int(diff.sum()), torch.nonzero(diff)[:4].tolist())
 
 
+def test_copy_batch(N):
+    """bsi_copy_batch_f32: many (src, dst, len) jobs in one launch -- lengths below, at and above a tile, not multiples of four,
+    sources and destinations at byte offsets that are not multiples of 16; bytes outside the destinations stay untouched."""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(3)
+    lens = [1, 3, 256, 2047, 2048, 2049, 131072, 5, 70001]
+    src_buf = dev(torch.randn(sum(lens) + 64, generator=gen))
+    dst_buf = torch.full((sum(lens) + 4 * len(lens) + 64,), 7.0, device=DEV)
+    descs, tiles, so, do = (N.CopyDesc * len(lens))(), 0, 1, 3  # element offsets 1 and 3: 4- and 12-byte misalignment
+    jobs = []
+    for i, n in enumerate(lens):
+        s_, d_ = src_buf[so:so + n], dst_buf[do:do + n]
+        descs[i].src, descs[i].dst, descs[i].len, descs[i].tile0 = s_.data_ptr(), d_.data_ptr(), n, tiles
+        tiles += N.lib().bsi_copy_batch_tiles(n)
+        jobs.append((so, do, n))
+        so += n
+        do += n + 4 if i % 2 else n + 1  # gaps, and alignments that differ between source and destination
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(DEV)
+    N.check(N.lib().bsi_copy_batch_f32(N.ptr(table), len(lens), tiles, N.stream()))
+    torch.cuda.synchronize()
+    expect = torch.full_like(dst_buf, 7.0)
+    for so, do, n in jobs:
+        expect[do:do + n] = src_buf[so:so + n]
+    assert torch.equal(dst_buf, expect)
+    N.check(N.lib().bsi_copy_batch_f32(None, 0, 0, N.stream()))  # nothing to do
+
+
 @pytest.mark.parametrize("Bs,tokens,d", [(3, 64, 128), (2, 256, 1024)])
 def test_gate_and_ln_backward(N, Bs, tokens, d):
     gen = torch.Generator().manual_seed(Bs + tokens + d)

@@ -261,30 +261,45 @@ __global__ __launch_bounds__(TPB) void ln_gate_bwd_kernel(
             if constexpr (HAS_GATE) gt[i] = reinterpret_cast<const f32x4*>(gate + (size_t)b * gate_stride)[c];
         }
     }
-    for (int r = 0; r < FRW; ++r) {
-        const int row = row0 + wave * FRW + r;
-        if (row >= M) break;
-        f32x4 xv[VPL], gv[VPL], dxv[VPL], dlv[VPL];
-        float mean = 0.f, rstd = 0.f;
+    // The NEXT row's loads go out before this row's arithmetic (round 5): at 190-210 registers two waves share a SIMD, and with one row
+    // per wave in flight the memory pipe idled while both reduced their rows.  The bf16 operands wait packed (24 registers more).
+    f32x4 nx[VPL], ndx[VPL];
+    u32x2 ng[VPL], ndl[VPL];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](int row) {
         if constexpr (HAS_LN) {
-            mean = stats[2 * (size_t)row];
-            rstd = stats[2 * (size_t)row + 1];
+            nmean = stats[2 * (size_t)row];
+            nrstd = stats[2 * (size_t)row + 1];
         }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = i * 64 + lane;
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            xv[i] = z; gv[i] = z; dxv[i] = z; dlv[i] = z;
+            nx[i] = z; ndx[i] = z; ng[i] = u32x2{0u, 0u}; ndl[i] = u32x2{0u, 0u};
             if (c < d4) {
-                dxv[i] = reinterpret_cast<const f32x4*>(dX + (size_t)row * d)[c];
+                ndx[i] = reinterpret_cast<const f32x4*>(dX + (size_t)row * d)[c];
                 if constexpr (HAS_LN) {
-                    xv[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
-                    gv[i] = bf16x4_to_f32(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d) + c));
+                    nx[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
+                    ng[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(dxn + (size_t)row * d) + c);
                 }
-                if constexpr (HAS_GATE)
-                    dlv[i] = bf16x4_to_f32(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)row * d) + c));
+                if constexpr (HAS_GATE) ndl[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)row * d) + c);
             }
         }
+    };
+    if (row0 + wave * FRW < M) fetch(row0 + wave * FRW);
+    for (int r = 0; r < FRW; ++r) {
+        const int row = row0 + wave * FRW + r;
+        if (row >= M) break;
+        f32x4 xv[VPL], gv[VPL], dxv[VPL], dlv[VPL];
+        const float mean = nmean, rstd = nrstd;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            xv[i] = nx[i];
+            dxv[i] = ndx[i];
+            gv[i] = bf16x4_to_f32(ng[i]);
+            dlv[i] = bf16x4_to_f32(ndl[i]);
+        }
+        if (r + 1 < FRW && row + 1 < M) fetch(row + 1);
         if constexpr (HAS_LN) {
             float s1 = 0.f, s2 = 0.f;
             const unsigned rh = dc.thr ? drop_row(dc, (unsigned)row) : 0u;

@@ -68,6 +68,9 @@ ROUNDS=2 bash tools/experiments/ab.sh "BSI_TRAIN_NO_TN_PAIR=0 STEPS=5" "BSI_TRAI
 for B in 512 64; do NOBIAS=1 B=$B timeout 300 python tools/tn_bench.py 2>&1 | grep -v amdgpu.ids; done > $O/tn_pair_vs_two_launches.txt
 ROUNDS=3 bash tools/experiments/ab.sh "BSI_CONV_ABL=0 B=512" "BSI_CONV_ABL=8192 B=512" -- python tools/unet_bench.py > $O/unet_two_source_slab_e2e_ab.txt 2>&1
 B=256 ABL=0,8192,0,8192 timeout 300 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids > $O/unet_two_source_slab_conv_ab.txt
+# attention backward: wave groups half a trip apart against lock step; the LayerNorm / gate backward at both batch sizes
+bash tools/experiments/attn_bwd_skew_ab.sh 2>&1 | grep -v amdgpu.ids > $O/attn_bwd_skew_ab_final.txt
+for B in 512 64; do B=$B timeout 120 python tools/experiments/ln_gate_bwd_time.py 2>&1 | grep -v amdgpu.ids; done > $O/ln_gate_bwd_time.txt
 # the GPU suite on the final tree: tail with every BOUND / PARITY line
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -90 > $O/gpu_suite_summary.txt; tail -3 $O/gpu_suite_summary.txt
 cp gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null

@@ -17,8 +17,9 @@
 // are fetched into them by LDS-DMA right there (one 1-KB instruction per wave and trip) -- and so are the trip's 1 KB of dropout
 // words; the K tile is only read in the pair's prologue (own K rows + the K^T fragments) and refilled during trip 0; a wave's own V
 // rows come straight from memory into registers (no V tile: its 32 KB hold the two X buffers).  delta = rowsum(dO * O) and the
-// log-sum-exp of the next pair are formed four queries per wave and trip from 8-byte loads.  One barrier per trip; every wait is
-// a counted vmcnt (the issue sequence per trip is fixed; past the last pair the stream re-fetches that pair).
+// log-sum-exp of the next pair are formed four queries per wave and trip from 8-byte loads.  One barrier per trip (lock step) or one
+// per half trip (SKEW, the default since round 5: see the kernel's comment); every wait is a counted vmcnt (the issue sequence per
+// trip is fixed; past the last pair the stream re-fetches that pair).
 #include <cstdlib>
 
 #include "common.h"

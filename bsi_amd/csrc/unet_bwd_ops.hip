@@ -274,6 +274,172 @@ __global__ __launch_bounds__(GN_TPB) void groupnorm_bwd_kernel(const __bf16* __r
     }
 }
 
+// The same with the workgroup's slice RESIDENT in registers (round 5): HW = ROWS x 64 pixel rows (the UNet's 32 x 32 maps: ROWS = 16).
+// Deterministic like the streaming kernel (the partial sums are cut by 64 instead of 32 row classes: other last bits).
+constexpr int GNR_TPB = 512;  // 64 pixel rows in parallel: 16 resident rows per thread at 32 x 32 pixels (with 256 threads and 32 rows hipcc
+                               // schedules itself to 490 registers, or spills at 256)
+template <int ROWS, int CT, int CSRC>  // channels of cat(x1, x2) (= row pitch of dA / add), channels of x1 and of x2 (= their row pitch)
+__global__ __launch_bounds__(GNR_TPB) void groupnorm_bwd_res_kernel(const __bf16* __restrict__ da, const float* __restrict__ x1, int C1,
+                                                             const float* __restrict__ x2, int C2, int HW,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int silu, const float* __restrict__ add,
+                                                             const float* __restrict__ add_b, float* __restrict__ out1,
+                                                             float* __restrict__ out2, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, __bf16* __restrict__ out1_bf, const float* __restrict__ stats,
+                                                             float* __restrict__ partials) {
+    __shared__ float red_s[GNR_TPB * 2], red_q[GNR_TPB * 2];
+    __shared__ float red_g[GNR_TPB * 4], red_b[GNR_TPB * 4];  // [pixel row][channel of the slice]
+    __shared__ float mean_s[16], rstd_s[16], m1_s[16], m2_s[16];
+    constexpr int C = CT, cpg = C / 32;  // (C1 = CSRC, C2 = CT - CSRC: compile-time row pitches keep the 2 x ROWS row addresses out of registers)
+    constexpr int CH4 = GN_CS / 4;
+    const int b = blockIdx.x, t = threadIdx.x, cs0 = blockIdx.y * GN_CS;
+    const int ch = t % CH4, prow = t / CH4, PPI = GNR_TPB / CH4;
+    const int c0 = cs0 + ch * 4, cl = ch * 4;
+    // wave-uniform bases + ONE 32-bit lane offset per stream (a 32-channel slice never straddles x1 | x2): per-lane 64-bit row addresses
+    // (16 rows x 6 streams) were what pushed the allocation past 256 registers
+    const bool second = cs0 >= C1;
+    const float* src = second ? x2 + (size_t)b * HW * C2 + (cs0 - C1) : x1 + (size_t)b * HW * C1 + cs0;
+    const unsigned lo_s = (unsigned)(prow * CSRC + cl), lo_c = (unsigned)(prow * CT + cl);  // element offsets at row pitch CSRC / CT
+    constexpr int sstride = CSRC;
+    const int NS = CH4 * 2;
+    const __bf16* dap = da + (size_t)b * HW * C + cs0;
+    // ---- the slice stays in registers between the passes: ROWS pixel rows of 4 channels per thread (x fp32 + dA bf16 = 6 registers a
+    //      row), every load issued before the first use.  The streaming kernel read x and dA twice, four rows at a time.
+    f32x4 vv[ROWS];
+    u32x2 gv[ROWS];
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+        vv[u] = *reinterpret_cast<const f32x4*>(src + u * PPI * sstride + lo_s);
+        gv[u] = *reinterpret_cast<const u32x2*>(dap + u * PPI * C + lo_c);
+    }
+    // ---- pass 0: statistics (taken from the forward pass when it saved them: one pass over x less)
+    if (stats) {
+        if (t < GN_CS / cpg) {
+            const float* st = stats + ((size_t)b * 32 + cs0 / cpg + t) * 2;
+            mean_s[t] = st[0];
+            rstd_s[t] = st[1];
+        }
+        __syncthreads();
+    } else {
+        {
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const f32x4 v = vv[u];
+                s0 += v[0] + v[1];
+                q0 += v[0] * v[0] + v[1] * v[1];
+                s1 += v[2] + v[3];
+                q1 += v[2] * v[2] + v[3] * v[3];
+            }
+            red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+            red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+        }
+        __syncthreads();
+        if (t < GN_CS / cpg) {
+            const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+            float ts = 0.f, tq = 0.f;
+            for (int r = 0; r < PPI; ++r)
+                for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+            const float n = (float)HW * cpg;
+            const float mean = ts / n;
+            mean_s[t] = mean;
+            rstd_s[t] = 1.0f / sqrtf(fmaxf(tq / n - mean * mean, 0.f) + eps);
+        }
+        __syncthreads();
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = mean_s[(cl + k) / cpg]; rstd[k] = rstd_s[(cl + k) / cpg]; }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    auto dz_of = [&](const f32x4 v, const u32x2 gw, float* nrm, float* dz) {
+        const float g[4] = {__uint_as_float(gw[0] << 16), __uint_as_float(gw[0] & 0xffff0000u), __uint_as_float(gw[1] << 16),
+                            __uint_as_float(gw[1] & 0xffff0000u)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nrm[k] = (v[k] - mean[k]) * rstd[k];
+            dz[k] = silu ? g[k] * silu_grad_f(__fmaf_rn(nrm[k], ga[k], be[k])) : g[k];
+        }
+    };
+    // ---- pass 1: group sums of dn and dn*n, per-channel dgamma / dbeta
+    {
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f, gg[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            float nrm[4], dz[4];
+            dz_of(vv[u], gv[u], nrm, dz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gg[k] = __fmaf_rn(dz[k], nrm[k], gg[k]); gb[k] += dz[k]; }
+            const float d0 = dz[0] * ga[0], d1 = dz[1] * ga[1], d2 = dz[2] * ga[2], d3 = dz[3] * ga[3];
+            s0 += d0 + d1; q0 += d0 * nrm[0] + d1 * nrm[1];
+            s1 += d2 + d3; q1 += d2 * nrm[2] + d3 * nrm[3];
+            if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two rows' arithmetic at a time: interleaving all of them costs > 256 registers
+        }
+        red_s[prow * NS + 2 * ch] = s0; red_q[prow * NS + 2 * ch] = q0;
+        red_s[prow * NS + 2 * ch + 1] = s1; red_q[prow * NS + 2 * ch + 1] = q1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red_g[prow * GN_CS + cl + k] = gg[k]; red_b[prow * GN_CS + cl + k] = gb[k]; }
+    }
+    __syncthreads();
+    if (t < GN_CS / cpg) {
+        const int k0 = t * cpg / 2, k1 = (t + 1) * cpg / 2;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < PPI; ++r)
+            for (int k = k0; k < k1; ++k) { ts += red_s[r * NS + k]; tq += red_q[r * NS + k]; }
+        const float n = (float)HW * cpg;
+        m1_s[t] = ts / n;
+        m2_s[t] = tq / n;
+    }
+    if (t >= 64 && t < 64 + GN_CS) {
+        const int c = t - 64;
+        float a = 0.f, bb = 0.f;
+        for (int r = 0; r < PPI; ++r) { a += red_g[r * GN_CS + c]; bb += red_b[r * GN_CS + c]; }
+        if (partials) {  // [B][2][C] per-image sums, added over the images in fixed order by the launcher: reproducible
+            partials[((size_t)b * 2 + 0) * C + cs0 + c] = a;
+            partials[((size_t)b * 2 + 1) * C + cs0 + c] = bb;
+        } else {
+            atomicAdd(dgamma + cs0 + c, a);
+            atomicAdd(dbeta + cs0 + c, bb);
+        }
+    }
+    __syncthreads();
+    float m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { m1[k] = m1_s[(cl + k) / cpg]; m2[k] = m2_s[(cl + k) / cpg]; }
+    // ---- pass 2: dx
+    float* dst = second ? out2 + (size_t)b * HW * C2 + (cs0 - C1) : out1 + (size_t)b * HW * C1 + cs0;
+    const float* ab = (!second && add_b) ? add_b + (size_t)b * HW * C1 + cs0 : nullptr;
+    const float* aa = add ? add + (size_t)b * HW * C + cs0 : nullptr;
+    __bf16* obf = (out1_bf && !second) ? out1_bf + (size_t)b * HW * CSRC + cs0 : nullptr;
+#pragma unroll
+    for (int u0 = 0; u0 < ROWS; u0 += 4) {
+        f32x4 a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a4[u] = aa ? *reinterpret_cast<const f32x4*>(aa + (u0 + u) * PPI * C + lo_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b4[u] = ab ? *reinterpret_cast<const f32x4*>(ab + (u0 + u) * PPI * CSRC + lo_s) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float nrm[4], dz[4];
+            // opaque to the optimiser: it would otherwise keep pass 1's n and dz of all ROWS rows alive across the barrier (256 registers)
+            asm volatile("" : "+v"(vv[u0 + u]), "+v"(gv[u0 + u]));
+            dz_of(vv[u0 + u], gv[u0 + u], nrm, dz);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (dz[k] * ga[k] - m1[k] - nrm[k] * m2[k]) + a4[u][k] + b4[u][k];
+            *reinterpret_cast<f32x4*>(dst + (u0 + u) * PPI * sstride + lo_s) = o;
+            if (obf) {  // bf16 copy of the x1 gradient: the next block's convolutions take it as their dY operand
+                u32x2 w2;
+                w2[0] = pack_bf16x2(o[0], o[1]);
+                w2[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(obf + (u0 + u) * PPI * CSRC + lo_s) = w2;
+            }
+            if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+
 // Backward of unet_decode_kernel: dY[m, o] = c_out[b] * g_xhat[b, o, pix];  dh[m, :] = sum_o dY[m, o] * w[o, :];
 // dw[o, :] += sum_m dY[m, o] * h[m, :];  db[o] += sum_m dY[m, o].  One workgroup per slab of 256 pixels.
 constexpr int DB_PIX = 256;
@@ -388,8 +554,18 @@ static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const flo
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
-    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
-                       HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats, partials);
+    static const bool streaming = getenv("BSI_GN_BWD_STREAM") != nullptr;  // A/B partner of the resident kernel (bit-identical)
+    if (HW == 1024 && C1 == 128 && C2 == 0 && !streaming)
+        hipLaunchKernelGGL((groupnorm_bwd_res_kernel<16, 128, 128>), dim3(B, C / GN_CS), dim3(GNR_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da),
+                           x1, C1, x2, C2, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16),
+                           stats, partials);
+    else if (HW == 1024 && C1 == 128 && C2 == 128 && !streaming)
+        hipLaunchKernelGGL((groupnorm_bwd_res_kernel<16, 256, 128>), dim3(B, C / GN_CS), dim3(GNR_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da),
+                           x1, C1, x2, C2, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16),
+                           stats, partials);
+    else
+        hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(B, C / GN_CS), dim3(GN_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da), x1, C1, x2, C2,
+                           HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16), stats, partials);
     BSI_CHECK_LAUNCH("bsi_groupnorm_bwd_nhwc");
     if (partials) {  // dgamma / dbeta are WRITTEN: per-image rows summed in image order
         return bsi_reduce_slabs2_launch(partials, (size_t)2 * C, (size_t)C, dgamma, partials + C, (size_t)2 * C, (size_t)C, dbeta, B, 0, S_(stream));

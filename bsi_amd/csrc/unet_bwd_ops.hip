@@ -554,7 +554,9 @@ static int groupnorm_bwd_impl(const void* da, const float* x1, int C1, const flo
     const int C = C1 + C2;
     BSI_CHECK_ARG((C == 128 || C == 256 || C == 64) && C1 % 32 == 0 && C2 % 32 == 0 && (C2 == 0 || (x2 && out2)),
                   "bsi_groupnorm_bwd_nhwc: C1+C2=%d unsupported (64, 128 or 256 channels, 32 groups)", C);
-    static const bool streaming = getenv("BSI_GN_BWD_STREAM") != nullptr;  // A/B partner of the resident kernel (bit-identical)
+    // per launch at 128 images (tools/experiments/gn_bwd_ab.sh): 128 channels 76.6 against 80.6 us streaming, cat(x, skip) with 256 channels 125.1
+    // against 150.8.  BSI_GN_BWD_STREAM=1: the streaming kernel everywhere (the A/B partner; other last bits).
+    static const bool streaming = getenv("BSI_GN_BWD_STREAM") != nullptr;
     if (HW == 1024 && C1 == 128 && C2 == 0 && !streaming)
         hipLaunchKernelGGL((groupnorm_bwd_res_kernel<16, 128, 128>), dim3(B, C / GN_CS), dim3(GNR_TPB), 0, S_(stream), reinterpret_cast<const __bf16*>(da),
                            x1, C1, x2, C2, HW, gamma, beta, eps, silu, add, add_b, out1, out2, dgamma, dbeta, reinterpret_cast<__bf16*>(out1_bf16),

@@ -347,6 +347,12 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
         auto trip = [&](const int t, StatSet& S) {
             const int qc = 32 * t;
             m1(t);
+            // SKEW: the next pair's V rows go out here, behind their last use (this trip's dP MFMAs), a slot and a half earlier than in lock
+            // step: they are waited for at the next pair's first MFMA, and from the matrix slot of trip 7 that was less than the memory
+            // latency under load.  (In issue order they now stand in front of trip 7's dQ store: every counted wait stays equal or stricter.)
+            if constexpr (SKEW && !(ABL & 32)) {
+                if (t == 7) issue_v(nxt);
+            }
             // ---- the transposed Q / dO fragments (for dK / dV): all 16 reads go out together behind the softmax and each group of eight MFMAs
             //      waits only for its own eight.  (The first eight in FRONT of the softmax -- they do not depend on it -- measured 1 % faster
             //      at 16 registers more, which the instances with the bias sums do not have.)
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 WAIT_S(S, 7 + 2 * NM);
                 consume_stats(S, pb ^ 1);
             }
-            if (t == 7) issue_v(nxt);
+            if (!SKEW && t == 7) issue_v(nxt);
             if (!(ABL & 256) && t == 0) issue_k(nxt);  // 256: no LDS-DMA
             if constexpr (!(ABL & 512)) issue_stats(S, nxt, t);  // 512: no statistics loads
             if constexpr (!(ABL & 256)) {

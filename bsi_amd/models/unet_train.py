@@ -68,14 +68,16 @@ def _grad_plan(model, cfg, flat, key):
     for i, pfx in enumerate(names):
         dst += [views[pfx + "project_onto_scale_shift.weight"], views[pfx + "project_onto_scale_shift.bias"]]
         src += [film_w[i * 2 * dim:(i + 1) * 2 * dim], film_b[i * 2 * dim:(i + 1) * 2 * dim]]
-    descs, tiles = (N.CopyDesc * len(dst))(), 0
-    for i, (d, s_) in enumerate(zip(dst, src)):
-        assert d.is_contiguous() and s_.is_contiguous() and d.numel() == s_.numel()
-        descs[i].src, descs[i].dst, descs[i].len, descs[i].tile0 = s_.data_ptr(), d.data_ptr(), d.numel(), tiles
-        tiles += lib.bsi_copy_batch_tiles(d.numel())
-    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
-    return {"key": key, "flat": flat, "views": views, "order": order, "g": g, "arr": arr, "film_w": film_w, "film_b": film_b,
-            "pm1_pad": pm1_pad, "copy_table": table, "copy_n": len(dst), "copy_tiles": tiles}
+    plan = {"key": key, "flat": flat, "views": views, "order": order, "g": g, "arr": arr, "film_w": film_w, "film_b": film_b,
+            "pm1_pad": pm1_pad, "copy_dst": dst, "copy_src": src, "copy_table": None}
+    if key is not None:  # a persistent buffer: the copy jobs go to the device once (the upload is a synchronous host-to-device copy)
+        descs, tiles = (N.CopyDesc * len(dst))(), 0
+        for i, (d, s_) in enumerate(zip(dst, src)):
+            assert d.is_contiguous() and s_.is_contiguous() and d.numel() == s_.numel()
+            descs[i].src, descs[i].dst, descs[i].len, descs[i].tile0 = s_.data_ptr(), d.data_ptr(), d.numel(), tiles
+            tiles += lib.bsi_copy_batch_tiles(d.numel())
+        plan.update(copy_table=torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev), copy_n=len(dst), copy_tiles=tiles)
+    return plan
 
 
 def transposed_pack(model):
@@ -183,8 +185,11 @@ class _UNetTrainFn(torch.autograd.Function):
                                       N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
         ctx.tape = None
         # the stacked FiLM gradients and the shared skip / conv2 bias gradients go to their parameters' places in the flat buffer:
-        # one launch of bsi_copy_batch_f32 instead of 167 (torch._foreach_copy_ issues a hipMemcpyAsync per pair on ROCm)
-        N.check(lib.bsi_copy_batch_f32(N.ptr(plan["copy_table"]), plan["copy_n"], plan["copy_tiles"], N.stream()))
+        # one launch of bsi_copy_batch_f32 instead of 167 when the buffer is the trainer's (torch._foreach_copy_ issues a hipMemcpyAsync per pair on ROCm)
+        if plan["copy_table"] is not None:
+            N.check(lib.bsi_copy_batch_f32(N.ptr(plan["copy_table"]), plan["copy_n"], plan["copy_tiles"], N.stream()))
+        else:  # a fresh gradient buffer per call (plain autograd): no table to upload, no synchronisation
+            torch._foreach_copy_(plan["copy_dst"], plan["copy_src"])
         views["pos_map.1.weight"].copy_(plan["pm1_pad"][:, :views["pos_map.1.weight"].shape[1]])
         model._last_flat_grad = flat
         if getattr(model, "_flat_grad_only", False):

@@ -40,7 +40,7 @@ constexpr int LDS_BYTES = MK + MK_BYTES;              // 159744
 constexpr int BPW = 24 * XP;  // bytes between two waves' partials; float i of wave w: XL + w * BPW + (i >> 3) * XP + 64 + (i & 7) * 4
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 #ifndef ATTN_ABL
-#define ATTN_ABL 0  // timing ablations of tools/experiments/attn_bwd_ablate.sh (wrong results): 1 softmax, 2 dV / dK, 4 dQ, 8 barrier, 16 S / dP, 32 next-pair fetches, 64 X write
+#define ATTN_ABL 0  // timing ablations of tools/experiments/attn_bwd_ablate.sh (wrong results): 1 softmax, 2 dV / dK, 4 dQ, 8 barrier, 16 S / dP, 32 next-pair fetches, 64 X write, 1024 dK / dV stores
 #endif
 constexpr int ABL = ATTN_ABL;
 #ifdef ATTN_NO_BIAS
@@ -518,8 +518,13 @@ __global__ __launch_bounds__(512) void attention_bwd_x_kernel(const __bf16* __re
                 const float vs = DROP == 2 ? dc.scale : 1.0f;
                 wv_[0] = pack_bf16x2(dv[dt][jk][0] * vs, dv[dt][jk][1] * vs);
                 wv_[1] = pack_bf16x2(dv[dt][jk][2] * vs, dv[dt][jk][3] * vs);
-                *reinterpret_cast<u32x2*>(ob + (heads * DH + 16 * dt) * 2 + out_off) = wk_;
-                *reinterpret_cast<u32x2*>(ob + (2 * heads * DH + 16 * dt) * 2 + out_off) = wv_;
+                if constexpr (ABL & 2048) {  // 2048 (timing only): the same bytes as lane-linear 512-B pieces of this wave's rows
+                    *reinterpret_cast<u32x2*>(ob + heads * DH * 2 + (size_t)(4 * dt) * ld_dqkv * 2 + lane * 8) = wk_;
+                    *reinterpret_cast<u32x2*>(ob + 2 * heads * DH * 2 + (size_t)(4 * dt) * ld_dqkv * 2 + lane * 8) = wv_;
+                } else if constexpr (!(ABL & 1024)) {  // 1024: no dK / dV stores
+                    *reinterpret_cast<u32x2*>(ob + (heads * DH + 16 * dt) * 2 + out_off) = wk_;
+                    *reinterpret_cast<u32x2*>(ob + (2 * heads * DH + 16 * dt) * 2 + out_off) = wv_;
+                }
                 if (BIAS_ON) {  // the accumulators are dead now: they carry the stored (rounded) values into the sums over jk below
                     dk[dt][jk] = f32x4{__uint_as_float(wk_[0] << 16), __uint_as_float(wk_[0] & 0xffff0000u), __uint_as_float(wk_[1] << 16),
                                        __uint_as_float(wk_[1] & 0xffff0000u)};

@@ -252,6 +252,11 @@ _PROTOS = {
     "bsi_dit_adaln": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _vp, _i, _vp, _vp, _vp]),
     "bsi_dit_forward": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                              _vp, _vp, _vp, _vp]),
+    "bsi_cu_pair_create": (_i, [_i, C.POINTER(_vp)]),
+    "bsi_cu_pair_destroy": (_i, [_vp]),
+    "bsi_cu_pair_streams": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i)]),
+    "bsi_dit_forward_pair": (_i, [C.POINTER(DitConfig), C.POINTER(DitWeights), _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
+                                  _vp, _vp, _vp, _i, _vp]),
     "bsi_sqnorm_segments": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),
     "bsi_sqnorm_finish": (_i, [_vp, _sz, _vp, _vp]),
     "bsi_copy_batch_tiles": (_i, [_sz]),
@@ -260,6 +265,7 @@ _PROTOS = {
     "bsi_clock_probe": (_i, [_vp, _i, _vp]),
     "bsi_set_cu_reserve": (_i, [_i]),
     "bsi_compute_cus": (_i, []),
+    "bsi_set_ln_stream_cus": (_i, [_i]),
     "bsi_set_tile_queue": (_i, [_i]),
     "bsi_set_attention_bwd_skew": (_i, [_i]),
     "bsi_prof_enable": (_i, [C.c_uint]),

@@ -83,6 +83,9 @@ inline int device_cus() {
 // split counts derived from it) with this: a 160-KB-LDS workgroup that cannot be placed because a communication kernel holds
 // its CU would otherwise start a whole kernel late and double the launch's duration.
 extern int g_bsi_cu_reserve;  // prof.hip
+extern int g_bsi_cu_masked;   // prof.hip: 1 while launches go to a CU-masked stream (bsi_dit_forward_pair): the reserve is then a HARD limit --
+                              // a workgroup beyond compute_cus() cannot be placed beside the others, tile queue or not
+extern int g_bsi_ln_stream_cus;  // prof.hip: > 0 = the LayerNorm passes of the inference engine run as persistent kernels sized for this many CUs
 inline int compute_cus() {
     const int c = device_cus() - g_bsi_cu_reserve;
     return c < 8 ? 8 : c;

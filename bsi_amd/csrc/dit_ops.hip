@@ -156,6 +156,120 @@ __global__ void ln_modulate_kernel(float* __restrict__ x, int M, int d, float ep
     }
 }
 
+// The same pass for a SMALL set of compute units (the H partition of bsi_dit_forward_pair; inference form: one shared modulation
+// row, no dropout, no statistics).  ln_modulate_kernel lives off the chip's occupancy: one row per wave, ~14 us from launch to exit,
+// 24-28 GB/s per CU -- enough for HBM with 256 CUs, not with 16-32.  Here the workgroups are PERSISTENT (one grid-stride walk over the
+// rows), every wave keeps the NEXT row's loads in flight while it reduces and stores the current one (two register sets, the
+// loop unrolled by two so that no move ever waits for a load), and the four modulation vectors are read once per workgroup into LDS
+// instead of once per row through the vector L1 (16 KB per 12-KB row).  Arithmetic, operand order and rounding are those of
+// ln_modulate_kernel: results are bit-identical.
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_modulate_stream_kernel(float* __restrict__ x, int M, int d, float eps, const float* __restrict__ shift,
+                                                                 const float* __restrict__ scale, const __bf16* delta0,
+                                                                 const float* __restrict__ gate0, const __bf16* delta,
+                                                                 const float* __restrict__ gate, int write_x, __bf16* out) {
+    __shared__ f32x4 tab[4][VPL * 64];  // gate0, gate, shift, scale
+    const int d4 = d >> 2;
+    for (int i = threadIdx.x; i < VPL * 64; i += blockDim.x) {
+        const f32x4 z{0.f, 0.f, 0.f, 0.f};
+        const bool in = i < d4;
+        tab[0][i] = (gate0 && in) ? reinterpret_cast<const f32x4*>(gate0)[i] : z;
+        tab[1][i] = (gate && in) ? reinterpret_cast<const f32x4*>(gate)[i] : z;
+        tab[2][i] = in ? reinterpret_cast<const f32x4*>(shift)[i] : z;
+        tab[3][i] = in ? reinterpret_cast<const f32x4*>(scale)[i] : z;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int stride = gridDim.x * wpb;
+    int row = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const bool has0 = delta0 != nullptr, has1 = delta != nullptr;
+
+    struct Row {
+        f32x4 v[VPL];
+        u32x2 a[VPL], b[VPL];
+    };
+    auto load = [&](int r, Row& R) {
+        const float* xr = x + (size_t)r * d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            R.v[i] = (c < d4) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has0 && c < d4) R.a[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta0 + (size_t)r * d) + c);
+            if (has1 && c < d4) R.b[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(delta + (size_t)r * d) + c);
+        }
+    };
+    auto finish = [&](int r, Row& R) {
+        float* xw = x + (size_t)r * d;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (has0 && c < d4) {
+                const f32x4 g = tab[0][c];
+                R.v[i][0] = __fmaf_rn(g[0], __uint_as_float(R.a[i][0] << 16), R.v[i][0]);
+                R.v[i][1] = __fmaf_rn(g[1], __uint_as_float(R.a[i][0] & 0xffff0000u), R.v[i][1]);
+                R.v[i][2] = __fmaf_rn(g[2], __uint_as_float(R.a[i][1] << 16), R.v[i][2]);
+                R.v[i][3] = __fmaf_rn(g[3], __uint_as_float(R.a[i][1] & 0xffff0000u), R.v[i][3]);
+            }
+            if (has1 && c < d4) {
+                const f32x4 g = tab[1][c];
+                R.v[i][0] = __fmaf_rn(g[0], __uint_as_float(R.b[i][0] << 16), R.v[i][0]);
+                R.v[i][1] = __fmaf_rn(g[1], __uint_as_float(R.b[i][0] & 0xffff0000u), R.v[i][1]);
+                R.v[i][2] = __fmaf_rn(g[2], __uint_as_float(R.b[i][1] << 16), R.v[i][2]);
+                R.v[i][3] = __fmaf_rn(g[3], __uint_as_float(R.b[i][1] & 0xffff0000u), R.v[i][3]);
+                if (write_x) reinterpret_cast<f32x4*>(xw)[c] = R.v[i];
+            }
+            s += (R.v[i][0] + R.v[i][1]) + (R.v[i][2] + R.v[i][3]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = R.v[i][k] - mean;
+                    q = __fmaf_rn(dd, dd, q);
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+        __bf16* orow = out + (size_t)r * d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                f32x4 y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = (R.v[i][k] - mean) * rstd;
+                const f32x4 a = tab[2][c];
+                const f32x4 b = tab[3][c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = __fmaf_rn(b[k] + 1.0f, y[k], a[k]);
+                u32x2 w;
+                w[0] = pack_bf16x2(y[0], y[1]);
+                w[1] = pack_bf16x2(y[2], y[3]);
+                reinterpret_cast<u32x2*>(orow)[c] = w;
+            }
+        }
+    };
+    Row A, B;
+    if (row >= M) return;
+    load(row, A);
+    while (true) {
+        if (row + stride < M) load(row + stride, B);
+        finish(row, A);
+        row += stride;
+        if (row >= M) break;
+        if (row + stride < M) load(row + stride, A);
+        finish(row, B);
+        row += stride;
+        if (row >= M) break;
+    }
+}
+
 // fourier_features.py:21-36 standalone: x [outer, C, inner] -> out [outer, C*nfreq*2, inner],
 // channel (c*nfreq + n)*2 + o holds sin(offset_o + coef_n * x[c]).
 __global__ void fourier_features_kernel(const float* __restrict__ x, size_t total, int C, int inner, int nmin,
@@ -429,6 +543,24 @@ int bsi_resid_ln_modulate_drop(float* x, int M, int d, float eps, const void* de
     dim3 grid((M + wpb - 1) / wpb);
     __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
     const __bf16* dl = reinterpret_cast<const __bf16*>(delta);
+    // inference passes on a small CU partition (bsi_dit_forward_pair's H stream; g_bsi_ln_stream_cus = its size): the persistent,
+    // prefetching form -- bit-identical, several times the bytes per CU
+    if (g_bsi_ln_stream_cus > 0 && d > 256 && d <= 1024 && shift && o && mod_rows == 1 && !ln_w && !dc.thr && !x_out && !stats &&
+        !(maskw && mdc.thr)) {
+        static int per_cu = 0;
+        if (per_cu == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ln_modulate_stream_kernel<4>, TPB, 0) != hipSuccess || n < 1) n = 2;
+            if (const char* e = getenv("BSI_LN_STREAM_WGS")) n = atoi(e) > 0 ? atoi(e) : n;
+            per_cu = n;
+        }
+        int g = g_bsi_ln_stream_cus * per_cu;
+        if (g > (int)grid.x) g = (int)grid.x;
+        hipLaunchKernelGGL(ln_modulate_stream_kernel<4>, dim3(g), dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, dl0, gate0, dl,
+                           gate, write_x, o);
+        BSI_CHECK_LAUNCH("bsi_resid_ln_modulate");
+        return BSI_OK;
+    }
     if (d <= 256)
         hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, dim3(TPB), 0, S(stream), x, M, d, eps, shift, scale, mod_rows,
                            mod_stride, tokens, ln_w, ln_b, dl, gate, o, dc, x_out, stats, dl0, gate0, write_x);

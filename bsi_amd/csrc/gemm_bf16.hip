@@ -1223,7 +1223,9 @@ int launch_k64r(const GemmParams& p0, hipStream_t s) {
     const size_t lds = 5 * (size_t)256 * 128;
     // tile queue (bsi_set_tile_queue): worth it when workgroups take more than one tile, possible when the ticket pipeline fits
     // into a tile (K >= 512); the grid then spans ALL CUs -- the queue, not a reserve, absorbs CUs that are busy elsewhere
-    const int all = device_cus() < BSI_TQ_MAX_WG ? device_cus() : BSI_TQ_MAX_WG;
+    // (on a CU-masked stream the masked-out CUs are not "busy elsewhere" but unreachable: the grid is the partition's size)
+    const int avail = g_bsi_cu_masked ? compute_cus() : device_cus();
+    const int all = avail < BSI_TQ_MAX_WG ? avail : BSI_TQ_MAX_WG;
     p.queue = (nwg > all && p.K >= 512) ? bsi_tile_queue_block(s) : nullptr;
 #ifdef BSI_LAB
     unsigned*& lab_block = g_lab_static_block;  // laboratory build: the static schedule stamps into a block of its own

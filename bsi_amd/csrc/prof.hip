@@ -30,6 +30,11 @@ hipEvent_t get_event() {
 }  // namespace
 
 int g_bsi_cu_reserve = 0;  // see compute_cus(), common.h
+int g_bsi_cu_masked = 0;
+int g_bsi_ln_stream_cus = [] {
+    const char* e = getenv("BSI_LN_STREAM_CUS");  // experiments: the persistent LayerNorm pass on the whole chip (256) or a part of it
+    return e ? atoi(e) : 0;
+}();
 
 extern "C" int bsi_set_cu_reserve(int cus) {
     BSI_CHECK_ARG(cus >= 0 && cus % 8 == 0 && cus <= BSI_MAX_CU_RESERVE,
@@ -40,6 +45,12 @@ extern "C" int bsi_set_cu_reserve(int cus) {
 }
 
 extern "C" int bsi_compute_cus(void) { return compute_cus(); }
+
+extern "C" int bsi_set_ln_stream_cus(int cus) {
+    BSI_CHECK_ARG(cus >= 0 && cus <= 1024, "bsi_set_ln_stream_cus: %d is not in [0, 1024]", cus);
+    g_bsi_ln_stream_cus = cus;
+    return BSI_OK;
+}
 
 // ---- tile queue control blocks (common.h) --------------------------------------------------------------------------------------
 int g_bsi_tile_queue = [] {

@@ -16,6 +16,34 @@ from ..nn import FourierFeatures
 from .pos_emb import NyquistPositionalEmbedding
 
 
+# ---- CU-partitioned stream pair (bsi_dit_forward_pair, include/bsi_hip.h) ---------------------------------------------------------
+# One pair per (device, h_cus), created on first use and kept for the life of the process (two HIP streams + an event ring).
+_PAIRS: dict = {}
+PAIR_MIN_BATCH = 64  # below this the GEMMs no longer fill the large partition with whole tiles: one chain on the caller's stream
+
+
+def _pair_default():
+    """(h_cus, flags) from BSI_CU_PAIR="<h_cus>[,attn_h]", or None (one stream).  Read per call: experiments flip it."""
+    import os
+    e = os.environ.get("BSI_CU_PAIR", "")
+    if not e or e == "0":
+        return None
+    parts = e.split(",")
+    return int(parts[0]), (1 if len(parts) > 1 and parts[1] == "attn_h" else 0)
+
+
+def cu_pair_handle(device, h_cus: int):
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, h_cus)
+    if key not in _PAIRS:
+        h = C.c_void_p()
+        with torch.cuda.device(idx):
+            N.check(N.lib().bsi_cu_pair_create(h_cus, C.byref(h)))
+        _PAIRS[key] = h
+    return _PAIRS[key]
+
+
 class Attention(nn.Module):
     """Parameter holder for dit.py:26-47 (`to_qkv`, `to_out`); rows of to_qkv are ordered (qkv, head, channel)."""
 
@@ -99,6 +127,7 @@ class DenoisingDiT(nn.Module):
         self._pack_t = None     # cached transposed shadows (training)
         self._pack_t_key = None
         self._plan = None       # persistent shadow buffers + descriptor table of the one-launch cast
+        self.cu_pair = "env"    # (h_cus, flags) | None | "env" (= BSI_CU_PAIR): two CU-masked streams for large inference batches
 
     # ------------------------------------------------------------------------------------------------
     # native plumbing
@@ -262,9 +291,16 @@ class DenoisingDiT(nn.Module):
         tokens = None
         if return_tokens:
             tokens = torch.empty((B * lib.bsi_dit_tokens(C.byref(cfg)), cfg.dim), dtype=torch.float32, device=mu.device)
-        N.check(lib.bsi_dit_forward(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(mod), mod.shape[0],
-                                    N.ptr(c_in), N.ptr(c_skip), N.ptr(c_out), coef_stride, N.ptr(out), N.ptr(ws),
-                                    N.ptr(tokens), N.stream()))
+        pair = _pair_default() if self.cu_pair == "env" else self.cu_pair
+        if pair is not None and not return_tokens and B >= PAIR_MIN_BATCH and not torch.cuda.is_current_stream_capturing():
+            # two half-batch chains over a G/H pair of CU-masked streams; bit-identical to the one-stream call
+            N.check(lib.bsi_dit_forward_pair(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(mod), mod.shape[0],
+                                             N.ptr(c_in), N.ptr(c_skip), N.ptr(c_out), coef_stride, N.ptr(out), N.ptr(ws),
+                                             cu_pair_handle(mu.device, pair[0]), pair[1], N.stream()))
+        else:
+            N.check(lib.bsi_dit_forward(C.byref(cfg), C.byref(w), B, N.ptr(mu), N.ptr(mod), mod.shape[0],
+                                        N.ptr(c_in), N.ptr(c_skip), N.ptr(c_out), coef_stride, N.ptr(out), N.ptr(ws),
+                                        N.ptr(tokens), N.stream()))
         return (out, tokens) if return_tokens else out
 
     def forward_train(self, mu: Tensor, t: Tensor, c_in=None, c_skip=None, c_out=None) -> Tensor:

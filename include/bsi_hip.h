@@ -384,6 +384,23 @@ int bsi_dit_forward(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/
                     const float* mod, int mod_rows, const float* c_in, const float* c_skip, const float* c_out,
                     int coef_stride, float* out, void* workspace, float* tokens_out, bsi_stream_t stream);
 
+/* Two-resource evaluation: the same result as bsi_dit_forward (bit for bit: every row's arithmetic is independent of the batch it
+ * is launched in), with the batch split into two halves whose launches are interleaved over a PAIR of CU-masked streams
+ * (hipExtStreamCreateWithCUMask): the matrix-pipe-bound launches (GEMMs, attention) on the large partition G, the HBM-bound ones
+ * (prologue, LayerNorm+modulate passes, final kernel) of the OTHER half on the small partition H (h_cus compute units, a multiple
+ * of 8 = the same number on every XCD), handed over by events.  While G multiplies for one half, H streams for the other: the loop
+ * of bsi.py:312-336 / dit.py:96-103 no longer alternates between an idle memory system and idle matrix pipes.  The caller's stream
+ * forks into the pair at entry and joins at exit; workspace: bsi_dit_workspace_bytes(cfg, B) bytes as for bsi_dit_forward.
+ * flags: BSI_PAIR_ATTN_ON_H = attention launches on H instead of G. */
+typedef struct bsi_cu_pair bsi_cu_pair;
+#define BSI_PAIR_ATTN_ON_H 1
+int bsi_cu_pair_create(int h_cus, bsi_cu_pair** pair);
+int bsi_cu_pair_destroy(bsi_cu_pair* pair);
+int bsi_cu_pair_streams(const bsi_cu_pair* pair, bsi_stream_t* g, bsi_stream_t* h, int* h_cus);
+int bsi_dit_forward_pair(const bsi_dit_config* cfg, const bsi_dit_weights* w /*host*/, int B, const float* mu,
+                         const float* mod, int mod_rows, const float* c_in, const float* c_skip, const float* c_out,
+                         int coef_stride, float* out, void* workspace, bsi_cu_pair* pair, int flags, bsi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * VDM-UNet building blocks — bsi/models/vdm_unet.py, bsi/nn/residual_block.py, bsi/nn/attention.py.
  * Activations are NHWC: [B*H*W pixels][channels].
@@ -693,6 +710,11 @@ enum {
 #define BSI_MAX_CU_RESERVE 64
 int bsi_set_cu_reserve(int cus);
 int bsi_compute_cus(void);
+/* LayerNorm + modulate passes of the inference engine (one shared modulation row, no dropout): cus > 0 = launch them as PERSISTENT
+ * kernels sized for `cus` compute units (every wave prefetches its next row; modulation vectors in LDS), the form
+ * bsi_dit_forward_pair uses on its small partition; 0 (default; env BSI_LN_STREAM_CUS) = one row per wave over the whole chip.
+ * Bit-identical results.  Process-wide, takes effect at the next launch. */
+int bsi_set_ln_stream_cus(int cus);
 /* Tile queue of the persistent bf16 GEMM (K >= 512, more tiles than CUs): 1 = workgroups draw tile tickets from per-XCD counters in
  * device memory (and from the other XCDs' once their own is empty) instead of taking a static share, and the grid ignores the CU
  * reserve: a workgroup whose CU is held by a kernel of another stream leaves its share to the others, and no CU idles while RCCL

@@ -227,9 +227,9 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
 
     N > 1: the step is measured in three variants so that the first hardware run can be read -- all-reduce with the CU reserve off,
     all-reduce with `--cu-reserve` CUs left to RCCL during the backward, and the sharded step (reduce-scatter / slice update /
-    all-gather) -- each with the same steps without the exchange (exposed communication = the difference); `value` is the fastest
-    variant (they end in bit-identical parameters), named in `headline_variant`.  Plus the bus bandwidth of one 80 MB bucket all-reduced in isolation and the
-    RCCL channel cap in force."""
+    all-gather) -- each with the same steps without the exchange (exposed communication = the difference); `value` is the
+    all-reduce step with the reserve off (the DDP-equivalent one), the others stand beside it in `variants` and `fastest_variant`
+    names the quickest.  Plus the bus bandwidth of one 80 MB bucket all-reduced in isolation and the RCCL channel cap in force."""
     from bsi_amd.dp import DPTrainer, split_batch, warmup_cosine_lr
 
     nb = split_batch(a.train_batch, world, rank)
@@ -246,7 +246,9 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
     variants = [("allreduce", dict(cu_reserve=0))]
     if world > 1:
         if a.cu_reserve:
-            variants.append((f"allreduce_cu_reserve_{a.cu_reserve}", dict(cu_reserve=a.cu_reserve)))
+            # (the reserve variant also switches the tile queue on -- off by default in DPTrainer until a run like this one has
+            # exercised it beside real RCCL kernels; DPTrainer self-checks it against the static schedule first)
+            variants.append((f"allreduce_cu_reserve_{a.cu_reserve}", dict(cu_reserve=a.cu_reserve, tile_queue=True)))
         variants.append(("sharded_update", dict(cu_reserve=0, shard_update=True)))
     runs, comm_runs = {}, {}
     for i, (name, kw) in enumerate(variants):
@@ -269,8 +271,12 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
                 raise
             runs[name] = comm_runs[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
-    # the fastest variant that ran: all three end in bit-identical parameters (tests/test_dp_host.py), so any of them is the step
-    head = min((n for n in runs if "error" not in runs[n]), key=lambda n: runs[n]["ms_per_step"])
+    # Headline = the DDP-equivalent step (bucketed all-reduce, every rank applies the whole update, the EMA complete on every rank
+    # after every step: bsi/tasks/bsi.py:163-198).  The other variants are reported beside it under `variants`, never as `value`:
+    # the sharded step leaves each rank's EMA copy complete only on the slices it owns until gather_ema() runs, and beyond two
+    # ranks a reduce-scatter sums in another ring order than an all-reduce (equal to rounding, not to the bit).
+    head = "allreduce"
+    fastest = min((n for n in runs if "error" not in runs[n]), key=lambda n: runs[n]["ms_per_step"])
     ms = runs[head]["ms_per_step"]
     comm = None
     if world > 1:
@@ -294,7 +300,7 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
                 for key, r_ in (("", 0), ("_cu_reserve", a.cu_reserve)):
                     if key and not r_:
                         continue
-                    tr = DPTrainer(bsi, **recipe, cu_reserve=r_, rehearse=(w_, 0), shard_update=True)
+                    tr = DPTrainer(bsi, **recipe, cu_reserve=r_, tile_queue=bool(r_), rehearse=(w_, 0), shard_update=True)
                     tr.train_step(xs, g)
                     n_ = max(3, min(a.train_steps, 5))
                     dt_, st_, _ = _timed_train(tr, xs, g, n_, barrier, dev, 1)
@@ -312,6 +318,7 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
     steps_per_s = 1e3 / ms
     return {"comm": comm, "metric": "train steps/s (DiT-L/2, global batch %d, fwd+bwd+gradient exchange+clip+AdamW+EMA, dropout 0.05)" % a.train_batch,
             "value": steps_per_s, "unit": "steps/s", "ms_per_step": ms, "global_batch": a.train_batch, "headline_variant": head,
+            "fastest_variant": fastest,
             "per_gpu_batch": nb, "images_per_s": steps_per_s * a.train_batch, "scaling": "strong",
             "model_tflops_per_gpu": steps_per_s * a.train_batch * 3 * FWD_GFLOP_PER_IMG / 1e3 / world,
             "fwd_bwd_exchange_ms": runs[head]["fwd_bwd_exchange_ms"], "optimizer_ms": runs[head]["optimizer_ms"],
@@ -521,6 +528,10 @@ def summary(line):
     pr = tr.get("per_rank_workloads_on_one_gpu")
     out = {"sample_images_per_s": r2(line.get("value")), "sample_frac_of_peak": r2(line.get("model_frac_of_peak")),
            "fc1_roofline_frac": round(get(line, "roofline", "frac") or 0, 3), "n_gpus": line.get("n_gpus"),
+           # box yardstick (register-only random-operand bf16 MFMA stream, GPU otherwise idle) and the model's rate as a share of it
+           "mfma_probe_tflops": r2(get(line, "box_probe", "tflops")), "mfma_probe_mhz": r2(get(line, "box_probe", "mhz")),
+           "sample_tflops_per_probe_tflops": round((line.get("model_tflops_per_gpu") or 0) / get(line, "box_probe", "tflops"), 4)
+           if get(line, "box_probe", "tflops") else None,
            "train_steps_per_s": r2(tr.get("value")), "train_ms_per_step": r2(tr.get("ms_per_step")),
            "train_frac_of_peak": r2((tr.get("model_tflops_per_gpu") or 0) / PEAK_BF16_TFLOPS) if tr.get("value") else None,
            "train_optimizer_ms": r2(tr.get("optimizer_ms")), "train_error": tr.get("error"),
@@ -648,6 +659,16 @@ def main():
         with torch.no_grad():
             return bsi.sample(a.batch, gen)
 
+    # Box yardstick (GPU otherwise idle, before anything is timed): a register-only random-operand bf16 MFMA stream on every CU, twice
+    # 50 ms -- the second run is the reported one (the first takes the clock from idle to its power-limited state).  Boxes of the pool
+    # differ by a few per cent in what they sustain; `value` / probe is comparable across boxes and rounds, `value` alone is not.
+    probe = None
+    try:
+        N.mfma_probe(50000, dev)
+        probe = N.mfma_probe(50000, dev)
+    except Exception as e:  # noqa: BLE001  (a yardstick must never cost the measurement)
+        probe = {"error": f"{type(e).__name__}: {e}"}
+
     for _ in range(a.warmup):
         step()
     N.prof_enable(["gemm_fc1"])
@@ -685,6 +706,7 @@ def main():
                                    "random-init weights",
                        "images_per_gpu": a.batch, "k": a.k, "parallelism": f"independent chains x{n_gpus}",
                        **({"test_hook": "BSI_BENCH_ONE_DEVICE: all ranks on one GPU over gloo -- not a multi-GPU measurement"} if ONE_DEVICE else {})},
+            "box_probe": probe,
             "model_tflops_per_gpu": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3,
             "model_frac_of_peak": value / n_gpus * (a.k + 1) * FWD_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -268,6 +268,8 @@ _PROTOS = {
     "bsi_set_ln_stream_cus": (_i, [_i]),
     "bsi_set_tile_queue": (_i, [_i]),
     "bsi_set_attention_bwd_skew": (_i, [_i]),
+    "bsi_mfma_probe_workspace_bytes": (_sz, []),
+    "bsi_mfma_probe": (_i, [_i, _vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _vp]),
     "bsi_prof_enable": (_i, [C.c_uint]),
     "bsi_prof_read": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
@@ -280,6 +282,19 @@ PROF_CLASSES = {"gemm_qkv": 0, "gemm_out": 1, "gemm_fc1": 2, "gemm_fc2": 3, "att
 def fc1_kernel_name():
     """Name (as rocprofv3 prints it) of the kernel the DiT engine launches for fc1 = the benchmark's dominant kernel."""
     return "gemm_bf16_k64r_kernel<BSI_EPI_BIAS_GELU_BF16=2, DYN=false> (fc1)"
+
+
+def mfma_probe(iters=50000, device=None):
+    """Run the box yardstick (bsi_mfma_probe) on the current stream and wait for it: {"tflops", "mhz", "ms"}."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ws = torch.zeros(lib().bsi_mfma_probe_workspace_bytes() // 8, dtype=torch.int64, device=dev)
+    nwg, flop = C.c_int(0), C.c_double(0.0)
+    check(lib().bsi_mfma_probe(iters, ptr(ws), C.byref(nwg), C.byref(flop), stream()))
+    torch.cuda.synchronize(dev)
+    w = ws[: 4 * 8 * nwg.value].reshape(nwg.value * 8, 4).cpu()
+    ticks = float(int(w[:, 3].max()) - int(w[:, 2].min()))  # first wave in to last wave out, on the chip-wide 100 MHz counter
+    return {"tflops": nwg.value * flop.value / (ticks * 1e-8) / 1e12, "mhz": float((100.0 * w[:, 0].double() / w[:, 1].double()).mean()),
+            "ms": ticks * 1e-5, "iters": iters}
 
 
 def prof_enable(names=()):

@@ -320,6 +320,8 @@ class BSI(nn.Module):
         mu = self._sample_q_mu_lambda(x, lambda_, generator)
         t, rpdf = self._lambda_to_t(lambda_)
         x_hat = self._predict_x(mu, t)
+        if rpdf.numel() == 1 and len(x) > 1:  # plain sampling (bsi.py:441-445): row 0 of the (batch, 1) grid is ONE lambda for the batch
+            rpdf = rpdf.expand(len(x)).contiguous()
         return _SqErr.apply(x, x_hat, rpdf, 1.0, True)
 
     # -- sampling (bsi.py:312-373) -------------------------------------------------------------------
@@ -482,6 +484,9 @@ class BSI(nn.Module):
 
     # -- pieces (bsi.py:375-445) ---------------------------------------------------------------------
     def _predict_x(self, mu: Tensor, t: Tensor) -> Tensor:
+        if t.ndim == 1 and t.numel() == 1 and mu.shape[0] > 1:
+            # one time for the whole batch: the reference's coefficient / embedding broadcasting (bsi.py:381-386, dit.py:177)
+            t = t.expand(mu.shape[0]).contiguous()
         if self.preconditioning is None:
             return self.model(mu, t)
         elif self.preconditioning == "edm":
@@ -521,6 +526,13 @@ class BSI(nn.Module):
         x = x.contiguous()
         lambda_ = lambda_.to(torch.float32).contiguous()
         eps = torch.randn((*lambda_.shape, *self.data_shape), **self.tensor_args, generator=generator)
+        # The reference broadcasts lambda [..., batch] against x[None, ..., batch] (bsi.py:411-419).  Every caller of the
+        # low-discrepancy branch passes [..., batch] itself; the plain branch's transposed grid (bsi.py:441-445) can pass ONE lambda
+        # (train_loss) -- then lambda and its ONE noise image are shared by the batch, as there.  Shapes torch cannot broadcast raise.
+        lead = torch.broadcast_shapes(tuple(lambda_.shape), (1,) * max(lambda_.ndim - 1, 0) + (len(x),))
+        if tuple(lead) != tuple(lambda_.shape):
+            eps = eps.expand(*lead, *self.data_shape).contiguous()
+            lambda_ = lambda_.expand(lead).contiguous()
         mu = torch.empty_like(eps)
         N.check(N.lib().bsi_q_sample(self._p(), N.ptr(x), N.ptr(lambda_), N.ptr(eps), lambda_.numel(), len(x),
                                      self._D, N.ptr(mu), N.stream()))

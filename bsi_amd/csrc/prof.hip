@@ -87,14 +87,15 @@ unsigned* bsi_tile_queue_block(hipStream_t s) {
     if (!g_bsi_tile_queue) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_DEVICES) return nullptr;
+    // A launch that is being CAPTURED takes the static schedule, always: a graph would bake this stream's control block into its
+    // kernel node and share its ticket counters with whatever stream the graph is replayed on, concurrently with eager launches.
+    // (The pool is also allocated and zeroed synchronously at the first launch that wants it, which cannot happen inside a capture.)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
     std::lock_guard<std::mutex> lk(g_tq_mu);
     TqPool& pl = g_tq[dev];
     if (!pl.base) {
         if (pl.failed) return nullptr;
-        // the pool is allocated (and zeroed, synchronously) at the first launch that wants it; that cannot happen inside a stream
-        // capture -- such a launch, and every launch after a failure, takes the static schedule
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
         void* mem = nullptr;
         const size_t bytes = (size_t)TQ_STREAMS * BSI_TQ_WORDS * sizeof(unsigned);
         if (hipMalloc(&mem, bytes) != hipSuccess || hipMemset(mem, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -177,5 +178,71 @@ extern "C" int bsi_clock_probe(unsigned long long* out /*device, 2 words*/, int 
     BSI_CHECK_ARG(out && us > 0 && us <= 100000, "bsi_clock_probe: bad args");
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out, (unsigned)us * 100u);
     BSI_CHECK_LAUNCH("bsi_clock_probe");
+    return BSI_OK;
+}
+
+// Box yardstick for the benchmark line (bench.py `summary.mfma_probe_*`): what THIS GPU sustains on a register-only stream of
+// v_mfma_f32_16x16x32_bf16 with random operands -- the instruction mix of the engine's GEMMs without LDS, memory or barriers
+// (tools/experiments/mfma_power.hip shape 0: 2.03 PFLOP/s at 1.9-1.95 GHz on the boxes of round 3).  The chip is power limited under
+// this load, and boxes of the pool differ by a few per cent: headline / probe is comparable across boxes, the headline alone is not.
+namespace {
+__global__ __launch_bounds__(512, 1) void mfma_probe_kernel(int iters, unsigned long long* __restrict__ clk, float* __restrict__ sink) {
+    const unsigned t = threadIdx.x + 512u * blockIdx.x;
+    bf16x8 a[2][8], b[2][4];
+    auto rnd = [&](unsigned k) {  // a bf16x8 of hashed values in [-1, 1)
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned h = (t * 0x9E3779B1u) ^ ((k * 8u + e) * 0x85EBCA77u);
+            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+            v[e] = (__bf16)((float)(int)h * (1.0f / 2147483648.0f));
+        }
+        return v;
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[s][i] = rnd(s * 12 + i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[s][i] = rnd(s * 12 + 8 + i);
+    }
+    f32x4 acc[8][4] = {};
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    if (r == 12345.678f) sink[0] = r;  // keeps the arithmetic alive
+    if ((threadIdx.x & 63) == 0) {  // per WAVE: the two waves of a SIMD take turns rather than interleave, so one wave's span is not the kernel's
+        unsigned long long* w = clk + 4 * (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6));
+        w[0] = c1 - c0;
+        w[1] = r1 - r0;
+        w[2] = r0;
+        w[3] = r1;
+    }
+}
+}  // namespace
+
+extern "C" size_t bsi_mfma_probe_workspace_bytes(void) { return (size_t)(4 * 8 * 1024 + 2) * sizeof(unsigned long long); }
+
+extern "C" int bsi_mfma_probe(int iters, void* workspace, int* workgroups, double* flop_per_workgroup, bsi_stream_t stream) {
+    BSI_CHECK_ARG(iters > 0 && iters <= 2000000 && workspace && workgroups && flop_per_workgroup, "bsi_mfma_probe: bad args");
+    const int grid = device_cus() < 1024 ? device_cus() : 1024;
+    unsigned long long* clk = reinterpret_cast<unsigned long long*>(workspace);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), iters, clk,
+                       reinterpret_cast<float*>(clk + 4 * 8 * 1024));
+    BSI_CHECK_LAUNCH("bsi_mfma_probe");
+    *workgroups = grid;
+    *flop_per_workgroup = 8.0 * iters * 64.0 * (2.0 * 16 * 16 * 32);  // 8 waves x iters x 64 MFMAs x 2*16*16*32
     return BSI_OK;
 }

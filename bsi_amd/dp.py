@@ -206,6 +206,41 @@ def _check_reserve(r):
     return r
 
 
+_TQ_CHECKED = {}
+
+
+def tile_queue_self_check(device) -> bool:
+    """One GEMM of the shape class the tile queue serves (K >= 512, more 256 x 256 tiles than CUs) with tickets against the static
+    schedule, bit for bit; cached per device.  Leaves the queue switch as it found it (off)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _TQ_CHECKED:
+        return _TQ_CHECKED[key]
+    lib = N.lib()
+    with torch.cuda.device(key):
+        g = torch.Generator(dev).manual_seed(7)
+        M, Nn, K = 256 * 45, 256 * 13, 512  # 585 tiles, ragged over the 8 XCDs
+        a = torch.randn((M, K), device=dev, generator=g).bfloat16()
+        w = torch.randn((Nn, K), device=dev, generator=g).bfloat16()
+        bias = torch.randn(Nn, device=dev, generator=g)
+        outs = []
+        for q in (0, 1, 1):
+            o = torch.zeros((M, Nn), dtype=torch.bfloat16, device=dev)
+            ga = N.GemmArgs()
+            ga.A, ga.W, ga.bias, ga.out = a.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr()
+            ga.M, ga.N, ga.K, ga.lda, ga.ldw, ga.ldo, ga.epilogue = M, Nn, K, K, K, Nn, N.EPI_BIAS_BF16
+            N.check(lib.bsi_set_tile_queue(q))
+            try:
+                N.check(lib.bsi_gemm_bf16(C.byref(ga), N.stream()))
+            finally:
+                N.check(lib.bsi_set_tile_queue(0))
+            outs.append(o)
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]))
+    _TQ_CHECKED[key] = ok
+    return ok
+
+
 class DPTrainer:
     """Native data-parallel train step around a `bsi_amd.BSI` whose model is a `bsi_amd.models.dit.DenoisingDiT` (per-block
     gradient buckets overlapped with the backward) or a `bsi_amd.models.vdm_unet.DenoisingVDMUNet` (28 M parameters: one
@@ -215,9 +250,10 @@ class DPTrainer:
     `DistributedDataParallel` does (bsi/tasks/bsi.py:165): ranks that were seeded differently still train ONE model.
 
     shard_update=True: the step is reduce-scatter -> clip + AdamW + EMA on this rank's 1/world slice of every bucket -> all-gather
-    of the updated parameters (identical parameters to the all-reduce step: same sums, same per-chunk norm, same arithmetic).
-    The EMA is then updated on the owned slices only; `gather_ema()` completes `ema_model` (call it before sampling from /
-    saving the EMA).  rehearse=(world, rank): lay the buckets and slices out as on that rank of that world size WITHOUT any
+    of the updated parameters (the same parameters as the all-reduce step up to the order in which the collective sums the ranks:
+    bit-identical on gloo and for two ranks, equal to fp32 rounding beyond -- a reduce-scatter ring and an all-reduce ring add in
+    different orders; same per-chunk norm, same arithmetic).  The EMA is then updated on the owned slices only: `ema_model` raises
+    until `gather_ema()` (a collective) has completed it, `ema_state_dict()` gathers first.  rehearse=(world, rank): lay the buckets and slices out as on that rank of that world size WITHOUT any
     communication -- a timing rehearsal of one rank's compute on a single GPU (bench.py); with shard_update the parameters
     outside the rank's slices are then simply not updated."""
 
@@ -262,11 +298,20 @@ class DPTrainer:
         # Tile queue (bsi_set_tile_queue): the persistent GEMMs of the backward that have more tiles than CUs draw their tiles from
         # counters instead of taking a static share, on ALL CUs whatever the reserve says -- a workgroup whose CU an RCCL kernel holds
         # leaves its share to the others, and no CU idles while RCCL is quiet (the reserve then only sizes the kernels that keep a
-        # static partition: weight-gradient GEMMs, attention).  Bit-identical results.  On for the launches of the backward of a
-        # bucketed model, like the reserve.  BSI_DP_TILE_QUEUE=0 switches it off.
+        # static partition: weight-gradient GEMMs, attention).  Bit-identical results.  In force for the launches of the backward of a
+        # bucketed model, like the reserve.
+        # Default OFF (BSI_DP_TILE_QUEUE=1 or tile_queue=True switches it on): no multi-GPU run has exercised it beside real RCCL
+        # kernels yet.  Whenever it is switched on, `tile_queue_self_check` first runs one ticketed GEMM against the static schedule
+        # on this device and refuses (warning, static schedule) if the bits differ -- the ticket pipeline keeps a value in a register
+        # the compiler must not touch (gemm_bf16.hip TQ_DRAW; the build's lint checks the generated code, this checks the loaded one).
         if tile_queue is None:
-            tile_queue = os.environ.get("BSI_DP_TILE_QUEUE", "1") != "0"
+            tile_queue = os.environ.get("BSI_DP_TILE_QUEUE", "0") == "1"
         self.tile_queue = bool(tile_queue) and (self.exchange or bool(rehearse)) and self.bucketed
+        if self.tile_queue and next(self.model.parameters()).is_cuda and not tile_queue_self_check(next(self.model.parameters()).device):
+            import warnings
+            warnings.warn("DPTrainer: the tile queue's self-check failed on this device (ticketed GEMM != static schedule); "
+                          "using the static schedule")
+            self.tile_queue = False
         # measurement hook (bench.py): with time_stages on, every step appends three HIP events (start, after backward + exchange,
         # after the optimizer) to stage_events; `stage_ms()` turns them into (forward + backward + exchange, optimizer) milliseconds
         self.time_stages = False
@@ -282,10 +327,10 @@ class DPTrainer:
         for attr in ("_plan", "_plan_t", "_grad_buffer"):  # persistent buffers + ctypes tables (rebuilt on demand; not deep-copyable)
             if hasattr(self.model, attr):
                 setattr(self.model, attr, None)
-        self.ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
+        self._ema_model = copy.deepcopy(self.model).eval().requires_grad_(False) if ema else None
         pad = self.lay_world * SEG_ALIGN
         self.fp = FlatParams(self.model, pad)
-        self.ema_fp = FlatParams(self.ema_model, pad) if ema else None
+        self.ema_fp = FlatParams(self._ema_model, pad) if ema else None
         self.ema_complete = True  # False while the EMA of a sharded step is current on the owned slices only
         dev = self.fp.flat.device
         if self.world > 1:
@@ -304,7 +349,7 @@ class DPTrainer:
         dist.broadcast(self.fp.flat, src=src, group=self.group)
         if self.ema_fp is not None:
             dist.broadcast(self.ema_fp.flat, src=src, group=self.group)
-        for m in (self.model, self.ema_model):
+        for m in (self.model, self._ema_model):
             for b in (m.buffers() if m is not None else ()):
                 dist.broadcast(b, src=src, group=self.group)
 
@@ -442,8 +487,23 @@ class DPTrainer:
         """Sharded step: all-gather the EMA slices so that `ema_model` is complete on every rank (no-op otherwise)."""
         if self.shard_update and self.exchange and self.ema_fp is not None and not self.ema_complete:
             self._gather(self.ema_fp.flat)
-            self._invalidate(self.ema_model)
+            self._invalidate(self._ema_model)
         self.ema_complete = True
+
+    @property
+    def ema_model(self):
+        """The EMA copy of the model (ema_pytorch's `ema_model`, bsi/tasks/ema_pytorch.py:203-217) -- always WHOLE, as there.  After
+        sharded steps across ranks each rank's copy is current only on the slices it owns: reading it then raises instead of
+        handing out a mix of current and stale slices; `gather_ema()` (a collective: every rank calls it) completes it."""
+        if self._ema_model is not None and self.shard_update and self.exchange and not self.ema_complete:
+            raise RuntimeError("DPTrainer.ema_model: after sharded steps the EMA is complete only on this rank's slices; call "
+                               "gather_ema() on every rank (or ema_state_dict(), which does) before sampling from or saving it")
+        return self._ema_model
+
+    def ema_state_dict(self):
+        """`ema_model.state_dict()` of a COMPLETE EMA (gathers first; every rank calls it)."""
+        self.gather_ema()
+        return None if self._ema_model is None else self._ema_model.state_dict()
 
     def stage_ms(self):
         """Mean (forward + backward + exchange, optimizer) milliseconds of the steps recorded since the last call."""
@@ -478,6 +538,6 @@ class DPTrainer:
             ev[2].record()
             self.stage_events.append(ev)
         self._invalidate(self.model)
-        if self.ema_model is not None:
-            self._invalidate(self.ema_model)
+        if self._ema_model is not None:
+            self._invalidate(self._ema_model)
         return loss.detach()

@@ -731,6 +731,13 @@ int bsi_set_attention_bwd_skew(int on);
 int bsi_prof_enable(unsigned mask);
 /* Diagnostic: shader clock seen by a one-wave kernel spinning `us` microseconds: out = {shader cycles, 100 MHz ticks}. */
 int bsi_clock_probe(unsigned long long* out /*device*/, int us, bsi_stream_t stream);
+/* Box yardstick: one 512-thread workgroup per CU runs iters x 64 v_mfma_f32_16x16x32_bf16 per wave on register operands with
+ * hashed (random) values -- the GEMMs' instruction without LDS, memory or barriers.  workspace (bsi_mfma_probe_workspace_bytes,
+ * device): after the launch, for wave v of workgroup w, words [4 (8 w + v) ..] = {shader cycles, 100 MHz ticks, first tick, last
+ * tick} of its loop (the constant 100 MHz counter is chip-wide).  Returns the workgroup count and the FLOP each one executed:
+ * TFLOP/s = workgroups * flop / ((max last tick - min first tick) * 10 ns), MHz = 100 * cycles / ticks of a wave. */
+size_t bsi_mfma_probe_workspace_bytes(void);
+int bsi_mfma_probe(int iters, void* workspace, int* workgroups, double* flop_per_workgroup, bsi_stream_t stream);
 /* Waits for the recorded launches of `cls`, returns their count and summed duration, and clears them. */
 int bsi_prof_read(int cls, int* count, double* total_ms);
 

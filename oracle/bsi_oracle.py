@@ -131,6 +131,32 @@ class BSIOracle:
         t = torch.remainder(grid.reshape(n, B) + offset, 1)
         return self.p_lambda.icdf(t)
 
+    # -- plain sampling (low_discrepancy_sampling=False, bsi.py:441-445).  Draw: rand((B, n)) -- and THAT transposed shape is
+    #    what the reference returns; `u` is the recorded draw
+    def lambda_plain(self, u):
+        return self.p_lambda.icdf(u)
+
+    # -- train loss on that branch (bsi.py:291-310 with 441-445): `_sample_lambda(1, B)[0]` is row 0 of a (B, 1) grid = ONE lambda of
+    #    shape (1,), which broadcasts over the batch together with ONE noise image (draws: rand((B, 1)), randn((1, *shape)))
+    def train_loss_plain(self, x, u, eps):
+        B = len(x)
+        lam = self.lambda_plain(u)[0]
+        mu = self.q_mu_lambda(x, lam, eps)
+        x_hat = self.predict_x(mu, self.p_lambda.cdf(lam))
+        err = (x - x_hat).square().reshape(B, -1).mean(dim=1)
+        return self.p_lambda.reciprocal_pdf(lam) * err
+
+    # -- infinite-step measurement loss on that branch (bsi.py:276-289): defined where the (B, n) grid broadcasts against the batch
+    #    (n == B); draws: rand((B, n)), randn((B, n, *shape))
+    def inf_measurement_loss_plain(self, x, u, eps):
+        lam = self.lambda_plain(u)
+        n = lam.shape[1]
+        mu = self.q_mu_lambda(x, lam, eps)
+        t = self.p_lambda.cdf(lam).flatten()
+        x_hat = self.predict_x(mu.flatten(end_dim=1), t).reshape(n, -1, *self.data_shape)
+        err = (x - x_hat).square().reshape(n, x_hat.shape[1], -1).sum(dim=2)
+        return 0.5 * self.p_lambda.reciprocal_pdf(lam) * err
+
     # -- train loss (bsi.py:291-310).  Draw order: rand(()), randperm(B), randn(B,*shape)
     def train_loss(self, x, offset, perm, eps):
         B = len(x)

@@ -243,6 +243,46 @@ def test_g6_elbo():
 
 
 # ----------------------------------------------------------------------------------------
+# G15: the two branches of the surface nothing else covers -- preconditioning=None (bsi.py:379-380) and
+# low_discrepancy_sampling=False (bsi.py:441-445, the transposed (batch, n) grid)
+# ----------------------------------------------------------------------------------------
+def test_g15_no_preconditioning():
+    g = golden("g15_branches")
+    W = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights("dit_noff").items()}
+    o = bo.BSIOracle(dit_f(W, False), data_shape=(3, 16, 16), k=4, preconditioning=None, discretization=bo.Disc.image_8bit())
+    loss = o.train_loss(g["A_x"], g["A_offset"], g["A_perm"], g["A_eps"])
+    assert max_rel(loss, g["A_loss"]) < 2e-5 and abs(float(loss.mean()) / float(g["A_loss_mean"]) - 1) < 1e-5
+    loss.mean().backward()
+    for k, ref in sub(g, "A_G.").items():
+        assert rel_linf(W[k].grad, ref) < 2e-3, (k, rel_linf(W[k].grad, ref))
+    with torch.no_grad():
+        mus, xh, ys = o.sample_history(g["A_eps0"], g["A_eps_steps"])
+        for a, b in [(mus, g["A_mus"]), (xh, g["A_x_hats"]), (ys, g["A_ys"])]:
+            assert a.shape == b.shape
+            for i in range(a.shape[0]):
+                assert rel_linf(a[i], b[i]) < 2e-5, (i, rel_linf(a[i], b[i]))
+        lr = o.reconstruction_loss(g["A_x"], g["A_eps_r"])
+        lm = o.inf_measurement_loss(g["A_x"], g["A_e_offset"], g["A_e_perm"], g["A_eps_m"])
+        elbo, bpd, extra = o.assemble_elbo(lr, lm, estimate_var=True)
+        assert max_rel(lr, g["A_l_recon"]) < 1e-5 and max_rel(lm, g["A_l_measure"]) < 2e-5
+        assert max_rel(elbo, g["A_elbo"]) < 1e-5 and max_rel(bpd, g["A_bpd"]) < 1e-5
+        assert max_rel(extra["bpd_var"], g["A_bpd_var"], floor=1e-12) < 1e-3
+
+
+def test_g15_plain_lambda_sampling():
+    g = golden("g15_branches")
+    o = make(dit_f(weights("dit_noff"), False), (3, 16, 16), k=4)
+    lam = o.lambda_plain(g["B_u"])
+    assert lam.shape == (5, 3) and torch.equal(lam, g["B_lam"])  # (batch, n): the reference's transposed shape
+    with torch.no_grad():
+        loss = o.train_loss_plain(g["A_x"], g["B_t_u"], g["B_t_eps"])
+        assert loss.shape == (4,) and max_rel(loss, g["B_t_loss"]) < 2e-5
+        ot = make(tiny_conv(sub(g, "B_m_W.")), (3, 8, 8), k=4)
+        lm = ot.inf_measurement_loss_plain(g["B_m_x"], g["B_m_u"], g["B_m_eps"])
+        assert lm.shape == g["B_m_loss"].shape and max_rel(lm, g["B_m_loss"]) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------
 # G7: components and full forwards
 # ----------------------------------------------------------------------------------------
 def test_g7_components():

@@ -255,6 +255,81 @@ def g14_config1():
          x_hats_first4=x_hats[:, :4], mus_first4=mus[:, :4], ys_first4=ys[:, :4], **sd(model), **grads)
 
 
+def g15_branches():
+    """The two branches of the BSI surface no other set exercises (bsi/bsi.py:379-380 and 441-445).
+
+    A. preconditioning=None: `_predict_x` is the bare denoiser.  Small DiT without Fourier features (weights w_dit_noff):
+       train_loss + gradients, free-running sample_history k = 4, elbo with estimate_var.
+    B. low_discrepancy_sampling=False: `_sample_lambda` draws `rand((batch, n))` and returns that TRANSPOSED (batch, n) shape
+       (SURVEY Appendix D.1).  Recorded: the draw and the result for (n, B) = (3, 5); `train_loss` of the small DiT at B = 4, where
+       `_sample_lambda(1, B)[0]` is ONE lambda (shape (1,)) that broadcasts over the batch together with ONE noise image
+       (bsi.py:309-310,405-420); and `inf_measurement_loss` at n = B = 4 (README denoiser), the one shape for which the reference's
+       broadcasting of the transposed grid against the batch is defined."""
+    import copy
+    shape = (3, 16, 16)
+    model = small_dit(ff=False, seed=5)
+    save_weights("dit_noff", model)
+    out = {}
+    # ---- A
+    b = ref.BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=4, preconditioning=None,
+                discretization=ref.Discretization.image_8bit())
+    B = 4
+    x = data(B, shape, 150)
+    g = torch.Generator().manual_seed(151)
+    loss = b.train_loss(x, g)
+    model.zero_grad()
+    loss.mean().backward()
+    grads = {"A_G." + k: p.grad.clone() for k, p in model.named_parameters()}
+    g = torch.Generator().manual_seed(151)
+    out.update(A_x=x, A_offset=torch.rand((), generator=g), A_perm=torch.randperm(B, generator=g),
+               A_eps=torch.randn((B, *shape), generator=g), A_loss=loss.detach(), A_loss_mean=loss.detach().mean())
+    g = torch.Generator().manual_seed(152)
+    with torch.no_grad():
+        mus, x_hats, ys = b.sample_history(2, g)
+    g = torch.Generator().manual_seed(152)
+    out.update(A_eps0=torch.randn((2, *shape), generator=g), A_eps_steps=torch.stack([torch.randn((2, *shape), generator=g) for _ in range(4)]),
+               A_mus=mus, A_x_hats=x_hats, A_ys=ys)
+    nr, nm = 2, 3
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(153)
+        elbo, bpd, extra = b.elbo(x, nr, nm, g, estimate_var=True)
+        g = torch.Generator().manual_seed(153)
+        out.update(A_eps_r=torch.randn((nr, B, *shape), generator=g), A_e_offset=torch.rand((), generator=g),
+                   A_e_perm=torch.randperm(nm * B, generator=g), A_eps_m=torch.randn((nm, B, *shape), generator=g),
+                   A_elbo=elbo, A_bpd=bpd, A_l_recon=extra["l_recon"], A_l_measure=extra["l_measure"], A_bpd_var=extra["bpd_var"])
+    # ---- B
+    bp = ref.BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=4, preconditioning="edm",
+                 low_discrepancy_sampling=False, discretization=ref.Discretization.image_8bit())
+    g = torch.Generator().manual_seed(154)
+    lam = bp._sample_lambda(3, 5, g)
+    g = torch.Generator().manual_seed(154)
+    u = torch.rand((5, 3), generator=g)
+    assert lam.shape == (5, 3)
+    out.update(B_u=u, B_lam=lam)
+    g = torch.Generator().manual_seed(155)
+    with torch.no_grad():
+        loss_b = bp.train_loss(x, g)
+    g = torch.Generator().manual_seed(155)
+    u1 = torch.rand((B, 1), generator=g)
+    eps1 = torch.randn((1, *shape), generator=g)
+    assert loss_b.shape == (B,)
+    out.update(B_t_u=u1, B_t_eps=eps1, B_t_loss=loss_b)
+    tc = TinyConv()
+    torch.manual_seed(156)
+    tc = TinyConv()
+    bt = ref.BSI(tc, data_shape=(3, 8, 8), lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=4, preconditioning="edm",
+                 low_discrepancy_sampling=False, discretization=ref.Discretization.image_8bit())
+    xt = data(4, (3, 8, 8), 157)
+    g = torch.Generator().manual_seed(158)
+    with torch.no_grad():
+        lm = bt.inf_measurement_loss(xt, 4, g)
+    g = torch.Generator().manual_seed(158)
+    um = torch.rand((4, 4), generator=g)
+    epsm = torch.randn((4, 4, 3, 8, 8), generator=g)
+    out.update(B_m_x=xt, B_m_u=um, B_m_eps=epsm, B_m_loss=lm, **sd(tc, "B_m_W."))
+    save("g15_branches", **out, **grads)
+
+
 def g6_elbo():
     torch.manual_seed(4)
     model = TinyConv()
@@ -552,4 +627,5 @@ if __name__ == "__main__":
     g11_calibration()
     g13_calibration_unet()
     g14_config1()
+    g15_branches()
     kat_reference_tests()

@@ -250,6 +250,8 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
             # exercised it beside real RCCL kernels; DPTrainer self-checks it against the static schedule first)
             variants.append((f"allreduce_cu_reserve_{a.cu_reserve}", dict(cu_reserve=a.cu_reserve, tile_queue=True)))
         variants.append(("sharded_update", dict(cu_reserve=0, shard_update=True)))
+        # the sharded step with its parameter all-gather overlapped with the next forward (block-by-block gates)
+        variants.append(("sharded_update_overlap", dict(cu_reserve=0, shard_update=True, overlap_gather=True)))
     runs, comm_runs = {}, {}
     for i, (name, kw) in enumerate(variants):
         try:
@@ -309,6 +311,16 @@ def train_bench(a, bsi, model, dev, world, rank, barrier):
                     rec["optimizer_ms_sharded" + key] = st_[1]
                     del tr
                     torch.cuda.empty_cache()
+                # the same rank's step with the gated forward of the overlapped gather (per-block casts and adaLN launches instead
+                # of one grouped launch each; no communication in a rehearsal): what the gates themselves cost
+                tr = DPTrainer(bsi, **recipe, cu_reserve=0, rehearse=(w_, 0), shard_update=True, overlap_gather=True)
+                tr.train_step(xs, g)
+                tr.train_step(xs, g)
+                dt_, st_, _ = _timed_train(tr, xs, g, n_, barrier, dev, 1)
+                rec["ms_per_step_gated_forward"] = 1e3 * dt_ / n_
+                tr.sync_params()
+                del tr
+                torch.cuda.empty_cache()
                 rec["optimizer_ms_replicated"] = runs[head]["optimizer_ms"]
                 rec["model_tflops"] = b_ * 3 * FWD_GFLOP_PER_IMG / rec["ms_per_step"]
                 per_rank.append(rec)
@@ -541,6 +553,9 @@ def summary(line):
            # per rank of a 2 / 4 / 8-GPU step on this one GPU: [world, fwd+bwd ms, fwd+bwd ms under the CU reserve, sharded optimizer ms]
            "per_rank_ms": [[r["world"], r2(r.get("fwd_bwd_ms")), r2(r.get("fwd_bwd_ms_cu_reserve")), r2(r.get("optimizer_ms_sharded"))]
                            for r in pr] if isinstance(pr, list) else pr,
+           # whole step of that rank: plain sharded step / with the gated forward of the overlapped all-gather
+           "per_rank_step_ms_plain_vs_gated": [[r["world"], r2(r.get("ms_per_step")), r2(r.get("ms_per_step_gated_forward"))]
+                                               for r in pr] if isinstance(pr, list) else None,
            "sample_256_128_64": [r2(get(sec, k, "value")) for k in ("dit_l2_sample_256", "dit_l2_sample_128", "dit_l2_sample_64")],
            "elbo_images_per_s": r2(get(sec, "dit_l2_elbo", "value")),
            "unet_images_per_s": r2(get(sec, "vdm_unet", "sample", "value")), "unet_train_steps_per_s": r2(get(sec, "vdm_unet", "train", "value")),

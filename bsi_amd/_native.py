@@ -32,6 +32,10 @@ class CastDesc(C.Structure):
                 ("ld_t", C.c_int), ("tile0", C.c_int), ("reserved", C.c_int)]
 
 
+class FwdGate(C.Structure):  # bsi_fwd_gate (include/bsi_hip.h)
+    _fields_ = [("event", C.c_void_p), ("cast", C.c_void_p), ("n_cast", C.c_int), ("cast_tiles", C.c_int)]
+
+
 class CopyDesc(C.Structure):  # bsi_copy_desc (include/bsi_hip.h)
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("len", C.c_size_t), ("tile0", C.c_uint), ("reserved", C.c_uint)]
 
@@ -214,6 +218,7 @@ _PROTOS = {
     "bsi_attention_fwd_dropout": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "bsi_attention_bwd_dropout": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "bsi_dit_backward_set_events": (_i, [_vp, _i]),
+    "bsi_dit_train_forward_set_gates": (_i, [_vp, _i]),
     "bsi_sqnorm_workspace_bytes": (_sz, []),
     "bsi_grad_sqnorm": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "bsi_clip_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp]),

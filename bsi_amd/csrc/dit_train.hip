@@ -192,6 +192,32 @@ int g_block_events_n = 0;
 
 }  // namespace
 
+// Gates of the NEXT forwards (bsi_dit_train_forward_set_gates): [0] what the front of the network needs (patch encoder), [1 + l]
+// block l, [depth + 1] the decoder.
+const bsi_fwd_gate* g_fwd_gates = nullptr;
+int g_fwd_gates_n = 0;
+
+extern "C" int bsi_dit_train_forward_set_gates(const bsi_fwd_gate* gates, int n) {
+    g_fwd_gates = gates;
+    g_fwd_gates_n = gates ? n : 0;
+    return BSI_OK;
+}
+
+namespace {
+// wait for the gate's event (the parameters behind it have arrived), then refresh the bf16 shadows that are cast from them
+int pass_gate(const bsi_fwd_gate& g, hipStream_t s) {
+    if (g.event) {
+        hipError_t e = hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(g.event), 0);
+        if (e != hipSuccess) {
+            bsi_set_error("bsi_dit_train_forward: waiting for a parameter gate failed: %s", hipGetErrorString(e));
+            return BSI_ELAUNCH;
+        }
+    }
+    if (g.cast && g.n_cast > 0 && g.cast_tiles > 0) return bsi_cast_batch_bf16(g.cast, g.n_cast, g.cast_tiles, reinterpret_cast<bsi_stream_t>(s));
+    return BSI_OK;
+}
+}  // namespace
+
 extern "C" int bsi_dit_backward_set_events(void* const* events, int depth) {
     g_block_events = events;
     g_block_events_n = events ? depth : 0;
@@ -226,6 +252,13 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
     const int mod_stride = d.depth * 6 * dim;
     Tape tp = carve_tape(d, B, tape_mem);
 
+    // Gated forward (data-parallel sharded step, bsi_dit_train_forward_set_gates): the parameters of block l may still be on their
+    // way (all-gather on another stream) when this function is called; block l waits for ITS gate only, then casts its own bf16
+    // shadows and runs its own adaLN MLP (the grouped launches below would need every block's parameters before the first block).
+    const bsi_fwd_gate* gates = g_fwd_gates;
+    BSI_CHECK_ARG(!gates || g_fwd_gates_n == d.depth + 2, "bsi_dit_train_forward: %d gates set, the model needs depth + 2 = %d",
+                  g_fwd_gates_n, d.depth + 2);
+    if (gates) TRY(pass_gate(gates[0], s));
     // adaLN tables, keeping the intermediate activations (dit.py:77-81)
     TRY(bsi_nyquist_embed(t, B, w->t_scale, w->t_bias, dim, nullptr, tp.emb, stream));
     // The adaLN MLP of every block depends on t only.  When the blocks' matrices and biases lie at uniform strides (the model's cast
@@ -244,7 +277,29 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         // positive strides only: they travel as size_t (a block order that runs DOWN in memory takes the per-block path)
         grouped = grouped && sw0 > 0 && sb0 > 0 && sw2 > 0 && sb2 > 0 && sw0 % 16 == 0 && sb0 % 16 == 0 && sw2 % 16 == 0 && sb2 % 16 == 0;
     }
-    if (grouped) {
+    // one block's adaLN MLP: as a group of ONE of the grouped kernel when the whole model would take the grouped path (the same
+    // arithmetic per block: a gated forward returns the bits of the ungated one), else the split-K GEMMs
+    auto adaln_block = [&](int l) -> int {
+        const bsi_dit_block_weights& bw = w->blocks[l];
+        float* pre = tp.ada_pre + (size_t)l * B * dim;
+        char* sl = tp.ada_s + (size_t)l * B * dim * 2;
+        if (grouped) {
+            bsi_gemm_args g{};
+            g.A = tp.emb; g.W = bw.ada0_w; g.bias = bw.ada0_b; g.out = pre;
+            g.M = B; g.N = dim; g.K = dim; g.lda = dim; g.ldw = dim; g.ldo = dim; g.epilogue = BSI_EPI_BIAS_F32;
+            TRY(bsi_gemm_bf16_grouped(&g, 1, 0, 0, 0, 0, stream));
+            TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
+            g.A = sl; g.W = bw.ada2_w; g.bias = bw.ada2_b; g.out = tp.mod + (size_t)l * 6 * dim;
+            g.N = 6 * dim; g.ldo = mod_stride;
+            return bsi_gemm_bf16_grouped(&g, 1, 0, 0, 0, 0, stream);
+        }
+        TRY(gemm_rows(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, tp.skws, tp.skws_bytes, stream));
+        TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
+        return gemm_rows(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, tp.skws, tp.skws_bytes, stream);
+    };
+    if (gates) {
+        // per block, inside the loop below
+    } else if (grouped) {
         bsi_gemm_args g{};
         g.A = tp.emb; g.W = w->blocks[0].ada0_w; g.bias = w->blocks[0].ada0_b; g.out = tp.ada_pre;
         g.M = B; g.N = dim; g.K = dim; g.lda = dim; g.ldw = dim; g.ldo = dim; g.epilogue = BSI_EPI_BIAS_F32;
@@ -254,14 +309,7 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         g.N = 6 * dim; g.ldo = mod_stride;
         TRY(bsi_gemm_bf16_grouped(&g, d.depth, (size_t)B * dim * 2, (size_t)sw2, (size_t)sb2, (size_t)6 * dim * 4, stream));
     } else {
-        for (int l = 0; l < d.depth; ++l) {
-            const bsi_dit_block_weights& bw = w->blocks[l];
-            float* pre = tp.ada_pre + (size_t)l * B * dim;
-            char* sl = tp.ada_s + (size_t)l * B * dim * 2;
-            TRY(gemm_rows(tp.emb, dim, bw.ada0_w, dim, bw.ada0_b, pre, dim, B, dim, dim, tp.skws, tp.skws_bytes, stream));
-            TRY(bsi_silu_bf16(pre, (size_t)B * dim, sl, stream));
-            TRY(gemm_rows(sl, dim, bw.ada2_w, dim, bw.ada2_b, tp.mod + (size_t)l * 6 * dim, mod_stride, B, 6 * dim, dim, tp.skws, tp.skws_bytes, stream));
-        }
+        for (int l = 0; l < d.depth; ++l) TRY(adaln_block(l));
     }
     TRY(bsi_dit_prologue_launch(mu, c_in, 1, B, cfg->C, cfg->H, cfg->W, cfg->patch, cfg->ff_nmin, d.nfreq, d.kpad, tp.a0, s));
     TRY(gemm(tp.a0, d.kpad, w->enc_w, d.kpad, w->enc_b, block_tape(tp, d, B, 0).xa, dim, M, dim, d.kpad, BSI_EPI_BIAS_POS_F32,
@@ -273,6 +321,10 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         const bsi_dit_block_weights& bw = w->blocks[l];
         BlockTape bt = block_tape(tp, d, B, l);
         const float* ml = tp.mod + (size_t)l * 6 * dim;
+        if (gates) {
+            TRY(pass_gate(gates[1 + l], s));
+            TRY(adaln_block(l));
+        }
         // xa = x_prev + gate * d2 of the block below (block 0: the encoder wrote xa), xn1 = LN(xa) * (1 + scale) + shift
         // (with dropout on the DiT geometry, this HBM-bound pass also computes the attention layer's dropout-mask words: row m ->
         //  block m, M = B * tokens = B * heads * 16 blocks when tokens == 16 * heads)
@@ -294,6 +346,7 @@ extern "C" int bsi_dit_train_forward(const bsi_dit_config* cfg, const bsi_dit_we
         pend_gate = ml + 5 * dim;
         x_prev = bt.xb;
     }
+    if (gates) TRY(pass_gate(gates[d.depth + 1], s));
     // materialise the final residual stream (kept for the decoder's backward), then the decoder
     TRY(bsi_resid_ln_modulate_drop(x_prev, M, dim, 1e-5f, pend_delta, pend_gate, nullptr, nullptr, B, mod_stride, d.tokens, nullptr,
                                    nullptr, nullptr, DropCfg{}, stream, tp.x, nullptr));

@@ -161,16 +161,24 @@ class GradExchange:
             _, sl, _, _, goff = self.layout[k]
             dist.reduce_scatter_tensor(shard[goff:goff + sl], flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
 
-    def run_all_gather(self, flat, rank):
+    def forward_order(self):
+        """Bucket indices in FORWARD order (front bucket, blocks first to last, tail)."""
+        return sorted(range(len(self.plan)), key=lambda k: self.plan[k][0])
+
+    def run_all_gather(self, flat, rank, after_bucket=None, communicate=True):
         """All-gather the slices of every bucket of `flat` in place (slice r of a bucket comes from rank r), buckets in FORWARD
-        order (front bucket, blocks first to last, tail) -- the order in which the next step's forward needs them."""
-        order = sorted(range(len(self.plan)), key=lambda k: self.plan[k][0])
-        for k in order:
+        order (front bucket, blocks first to last, tail) -- the order in which the next step's forward needs them.
+        `after_bucket(k)` is called when bucket k's collective has been enqueued (the overlapped step records an event there);
+        communicate=False walks the buckets without collectives (a one-GPU rehearsal of the schedule)."""
+        for k in self.forward_order():
             b, sl = self.layout[k][0], self.layout[k][1]
-            src = flat[b + rank * sl:b + (rank + 1) * sl]
-            if not flat.is_cuda:
-                src = src.clone()  # gloo: no in-place guarantee for an input that aliases the output
-            dist.all_gather_into_tensor(flat[b:b + self.world * sl], src, group=self.group)
+            if communicate:
+                src = flat[b + rank * sl:b + (rank + 1) * sl]
+                if not flat.is_cuda:
+                    src = src.clone()  # gloo: no in-place guarantee for an input that aliases the output
+                dist.all_gather_into_tensor(flat[b:b + self.world * sl], src, group=self.group)
+            if after_bucket is not None:
+                after_bucket(k)
 
 
 class FlatParams:
@@ -260,7 +268,8 @@ class DPTrainer:
     def __init__(self, bsi, *, lr: float = 5e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = 1.0, ema: bool = True, ema_beta: float = 0.9999,
                  ema_update_after_step: int = 1000, lr_schedule=None, process_group=None, force_exchange: bool = False,
-                 cu_reserve: int | None = None, tile_queue: bool | None = None, shard_update: bool = False, rehearse=None):
+                 cu_reserve: int | None = None, tile_queue: bool | None = None, shard_update: bool = False, rehearse=None,
+                 overlap_gather: bool = False):
         self.bsi = bsi
         self.model = bsi.model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -273,6 +282,13 @@ class DPTrainer:
         # the multi-GPU code path can be exercised on a single device
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
         self.shard_update = bool(shard_update)
+        # overlap_gather (sharded step of a bucketed model): the all-gather of the updated parameters is NOT waited for at the end of
+        # the step; it runs bucket by bucket in forward order on the communication stream while the next step's forward is enqueued,
+        # and the forward waits block by block (bsi_dit_train_forward_set_gates) -- what DDP's own exchange gets from hiding behind
+        # the backward (bsi/tasks/bsi.py:163-166).  Same arithmetic, same bits as the step that waits.
+        self.overlap_gather = bool(overlap_gather) and self.shard_update
+        self._gates_pending = False
+        self._gate_events, self._gate_used, self._gate_arr = None, None, None
         # the world / rank the buckets and slices are laid out for (a rehearsal lays out another world's without communicating)
         self.lay_world, self.lay_rank = (int(rehearse[0]), int(rehearse[1])) if rehearse else (self.world, self.rank)
         assert not (rehearse and self.exchange), "a rehearsal does not communicate"
@@ -376,7 +392,7 @@ class DPTrainer:
         self.seg_tab = self._seg_table(self.seg_rows, dev) if dev.type == "cuda" else None
 
     def _setup_exchange_state(self, dev, depth):
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange or (self.overlap_gather and dev.type == "cuda")) else None
         self.events = None
         if self.exchange and self.bucketed:
             self.events = [torch.cuda.Event() for _ in range(depth)]
@@ -397,7 +413,12 @@ class DPTrainer:
             N.check(lib.bsi_dit_backward_set_events(self._ev_arr, len(self.events)))
         self.model._flat_grad_only = True
         try:
-            loss = self.bsi.train_loss(x, generator).mean()
+            gated = self._install_gates()
+            try:
+                loss = self.bsi.train_loss(x, generator).mean()
+            finally:
+                if gated:
+                    N.check(lib.bsi_dit_train_forward_set_gates(None, 0))
             # grids are sized when a kernel is LAUNCHED: the switches are on while the backward's kernels are enqueued (the forward
             # above overlaps with nothing) and off again before this returns -- the exchange only launches RCCL's own kernels
             if self.cu_reserve:
@@ -421,6 +442,73 @@ class DPTrainer:
 
     def _gate_wait(self, l):
         self.comm_stream.wait_event(self.events[l])
+
+    # -- overlapped parameter all-gather (sharded step) --------------------------------------------------------------------------
+    def _gate_of_bucket(self, k):
+        """Forward gate of plan bucket k: 0 = front (patch encoder), 1 + l = block l, depth + 1 = tail (decoder)."""
+        b, _, gate = self.xchg.plan[k]
+        if gate is not None:
+            return 1 + gate
+        return 0 if b == 0 else len(self.model.dit.blocks) + 1
+
+    def _gather_async(self, flat):
+        """Enqueue the all-gather of `flat` on the communication stream WITHOUT making the compute stream wait: one event per
+        bucket, which the next forward waits for block by block.  Anything else that reads the parameters first (sampling from the
+        model, a checkpoint) goes through `sync_params`, which the model's cast path calls by itself."""
+        depth = len(self.model.dit.blocks)
+        if self._gate_events is None:
+            self._gate_events = [torch.cuda.Event() if flat.is_cuda else None for _ in range(depth + 2)]
+        used = [False] * (depth + 2)
+
+        def mark(k):
+            g = self._gate_of_bucket(k)
+            used[g] = True
+            if flat.is_cuda:
+                self._gate_events[g].record()  # on the current (= communication) stream
+
+        if flat.is_cuda and self.comm_stream is not None:
+            cur = torch.cuda.current_stream()
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self.xchg.run_all_gather(flat, self.rank, after_bucket=mark, communicate=self.exchange)
+        else:
+            self.xchg.run_all_gather(flat, self.rank, after_bucket=mark, communicate=self.exchange)
+        self._gate_used = used
+        self._gates_pending = True
+        self.model._params_pending_sync = self.sync_params
+
+    def sync_params(self):
+        """Make the current stream wait for an all-gather of the parameters that is still in flight (no-op otherwise)."""
+        if self._gates_pending:
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._gates_pending = False
+        self.model.__dict__["_params_pending_sync"] = None
+
+    def _install_gates(self):
+        """Before the forward of a step whose parameters are still arriving: hand the per-bucket events and the per-part cast
+        sub-tables to the training engine (the forward then casts block l's shadows behind block l's event).  False when nothing is
+        pending or the model has no gate tables (then the ordinary cast path waits for the whole gather)."""
+        if not self._gates_pending:
+            return False
+        plan = self.model.native_pack_uncast() if hasattr(self.model, "native_pack_uncast") else None
+        tabs = plan.get("gate_tables") if plan is not None else None
+        if tabs is None or plan.get("pack_t") is None:
+            self.sync_params()
+            self._invalidate(self.model)
+            return False
+        raw, spans = tabs
+        n = len(spans)
+        arr = (N.FwdGate * n)()
+        desc = C.sizeof(N.CastDesc)
+        for gi, (pos, cnt, tiles) in enumerate(spans):
+            ev = self._gate_events[gi] if (self._gate_events and self._gate_used[gi] and self._gate_events[gi] is not None) else None
+            arr[gi] = N.FwdGate(ev.cuda_event if ev is not None else None, raw.data_ptr() + pos * desc if cnt else None, cnt, tiles)
+        self._gate_arr = arr  # stays alive until cleared
+        N.check(N.lib().bsi_dit_train_forward_set_gates(arr, n))
+        self._gates_pending = False
+        self.model.__dict__["_params_pending_sync"] = None
+        return True
 
     def _exchange(self, flat_g):
         """Sum the gradient over the ranks, bucket by bucket (GradExchange.plan): all-reduce, or reduce-scatter into this rank's
@@ -469,7 +557,9 @@ class DPTrainer:
             self._sq_finish(self.part)
             self._apply(self.gshard, lr, ema_w)
             self.ema_complete = self.ema_fp is None or ema_w < 0
-            if self.exchange:
+            if self.overlap_gather and self.bucketed and (self.exchange or self.lay_world > 1):
+                self._gather_async(self.fp.flat)
+            elif self.exchange:
                 self._gather(self.fp.flat)
         self.last_grad_norm = self.sq  # squared norm of the summed gradient (device scalar)
 

@@ -139,7 +139,8 @@ class DenoisingDiT(nn.Module):
         return N.DitConfig(Cc, H, W, a["patch"], a["dim"], a["depth"], a["heads"],
                            ff.n_min if ff is not None else 1, ff.n_max if ff is not None else 0)
 
-    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad", "_grad_buffer")
+    _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad", "_grad_buffer",
+                      "_params_pending_sync")
 
     def __deepcopy__(self, memo):
         """`copy.deepcopy(model)` (EMA copies, checkpoint tooling) after the model has run: the native caches hold ctypes tables with raw
@@ -235,6 +236,42 @@ class DenoisingDiT(nn.Module):
             tiles += lib.bsi_cast_batch_tiles(rows, cols, ld if dst is not None else cols)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         plan["table"] = (raw.to(plan["descs"][0][0].device), len(plan["descs"]), tiles)
+        # The same descriptors grouped by the GATES of a gated training forward (bsi_dit_train_forward_set_gates): [0] the patch
+        # encoder (the last descriptor), [1 + l] the six matrices of block l, [depth + 1] nothing -- one device table of sub-tables
+        # whose tile0 restart at 0, and per gate (first descriptor, count, tiles).
+        depth = len(self.dit.blocks)
+        if len(plan["descs"]) == 6 * depth + 1:
+            groups = [[6 * depth]] + [list(range(6 * l, 6 * l + 6)) for l in range(depth)] + [[]]
+            sub = (N.CastDesc * len(plan["descs"]))()
+            spans, pos = [], 0
+            for idx in groups:
+                t0 = 0
+                for j in idx:
+                    src, dst, dst_t, rows, cols, ld, ld_t = plan["descs"][j]
+                    sub[pos + len([k for k in idx if k < j])] = N.CastDesc(
+                        src.data_ptr(), dst.data_ptr() if dst is not None else None, dst_t.data_ptr() if dst_t is not None else None,
+                        rows, cols, ld, ld_t, t0, 0)
+                    t0 += lib.bsi_cast_batch_tiles(rows, cols, ld if dst is not None else cols)
+                spans.append((pos, len(idx), t0))
+                pos += len(idx)
+            raw_g = torch.frombuffer(bytearray(bytes(sub)), dtype=torch.uint8).to(plan["descs"][0][0].device)
+            plan["gate_tables"] = (raw_g, spans)
+        else:
+            plan["gate_tables"] = None
+
+    def native_pack_uncast(self):
+        """The pack WITHOUT refreshing the shadows: for a caller that casts them itself, part by part, as the parameters arrive (the
+        gated training forward of a sharded data-parallel step, DPTrainer).  Marks the shadows as current for this parameter
+        version -- the caller's casts are enqueued in front of every use."""
+        key = self._weights_key()
+        skey = self._storage_key()
+        if getattr(self, "_plan", None) is None or self._plan["skey"] != skey:
+            self._plan = self._build_plan(skey)
+        plan = self._plan
+        self._pack, self._pack_key = plan["pack"], key
+        if plan["pack_t"] is not None:
+            self._pack_t, self._pack_t_key = plan["pack_t"], key
+        return plan
 
     def native_pack(self):
         """bf16 [N][K] shadows of the GEMM weights + the ctypes weight table.  The shadows are PERSISTENT buffers described once by a
@@ -244,6 +281,9 @@ class DenoisingDiT(nn.Module):
         key = self._weights_key()
         if self._pack is not None and self._pack_key == key:
             return self._pack
+        sync = self.__dict__.get("_params_pending_sync")
+        if sync is not None:  # a trainer's all-gather of these parameters is still in flight on another stream: wait for it first
+            sync()
         skey = self._storage_key()
         if getattr(self, "_plan", None) is None or self._plan["skey"] != skey:
             self._plan = self._build_plan(skey)

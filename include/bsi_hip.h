@@ -648,6 +648,15 @@ int bsi_attention_fwd_dropout(const void* qkv, int ld_qkv, int B, int tokens, in
 int bsi_attention_bwd_dropout(const void* qkv, int ld_qkv, const void* out, const void* dout, int ld_o, const float* lse, int B,
                               int tokens, int heads, int dh, void* dqkv, int ld_dqkv, float p, unsigned long long seed, unsigned site,
                               const void* words, bsi_stream_t stream);
+/* Optional hook for the data-parallel SHARDED step (replaces what DDP gets from hiding its traffic behind the backward,
+ * /root/reference bsi/tasks/bsi.py:163-166): the all-gather of the updated parameters may still be running, bucket by bucket in
+ * forward order on another stream, when the next forward is enqueued.  gates: host array of depth + 2 entries -- [0] the front of the
+ * network (patch encoder), [1 + l] block l, [depth + 1] the decoder -- each an event (hipEvent_t or NULL) that the forward's stream
+ * waits for before it touches that part's parameters, and the part's descriptors of the bf16 shadow cast (a DEVICE sub-table whose
+ * tile0 start at 0, or NULL), launched right behind the wait.  With gates set every block runs its own adaLN MLP (same arithmetic as
+ * the grouped launches: bit-identical results).  The array must stay valid until cleared; pass NULL to clear. */
+typedef struct bsi_fwd_gate { void* event; const bsi_cast_desc* cast; int n_cast; int cast_tiles; } bsi_fwd_gate;
+int bsi_dit_train_forward_set_gates(const bsi_fwd_gate* gates /*host*/, int n);
 /* Optional hook for data-parallel overlap: events[l] (hipEvent_t, host array [depth], entries may be NULL) is recorded
  * on the stream as soon as every parameter gradient of block l has been enqueued, so the caller can start that
  * block's gradient all-reduce on another stream while the backward continues.  Pass NULL to clear. */

@@ -47,7 +47,9 @@ def main():
     x = g["x"][start:start + nb].to(dev)
     out = {}
     # the all-reduce step, then -- from the same start state and draws -- the sharded step (reduce-scatter, slice update, all-gather)
-    for mode, kw in (("allreduce", {}), ("sharded", {"shard_update": True})):
+    # and the sharded step whose parameter all-gather is not waited for: the next forward waits block by block (gated forward)
+    for mode, kw in (("allreduce", {}), ("sharded", {"shard_update": True}),
+                     ("sharded_overlap", {"shard_update": True, "overlap_gather": True})):
         bsi = build(dev)
         tr = DPTrainer(bsi, **TRAINER, **kw)
         assert tr.world == world and tr.exchange and tr.bucketed and tr.comm_stream is not None and tr.events is not None
@@ -56,6 +58,7 @@ def main():
             off, perm, eps = shard_draws(rank, s, nb, (3, 16, 16))
             with replay_draws(dev, rand=[off], randperm=[perm], randn=[eps]):
                 losses.append(float(tr.train_step(x)))
+        tr.sync_params()
         tr.gather_ema()
         torch.cuda.synchronize()
         out[mode] = {"flat": tr.fp.flat.cpu(), "ema": tr.ema_fp.flat.cpu(), "losses": losses, "buckets": len(tr.xchg.plan),

@@ -235,7 +235,8 @@ def _worker_modes(rank, world, port, ret):
     nb = dp.split_batch(129, world, rank)
     start = sum(dp.split_batch(129, world, r) for r in range(rank))
     out = {}
-    for mode, seed, kw in (("allreduce", 0, {}), ("own_seed", 100 * rank, {}), ("sharded", 0, {"shard_update": True})):
+    for mode, seed, kw in (("allreduce", 0, {}), ("own_seed", 100 * rank, {}), ("sharded", 0, {"shard_update": True}),
+                           ("sharded_overlap", 0, {"shard_update": True, "overlap_gather": True})):
         torch.manual_seed(seed)
         model = _ToyDiT()
         log = []
@@ -279,8 +280,11 @@ def test_gloo_world2_start_broadcast_and_sharded_update():
     ret = mgr.dict()
     mp.spawn(_worker_modes, args=(world, _free_port(), ret), nprocs=world, join=True)
     a, b = ret[0], ret[1]
-    for mode in ("allreduce", "own_seed", "sharded"):
+    for mode in ("allreduce", "own_seed", "sharded", "sharded_overlap"):
         assert torch.equal(a[mode]["flat"], b[mode]["flat"]) and torch.equal(a[mode]["ema"], b[mode]["ema"]), mode
+    # the overlapped gather (per-bucket, in forward order, not waited for at the end of the step) moves the same bytes to the same places
+    assert torch.equal(a["sharded_overlap"]["flat"], a["sharded"]["flat"]) and torch.equal(a["sharded_overlap"]["ema"], a["sharded"]["ema"])
+    assert a["sharded_overlap"]["calls"] == a["sharded"]["calls"]
     # (1) rank 1 was seeded 100, rank 0 seeded 0: both follow the trajectory of the identically seeded run
     assert torch.equal(a["own_seed"]["flat"], a["allreduce"]["flat"]) and torch.equal(a["own_seed"]["ema"], a["allreduce"]["ema"])
     # (2) sharded == all-reduce, bit for bit (parameters, EMA after gather_ema, squared norm)

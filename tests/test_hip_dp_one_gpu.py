@@ -38,11 +38,15 @@ def test_two_processes_on_one_gpu_run_the_product_train_step(tmp_path):
                 p.kill()
     assert [p.returncode for p in procs] == [0, 0], logs
     a0, a1 = (torch.load(out + f".rank{r}.pt") for r in range(2))
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sharded_overlap"):
         assert torch.equal(a0[mode]["flat"], a1[mode]["flat"]) and torch.equal(a0[mode]["ema"], a1[mode]["ema"]), mode  # replicas stay bit-identical
     # the sharded step (reduce-scatter -> bsi_clip_adamw_ema_segments on the rank's slices -> all-gather) == the all-reduce step, bit for bit
     assert torch.equal(a0["sharded"]["flat"], a0["allreduce"]["flat"]) and torch.equal(a0["sharded"]["ema"], a0["allreduce"]["ema"])
     assert a0["sharded"]["sq"] == a0["allreduce"]["sq"] and a0["sharded"]["losses"] == a0["allreduce"]["losses"]
+    # ... and so is the sharded step whose all-gather overlaps the next (gated) forward
+    for k in ("flat", "ema", "sq", "losses"):
+        same = torch.equal(a0["sharded_overlap"][k], a0["sharded"][k]) if torch.is_tensor(a0["sharded"][k]) else a0["sharded_overlap"][k] == a0["sharded"][k]
+        assert same, f"sharded_overlap differs from sharded in {k}"
     r0, r1 = a0["allreduce"], a1["allreduce"]
     assert r0["buckets"] == 2 + 2  # one per block (last first) + patch encoder + decoder
 

@@ -1,0 +1,114 @@
+"""The sharded data-parallel step with its parameter all-gather OVERLAPPED with the next forward (DPTrainer(overlap_gather=True),
+bsi_dit_train_forward_set_gates): what DistributedDataParallel gets from hiding its traffic behind the backward
+(/root/reference/bsi/tasks/bsi.py:163-166, static_graph=True).  In a process group of ONE rank over RCCL (all there is on a one-GPU
+box): (1) the overlapped step returns the bits of the step that waits for the gather; (2) a timeline check -- with the gather of
+block 12's bucket held back on the communication stream, blocks 0..11 of the next forward run meanwhile: after the last bucket has
+arrived, less than 0.7 of a forward is left (the step that waits has a whole forward left)."""
+import ctypes as C
+import os
+import tempfile
+
+import pytest
+import torch
+
+from tests.util import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model_and_bsi():
+    import bench
+    from bsi_amd import BSI, Discretization
+    model, shape = bench.build_model(torch.device(DEV, 0))
+    for blk in model.dit.blocks:  # dropout off: the masks' seeds depend on a call counter, the two trainers must see the same arithmetic
+        blk.attn.dropout = 0.0
+    bsi = BSI(model, data_shape=shape, lambda_0=1e-2, alpha_M=1e6, alpha_R=2e6, k=16, preconditioning="edm",
+              discretization=Discretization.image_8bit()).to(DEV)
+    return model.train(), bsi, shape
+
+
+def test_overlapped_gather_is_bit_identical_and_overlaps():
+    import torch.distributed as dist
+    from bsi_amd import _native as N
+    from bsi_amd.dp import DPTrainer
+    store = tempfile.NamedTemporaryFile(delete=False)
+    store.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"file://{store.name}", rank=0, world_size=1)
+    lib = N.lib()
+    try:
+        B = 32
+        results, left_ms, fwd_ms = {}, {}, {}
+        for mode, overlap in (("waits", False), ("overlapped", True)):
+            torch.manual_seed(3)
+            model, bsi, shape = _model_and_bsi()
+            gen = torch.Generator(DEV).manual_seed(11)
+            x = (torch.round(255 * torch.rand((B, *shape), device=DEV, generator=gen)) / 255) * 2 - 1
+            tr = DPTrainer(bsi, lr=5e-4, betas=(0.9, 0.99), weight_decay=1e-2, max_grad_norm=1.0, force_exchange=True,
+                           shard_update=True, overlap_gather=overlap)
+            assert tr.exchange and tr.bucketed and tr.overlap_gather == overlap
+            # time the forward (= train_loss) of every step on the compute stream
+            ev = []
+            real_loss = bsi.train_loss
+
+            def timed_loss(*a, _f=real_loss, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _f(*a, **k)
+                e1.record()
+                ev.append((e0, e1))
+                return out
+
+            bsi.train_loss = timed_loss
+            losses = []
+            g2 = torch.Generator(DEV).manual_seed(5)
+            for _ in range(3):
+                losses.append(float(tr.train_step(x, g2)))
+            torch.cuda.synchronize()
+            fwd_ms[mode] = ev[-1][0].elapsed_time(ev[-1][1])
+            # ---- timeline: hold the gather of block 12's bucket back by 30 ms, then run one more step
+            calls = {"n": 0}
+            real_ag = dist.all_gather_into_tensor
+            spin_out = torch.zeros(2, dtype=torch.int64, device=DEV)
+
+            def slow_ag(*a, **k):
+                calls["n"] += 1
+                if calls["n"] == 14:  # front bucket, blocks 0..11, then block 12: the 14th collective of the gather
+                    N.check(lib.bsi_clock_probe(N.ptr(spin_out), 30000, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                return real_ag(*a, **k)
+
+            dist.all_gather_into_tensor = slow_ag
+            try:
+                losses.append(float(tr.train_step(x, g2)))   # its update's gather carries the delay
+            finally:
+                dist.all_gather_into_tensor = real_ag
+            assert calls["n"] == len(tr.xchg.plan)
+            gathered = torch.cuda.Event(enable_timing=True)
+            gathered.record(tr.comm_stream)                   # fires when the last bucket has arrived
+            losses.append(float(tr.train_step(x, g2)))       # the forward under test
+            tr.sync_params()
+            torch.cuda.synchronize()
+            e0, e1 = ev[-1]
+            left_ms[mode] = gathered.elapsed_time(e1)         # forward time left once every parameter is there
+            assert left_ms[mode] > 0, "the forward cannot end before its last gate"
+            tr.gather_ema()
+            torch.cuda.synchronize()
+            results[mode] = (losses, tr.fp.flat.clone(), tr.ema_fp.flat.clone())
+            bsi.train_loss = real_loss
+            del tr
+            torch.cuda.empty_cache()
+        a, b = results["waits"], results["overlapped"]
+        assert a[0] == b[0], (a[0], b[0])
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), "overlapped gather changed the parameters or the EMA"
+        report("overlap_gather_timeline", forward_ms=fwd_ms["waits"], forward_ms_gated=fwd_ms["overlapped"],
+               left_after_last_bucket_ms_waits=left_ms["waits"], left_after_last_bucket_ms_overlapped=left_ms["overlapped"], bit_identical=True)
+        # the step that waits starts its forward behind the whole gather; the overlapped one has run blocks 0..11 by then
+        assert left_ms["waits"] > 0.9 * fwd_ms["waits"], (left_ms, fwd_ms)
+        assert left_ms["overlapped"] < 0.7 * fwd_ms["overlapped"], (left_ms, fwd_ms)
+        # gating costs the grouped adaLN launches and the single cast launch: a few per cent of a forward at most
+        assert fwd_ms["overlapped"] < 1.15 * fwd_ms["waits"], fwd_ms
+    finally:
+        dist.destroy_process_group()
+        if os.path.exists(store.name):
+            os.unlink(store.name)

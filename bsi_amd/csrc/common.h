@@ -82,10 +82,11 @@ inline int device_cus() {
 // kernel of this library that launches "one workgroup per CU" with a static partition of its tiles sizes its grid (and the
 // split counts derived from it) with this: a 160-KB-LDS workgroup that cannot be placed because a communication kernel holds
 // its CU would otherwise start a whole kernel late and double the launch's duration.
-extern int g_bsi_cu_reserve;  // prof.hip
-extern int g_bsi_cu_masked;   // prof.hip: 1 while launches go to a CU-masked stream (bsi_dit_forward_pair): the reserve is then a HARD limit --
+// (thread_local: a setting belongs to the thread that launches -- an evaluation or a sampling call on another thread keeps its own)
+extern thread_local int g_bsi_cu_reserve;  // prof.hip
+extern thread_local int g_bsi_cu_masked;   // prof.hip: 1 while launches go to a CU-masked stream (bsi_dit_forward_pair): the reserve is then a HARD limit --
                               // a workgroup beyond compute_cus() cannot be placed beside the others, tile queue or not
-extern int g_bsi_ln_stream_cus;  // prof.hip: > 0 = the LayerNorm passes of the inference engine run as persistent kernels sized for this many CUs
+extern thread_local int g_bsi_ln_stream_cus;  // prof.hip: > 0 = the LayerNorm passes of the inference engine run as persistent kernels sized for this many CUs
 inline int compute_cus() {
     const int c = device_cus() - g_bsi_cu_reserve;
     return c < 8 ? 8 : c;
@@ -101,7 +102,7 @@ inline int compute_cus() {
 // (kernels of a stream are serialised).
 constexpr int BSI_TQ_GONE = 8, BSI_TQ_XCDS = 16, BSI_TQ_MBOX = 32, BSI_TQ_MAX_WG = 512;
 constexpr size_t BSI_TQ_WORDS = BSI_TQ_MBOX + 16 * (size_t)BSI_TQ_MAX_WG;
-extern int g_bsi_tile_queue;                    // prof.hip: 0 = static shares, 1 = tickets where a kernel supports them
+extern thread_local int g_bsi_tile_queue;       // prof.hip: 0 = static shares, 1 = tickets where a kernel supports them
 unsigned* bsi_tile_queue_block(hipStream_t s);  // prof.hip: the stream's control block, or nullptr (queue off / none available)
 #ifdef BSI_LAB
 extern unsigned* g_lab_static_block;            // prof.hip (laboratory build): where the static schedule leaves its stamps

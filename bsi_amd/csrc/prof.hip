@@ -29,9 +29,9 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-int g_bsi_cu_reserve = 0;  // see compute_cus(), common.h
-int g_bsi_cu_masked = 0;
-int g_bsi_ln_stream_cus = [] {
+thread_local int g_bsi_cu_reserve = 0;  // see compute_cus(), common.h
+thread_local int g_bsi_cu_masked = 0;
+thread_local int g_bsi_ln_stream_cus = [] {
     const char* e = getenv("BSI_LN_STREAM_CUS");  // experiments: the persistent LayerNorm pass on the whole chip (256) or a part of it
     return e ? atoi(e) : 0;
 }();
@@ -53,7 +53,7 @@ extern "C" int bsi_set_ln_stream_cus(int cus) {
 }
 
 // ---- tile queue control blocks (common.h) --------------------------------------------------------------------------------------
-int g_bsi_tile_queue = [] {
+thread_local int g_bsi_tile_queue = [] {
     const char* e = getenv("BSI_TILE_QUEUE");
     return e ? atoi(e) : 0;
 }();

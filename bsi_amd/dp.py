@@ -419,20 +419,16 @@ class DPTrainer:
             finally:
                 if gated:
                     N.check(lib.bsi_dit_train_forward_set_gates(None, 0))
-            # grids are sized when a kernel is LAUNCHED: the switches are on while the backward's kernels are enqueued (the forward
-            # above overlaps with nothing) and off again before this returns -- the exchange only launches RCCL's own kernels
-            if self.cu_reserve:
-                N.check(lib.bsi_set_cu_reserve(self.cu_reserve))
-            if self.tile_queue:
-                N.check(lib.bsi_set_tile_queue(1))
+            # grids are sized when a kernel is LAUNCHED: the reserve and the queue apply to the launches of the backward only (the
+            # forward above overlaps with nothing; the exchange only launches RCCL's own kernels).  They are per launching thread and
+            # the backward runs on autograd's thread: the training engine applies `_bwd_sched` around its own launches
+            # (models/dit_train.py), so nothing else in the process -- an evaluation on another thread or stream -- is affected.
+            self.model._bwd_sched = (self.cu_reserve, self.tile_queue)
             loss.backward()
         finally:
             self.model._flat_grad_only = False
             self.model._grad_buffer = None
-            if self.cu_reserve:
-                N.check(lib.bsi_set_cu_reserve(0))
-            if self.tile_queue:
-                N.check(lib.bsi_set_tile_queue(0))
+            self.model._bwd_sched = None
             if self.exchange and self.bucketed:
                 N.check(lib.bsi_dit_backward_set_events(None, 0))
         flat_g = self.model._last_flat_grad

@@ -140,7 +140,7 @@ class DenoisingDiT(nn.Module):
                            ff.n_min if ff is not None else 1, ff.n_max if ff is not None else 0)
 
     _NATIVE_CACHES = ("_pack", "_pack_key", "_pack_t", "_pack_t_key", "_plan", "_plan_t", "_ws", "_last_flat_grad", "_grad_buffer",
-                      "_params_pending_sync")
+                      "_params_pending_sync", "_bwd_sched")
 
     def __deepcopy__(self, memo):
         """`copy.deepcopy(model)` (EMA copies, checkpoint tooling) after the model has run: the native caches hold ctypes tables with raw

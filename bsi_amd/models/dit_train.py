@@ -111,8 +111,22 @@ class _DitTrainFn(torch.autograd.Function):
         g.dec_b = views["dit.patch_decoder.1.bias"].data_ptr()
         g.blocks = C.cast(blocks, C.POINTER(N.DitBlockGrads))
         ws = torch.empty(lib.bsi_dit_backward_workspace_bytes(C.byref(cfg), B), dtype=torch.uint8, device=dev)
-        N.check(lib.bsi_dit_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
-                                     N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
+        # launch schedule of THIS backward (DPTrainer: CU reserve / tile queue while gradient buckets are in flight).  The switches are
+        # per launching thread, and this function runs on autograd's device thread, not on the caller's: they are applied here, around
+        # the one call whose launches they are meant for, and nothing else in the process sees them.
+        reserve, queue = getattr(model, "_bwd_sched", None) or (0, False)
+        try:
+            if reserve:
+                N.check(lib.bsi_set_cu_reserve(int(reserve)))
+            if queue:
+                N.check(lib.bsi_set_tile_queue(1))
+            N.check(lib.bsi_dit_backward(C.byref(cfg), C.byref(w), C.byref(wt), C.byref(g), B, N.ptr(g_out), N.ptr(ctx.c_out),
+                                         N.ptr(ctx.tape), N.ptr(ws), ctx.drop[0], ctx.drop[1], N.stream()))
+        finally:
+            if reserve:
+                N.check(lib.bsi_set_cu_reserve(0))
+            if queue:
+                N.check(lib.bsi_set_tile_queue(0))
         ctx.tape = None
         model._last_flat_grad = flat  # the data-parallel trainer all-reduces and consumes this buffer directly
         kin = named["dit.patch_encoder.weight"].shape[1]

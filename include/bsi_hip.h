@@ -714,21 +714,23 @@ enum {
 /* Data-parallel step (replaces what DDP's reducer gets from running on its own stream, /root/reference bsi/tasks/bsi.py:163-166):
  * leave `cus` compute units (0 or a multiple of 8, at most BSI_MAX_CU_RESERVE) out of every persistent kernel's grid -- the
  * GEMMs, weight-gradient GEMMs, convolutions and attention kernels launch one 160-KB-LDS workgroup per CU with a static share
- * of the tiles, so a workgroup whose CU is held by an RCCL kernel would start a whole kernel late.  Process-wide, takes effect
- * at the next launch; 0 (the default) = all CUs.  bsi_compute_cus: the CU count those kernels size their grids with. */
+ * of the tiles, so a workgroup whose CU is held by an RCCL kernel would start a whole kernel late.  Per CALLING THREAD (launches of
+ * other threads -- an evaluation beside a training step -- keep their own setting), takes effect at that thread's next launch; 0 (the
+ * default) = all CUs.  bsi_compute_cus: the CU count those kernels size their grids with. */
 #define BSI_MAX_CU_RESERVE 64
 int bsi_set_cu_reserve(int cus);
 int bsi_compute_cus(void);
 /* LayerNorm + modulate passes of the inference engine (one shared modulation row, no dropout): cus > 0 = launch them as PERSISTENT
  * kernels sized for `cus` compute units (every wave prefetches its next row; modulation vectors in LDS), the form
  * bsi_dit_forward_pair uses on its small partition; 0 (default; env BSI_LN_STREAM_CUS) = one row per wave over the whole chip.
- * Bit-identical results.  Process-wide, takes effect at the next launch. */
+ * Bit-identical results.  Per calling thread, takes effect at its next launch. */
 int bsi_set_ln_stream_cus(int cus);
 /* Tile queue of the persistent bf16 GEMM (K >= 512, more tiles than CUs): 1 = workgroups draw tile tickets from per-XCD counters in
  * device memory (and from the other XCDs' once their own is empty) instead of taking a static share, and the grid ignores the CU
  * reserve: a workgroup whose CU is held by a kernel of another stream leaves its share to the others, and no CU idles while RCCL
- * is quiet.  Same tiles, same arithmetic per tile: results are bit-identical to the static schedule.  Process-wide, takes effect
- * at the next launch; default 0 (env BSI_TILE_QUEUE overrides).  DPTrainer switches it on for steps that exchange gradients. */
+ * is quiet.  Same tiles, same arithmetic per tile: results are bit-identical to the static schedule.  Per calling thread, takes
+ * effect at its next launch; default 0 (env BSI_TILE_QUEUE overrides).  A launch that is being captured into a HIP graph always
+ * takes the static schedule.  DPTrainer(tile_queue=True) applies it to the launches of the backward only. */
 int bsi_set_tile_queue(int on);
 /* Schedule of the single-sweep attention backward (256 tokens, head dim 64: autograd of dit.py:43-44).  1 (default; env
  * BSI_ATTN_BWD_SKEW=0 overrides): the workgroup's two wave groups run half a trip apart, so that the softmax of one shares a SIMD with

@@ -335,10 +335,11 @@ extern "C" int bsi_cu_pair_create(int h_cus, bsi_cu_pair** out) {
         delete p;
         return BSI_ELAUNCH;
     }
-    p->ev.resize(2048);
+    p->ev.assign(2048, nullptr);
     for (hipEvent_t& ev : p->ev) {
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
             bsi_set_error("bsi_cu_pair_create: hipEventCreate failed");
+            (void)bsi_cu_pair_destroy(p);
             return BSI_ELAUNCH;
         }
     }
@@ -350,7 +351,8 @@ extern "C" int bsi_cu_pair_destroy(bsi_cu_pair* p) {
     if (!p) return BSI_OK;
     (void)hipStreamSynchronize(p->g);
     (void)hipStreamSynchronize(p->h);
-    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(p->g);
     (void)hipStreamDestroy(p->h);
     delete p;
@@ -445,14 +447,18 @@ extern "C" int bsi_dit_forward_pair(const bsi_dit_config* cfg, const bsi_dit_wei
         }
         return BSI_OK;
     };
-    while (pos[0] < ch[0].size() || pos[1] < ch[1].size()) {
-        for (int h = 0; h < 2; ++h)
-            if (pos[h] < ch[h].size())
-                if (int rc = segment(h)) return rc;
+    int rc_all = BSI_OK;
+    while (rc_all == BSI_OK && (pos[0] < ch[0].size() || pos[1] < ch[1].size())) {
+        for (int h = 0; h < 2 && rc_all == BSI_OK; ++h)
+            if (pos[h] < ch[h].size()) rc_all = segment(h);
     }
-    // join: the caller's stream continues behind both chains
-    for (int h = 0; h < 2; ++h)
-        if (pending[h]) PAIR_HIP(hipStreamWaitEvent(s, pending[h], 0));
+    // join: the caller's stream continues behind both chains -- also when a launch failed half way (whatever was enqueued on G and H
+    // still reads and writes the caller's buffers; the caller must not get ahead of it)
+    for (int h = 0; h < 2; ++h) {
+        hipEvent_t e = pair->take();
+        PAIR_HIP(hipEventRecord(e, st[h]));
+        PAIR_HIP(hipStreamWaitEvent(s, e, 0));
+    }
 #undef PAIR_HIP
-    return BSI_OK;
+    return rc_all;
 }

